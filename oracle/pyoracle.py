@@ -1,0 +1,158 @@
+"""ctypes binding of the CPU oracle (oracle/rr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by anything under rrmpg_amd/.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librroracle.so")
+
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i8p = ctypes.POINTER(ctypes.c_int8)
+_i64 = ctypes.c_int64
+_dbl = ctypes.c_double
+
+
+def build(force=False):
+    """Compile librroracle.so with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "rr_oracle.c")
+    if (force or not os.path.exists(_SO)
+            or os.path.getmtime(_SO) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librroracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.oracle_simulate_abc.argtypes = [_f64p, _i64, _dbl, _f64p, _i64,
+                                          _f64p, _f64p, ctypes.c_int]
+        L.oracle_simulate_abc.restype = None
+        L.oracle_simulate_hbvedu.argtypes = (
+            [_f64p, _f64p, _i8p, _f64p, _f64p, _i64] + [_dbl] * 4
+            + [_f64p, _i64] + [_f64p] * 5 + [ctypes.c_int])
+        L.oracle_simulate_hbvedu.restype = None
+        L.oracle_simulate_gr4j.argtypes = (
+            [_f64p, _f64p, _i64, _dbl, _dbl, _f64p, _i64] + [_f64p] * 3
+            + [ctypes.c_int])
+        L.oracle_simulate_gr4j.restype = ctypes.c_int
+        L.oracle_simulate_cemaneige.argtypes = (
+            [_f64p, _f64p, _f64p, _i64, _i64, _dbl, _dbl, _f64p, _i64]
+            + [_f64p] * 3 + [ctypes.c_int])
+        L.oracle_simulate_cemaneige.restype = None
+        L.oracle_simulate_cemaneigegr4j.argtypes = (
+            [_f64p] * 4 + [_i64, _i64] + [_dbl] * 4 + [_f64p, _i64]
+            + [_f64p] * 5 + [ctypes.c_int])
+        L.oracle_simulate_cemaneigegr4j.restype = ctypes.c_int
+        L.oracle_max_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _c(a, dtype=np.float64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    if a is None:
+        return None
+    if a.dtype == np.int8:
+        return a.ctypes.data_as(_i8p)
+    return a.ctypes.data_as(_f64p)
+
+
+def _params2d(params, k):
+    p = _c(params).reshape(-1, k)
+    return p, p.shape[0]
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+def simulate_abc(prec, initial_state, params, return_storage=False,
+                 nthreads=1):
+    prec = _c(prec)
+    p, n = _params2d(params, 3)
+    t = prec.size
+    q = np.zeros((t, n))
+    s = np.zeros((t, n)) if return_storage else None
+    lib().oracle_simulate_abc(_p(prec), t, float(initial_state), _p(p), n,
+                              _p(q), _p(s), nthreads)
+    return (q, s) if return_storage else q
+
+
+def simulate_hbvedu(temp, prec, month0, PE_m, T_m, inits, params,
+                    return_storage=False, nthreads=1):
+    """month0: 0..11 (already decremented, as run_hbvedu receives it)."""
+    temp, prec, PE_m, T_m = _c(temp), _c(prec), _c(PE_m), _c(T_m)
+    month0 = _c(month0, np.int8)
+    p, n = _params2d(params, 11)
+    t = prec.size
+    q = np.zeros((t, n))
+    st = [np.zeros((t, n)) if return_storage else None for _ in range(4)]
+    lib().oracle_simulate_hbvedu(
+        _p(temp), _p(prec), _p(month0), _p(PE_m), _p(T_m), t,
+        *[float(x) for x in inits], _p(p), n, _p(q), *[_p(a) for a in st],
+        nthreads)
+    return (q, *st) if return_storage else q
+
+
+def simulate_gr4j(prec, etp, inits, params, return_storage=False, nthreads=1):
+    prec, etp = _c(prec), _c(etp)
+    p, n = _params2d(params, 4)
+    t = prec.size
+    q = np.zeros((t, n))
+    st = [np.zeros((t, n)) if return_storage else None for _ in range(2)]
+    rc = lib().oracle_simulate_gr4j(_p(prec), _p(etp), t, float(inits[0]),
+                                    float(inits[1]), _p(p), n, _p(q),
+                                    *[_p(a) for a in st], nthreads)
+    if rc != 0:
+        raise IndexError("GR4J unit hydrograph has no ordinates (x4 <= 0)")
+    return (q, *st) if return_storage else q
+
+
+def simulate_cemaneige(prec, mean_temp, frac_solid, inits, params,
+                       return_storages=False, nthreads=1):
+    prec, mean_temp, frac_solid = _c(prec), _c(mean_temp), _c(frac_solid)
+    t, nl = prec.shape
+    p, n = _params2d(params, 2)
+    o = np.zeros((t, n))
+    g = np.zeros((t, nl, n)) if return_storages else None
+    e = np.zeros((t, nl, n)) if return_storages else None
+    lib().oracle_simulate_cemaneige(_p(prec), _p(mean_temp), _p(frac_solid),
+                                    t, nl, float(inits[0]), float(inits[1]),
+                                    _p(p), n, _p(o), _p(g), _p(e), nthreads)
+    return (o, g, e) if return_storages else o
+
+
+def simulate_cemaneigegr4j(prec, mean_temp, etp, frac_solid, inits, params,
+                           return_storages=False, nthreads=1):
+    prec, mean_temp, frac_solid = _c(prec), _c(mean_temp), _c(frac_solid)
+    etp = _c(etp)
+    t, nl = prec.shape
+    p, n = _params2d(params, 6)
+    q = np.zeros((t, n))
+    g = np.zeros((t, nl, n)) if return_storages else None
+    e = np.zeros((t, nl, n)) if return_storages else None
+    s = np.zeros((t, n)) if return_storages else None
+    r = np.zeros((t, n)) if return_storages else None
+    rc = lib().oracle_simulate_cemaneigegr4j(
+        _p(prec), _p(mean_temp), _p(etp), _p(frac_solid), t, nl,
+        *[float(x) for x in inits], _p(p), n, _p(q), _p(g), _p(e), _p(s),
+        _p(r), nthreads)
+    if rc != 0:
+        raise IndexError("GR4J unit hydrograph has no ordinates (x4 <= 0)")
+    return (q, g, e, s, r) if return_storages else q

@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def rel_err(a, b, floor=1e-9):
+    """max |a-b| / max(|b|, floor); NaN positions must coincide."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), "NaN pattern differs"
+    if a.size == 0:
+        return 0.0
+    ok = ~na
+    return float(np.max(np.abs(a[ok] - b[ok])
+                        / np.maximum(np.abs(b[ok]), floor), initial=0.0))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
