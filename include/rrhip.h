@@ -1,0 +1,192 @@
+/*
+ * rrhip.h -- C-ABI of librrhip.so, the MI355X (gfx950) ensemble
+ * rainfall-runoff engine.
+ *
+ * The reference (kratzert/RRMPG) has no FFI: its seam is the Python call
+ *     run_<model>(*forcing, *inits, params_record) -> tuple of [T] arrays
+ * made once per parameter set from Model.simulate()'s Python loop and from
+ * _loss() (reference: rrmpg/models/hbvedu.py:199-209 and :310-346, likewise
+ * abcmodel.py:168-186, gr4j.py:162-183, cemaneige.py:218-245,
+ * cemaneigegr4j.py:238-273).  Each entry point below replaces that loop AND
+ * the run_* function under it with ONE batched call over N parameter sets:
+ * argument order and meaning follow run_*'s signature, followed by the
+ * parameter block, the outputs, and the optional fused error metric.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every buffer is owned by the caller and
+ *     borrowed for the duration of the call;
+ *   - `params` is the reference's structured-dtype buffer unchanged: packed
+ *     all-float64 records in _param_list order, i.e. a row-major
+ *     double[N][k] (reference: hbvedu.py:63-66, abcmodel.py:53-55,
+ *     gr4j.py:57-60, cemaneige.py:64-65, cemaneigegr4j.py:67-72);
+ *   - 2-D outputs are [T][ld] row-major with the parameter-set axis
+ *     contiguous (the reference's qsim[T, N], hbvedu.py:191); 3-D storages
+ *     are [T][L][ld] (reference: cemaneige.py:219-224).  ld >= N;
+ *   - any output pointer may be NULL = "do not materialise it"
+ *     (return_storage=False in the reference);
+ *   - qobs/sse: if both non-NULL the kernel also accumulates, in time order,
+ *     sse[i] = sum_t (qobs[t] - qsim[t, i])^2  -- the numerator of
+ *     calc_mse / calc_nse (reference: rrmpg/utils/metrics.py:131, :72) so a
+ *     Monte-Carlo sweep (rrmpg/tools/monte_carlo.py:66-71) need not move
+ *     qsim at all;
+ *   - return value: RR_OK or a negative RR_E_* code; rr_last_error() gives
+ *     the text.  Numerical trouble is not an error: NaN propagates exactly
+ *     as in the reference.  Nothing here falls back to a CPU path.
+ *
+ * Two families:
+ *   rr_<model>_simulate      host pointers; synchronous; the library moves
+ *                            data to the GPU, runs, and copies results back
+ *                            (drop-in for the reference's host-array seam).
+ *   rr_<model>_simulate_dev  device pointers on the current HIP device;
+ *                            enqueued on `stream` (a hipStream_t, may be
+ *                            NULL = default stream) and asynchronous;
+ *                            needs a caller-provided device workspace of
+ *                            rr_<model>_workspace_bytes() bytes.
+ */
+#ifndef RRHIP_H
+#define RRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_OK          0
+#define RR_E_NULL     -1  /* a required pointer is NULL                     */
+#define RR_E_SIZE     -2  /* negative or inconsistent size / ld < N         */
+#define RR_E_HIP      -3  /* a HIP runtime call failed                      */
+#define RR_E_PARAM    -4  /* parameter value the kernels cannot represent   */
+#define RR_E_NODEVICE -5  /* no usable gfx950 device                        */
+#define RR_E_WORKSPACE -6 /* workspace missing or too small                 */
+
+/* Cemaneige: elevation layers held in registers per parameter set. */
+#define RR_CEMANEIGE_MAX_LAYERS 8
+/* GR4J: largest x4 the LDS unit-hydrograph tier holds (ceil(x4) ordinates
+ * for UH1, ceil(2*x4+1) for UH2). */
+#define RR_GR4J_MAX_X4 20.0
+
+int rr_version(void);
+/* Number of visible HIP devices (0 if none / no driver). */
+int rr_device_count(void);
+/* Text of the last error on the calling thread ("" if none). */
+const char *rr_last_error(void);
+
+/* ---- ABC model -------------------------------------------------------
+ * replaces run_abcmodel(prec, initial_state, params)
+ * (reference: rrmpg/models/abcmodel_model.py:15-60); params = {a, b, c}. */
+size_t rr_abc_workspace_bytes(int64_t T, int64_t N);
+int rr_abc_simulate_dev(const double *prec, int64_t T, double initial_state,
+                        const double *params, int64_t N,
+                        double *qsim, double *storage, int64_t ld,
+                        const double *qobs, double *sse,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int rr_abc_simulate(const double *prec, int64_t T, double initial_state,
+                    const double *params, int64_t N,
+                    double *qsim, double *storage,
+                    const double *qobs, double *sse);
+
+/* ---- HBV-Edu ---------------------------------------------------------
+ * replaces run_hbvedu(temp, prec, month, PE_m, T_m, snow_init, soil_init,
+ *                     s1_init, s2_init, params)
+ * (reference: rrmpg/models/hbvedu_model.py:15-129); month holds 0..11
+ * (already decremented, hbvedu.py:164); PE_m, T_m have 12 entries;
+ * params = {T_t, DD, FC, Beta, C, PWP, K_0, K_1, K_2, K_p, L}. */
+size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N);
+int rr_hbvedu_simulate_dev(const double *temp, const double *prec,
+                           const int8_t *month, const double *PE_m,
+                           const double *T_m, int64_t T,
+                           double snow_init, double soil_init, double s1_init,
+                           double s2_init, const double *params, int64_t N,
+                           double *qsim, double *snow, double *soil,
+                           double *s1, double *s2, int64_t ld,
+                           const double *qobs, double *sse,
+                           void *workspace, size_t workspace_bytes,
+                           void *stream);
+int rr_hbvedu_simulate(const double *temp, const double *prec,
+                       const int8_t *month, const double *PE_m,
+                       const double *T_m, int64_t T,
+                       double snow_init, double soil_init, double s1_init,
+                       double s2_init, const double *params, int64_t N,
+                       double *qsim, double *snow, double *soil, double *s1,
+                       double *s2, const double *qobs, double *sse);
+
+/* ---- GR4J ------------------------------------------------------------
+ * replaces run_gr4j(prec, etp, s_init, r_init, params)
+ * (reference: rrmpg/models/gr4j_model.py:15-192); params = {x1,x2,x3,x4};
+ * s_init / r_init are fractions of x1 / x3 (gr4j_model.py:64-65); out[k] is
+ * the state after day k (the reference's artificial step 0 is dropped,
+ * gr4j_model.py:157).  RR_E_PARAM if any x4 gives no ordinates
+ * (ceil(x4) < 1: the reference raises IndexError) or x4 > RR_GR4J_MAX_X4. */
+size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N);
+int rr_gr4j_simulate_dev(const double *prec, const double *etp, int64_t T,
+                         double s_init, double r_init,
+                         const double *params, int64_t N,
+                         double *qsim, double *s_store, double *r_store,
+                         int64_t ld, const double *qobs, double *sse,
+                         void *workspace, size_t workspace_bytes,
+                         void *stream);
+int rr_gr4j_simulate(const double *prec, const double *etp, int64_t T,
+                     double s_init, double r_init,
+                     const double *params, int64_t N,
+                     double *qsim, double *s_store, double *r_store,
+                     const double *qobs, double *sse);
+
+/* ---- Cemaneige snow routine -------------------------------------------
+ * replaces run_cemaneige(prec, mean_temp, frac_solid_prec, snow_pack_init,
+ *                        thermal_state_init, params)
+ * (reference: rrmpg/models/cemaneige_model.py:15-126); the three forcing
+ * arrays are [T][L] row-major; params = {CTG, Kf}; G, eTG are [T][L][ld].
+ * 1 <= L <= RR_CEMANEIGE_MAX_LAYERS else RR_E_PARAM.  qobs/sse compare
+ * against `outflow`. */
+size_t rr_cemaneige_workspace_bytes(int64_t T, int64_t L, int64_t N);
+int rr_cemaneige_simulate_dev(const double *prec, const double *mean_temp,
+                              const double *frac_solid_prec, int64_t T,
+                              int64_t L, double snow_pack_init,
+                              double thermal_state_init,
+                              const double *params, int64_t N,
+                              double *outflow, double *G, double *eTG,
+                              int64_t ld, const double *qobs, double *sse,
+                              void *workspace, size_t workspace_bytes,
+                              void *stream);
+int rr_cemaneige_simulate(const double *prec, const double *mean_temp,
+                          const double *frac_solid_prec, int64_t T, int64_t L,
+                          double snow_pack_init, double thermal_state_init,
+                          const double *params, int64_t N,
+                          double *outflow, double *G, double *eTG,
+                          const double *qobs, double *sse);
+
+/* ---- Cemaneige + GR4J coupled ------------------------------------------
+ * replaces run_cemaneigegr4j(prec, mean_temp, etp, frac_solid_prec,
+ *                            snow_pack_init, thermal_state_init, s_init,
+ *                            r_init, params)
+ * (reference: rrmpg/models/cemaneigegr4j_model.py:16-63);
+ * params = {CTG, Kf, x1, x2, x3, x4}.  One fused pass: the snow routine's
+ * outflow feeds GR4J's precipitation in registers, no [T] intermediate. */
+size_t rr_cemaneigegr4j_workspace_bytes(int64_t T, int64_t L, int64_t N);
+int rr_cemaneigegr4j_simulate_dev(const double *prec, const double *mean_temp,
+                                  const double *etp,
+                                  const double *frac_solid_prec, int64_t T,
+                                  int64_t L, double snow_pack_init,
+                                  double thermal_state_init, double s_init,
+                                  double r_init, const double *params,
+                                  int64_t N, double *qsim, double *G,
+                                  double *eTG, double *s_store,
+                                  double *r_store, int64_t ld,
+                                  const double *qobs, double *sse,
+                                  void *workspace, size_t workspace_bytes,
+                                  void *stream);
+int rr_cemaneigegr4j_simulate(const double *prec, const double *mean_temp,
+                              const double *etp, const double *frac_solid_prec,
+                              int64_t T, int64_t L, double snow_pack_init,
+                              double thermal_state_init, double s_init,
+                              double r_init, const double *params, int64_t N,
+                              double *qsim, double *G, double *eTG,
+                              double *s_store, double *r_store,
+                              const double *qobs, double *sse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRHIP_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of librrhip.so (include/rrhip.h) -- the only compute path.
+
+There is deliberately no fallback: if the shared library is missing, or no
+MI355X is visible when a simulation is requested, a RuntimeError is raised.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librrhip.so")
+
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i8p = ctypes.POINTER(ctypes.c_int8)
+_i64 = ctypes.c_int64
+_dbl = ctypes.c_double
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+RR_OK = 0
+ERROR_NAMES = {-1: "RR_E_NULL", -2: "RR_E_SIZE", -3: "RR_E_HIP",
+               -4: "RR_E_PARAM", -5: "RR_E_NODEVICE", -6: "RR_E_WORKSPACE"}
+
+# name -> (restype, argtypes); mirrors include/rrhip.h one to one
+_SIGNATURES = {
+    "rr_version": (ctypes.c_int, []),
+    "rr_device_count": (ctypes.c_int, []),
+    "rr_last_error": (ctypes.c_char_p, []),
+    "rr_abc_workspace_bytes": (_sz, [_i64, _i64]),
+    "rr_abc_simulate_dev": (ctypes.c_int, [_vp, _i64, _dbl, _vp, _i64, _vp,
+                                           _vp, _i64, _vp, _vp, _vp, _sz,
+                                           _vp]),
+    "rr_abc_simulate": (ctypes.c_int, [_f64p, _i64, _dbl, _f64p, _i64, _f64p,
+                                       _f64p, _f64p, _f64p]),
+    "rr_hbvedu_workspace_bytes": (_sz, [_i64, _i64]),
+    "rr_hbvedu_simulate_dev": (ctypes.c_int,
+                               [_vp] * 5 + [_i64] + [_dbl] * 4 + [_vp, _i64]
+                               + [_vp] * 5 + [_i64, _vp, _vp, _vp, _sz, _vp]),
+    "rr_hbvedu_simulate": (ctypes.c_int,
+                           [_f64p, _f64p, _i8p, _f64p, _f64p, _i64]
+                           + [_dbl] * 4 + [_f64p, _i64] + [_f64p] * 7),
+    "rr_gr4j_workspace_bytes": (_sz, [_i64, _i64]),
+    "rr_gr4j_simulate_dev": (ctypes.c_int,
+                             [_vp, _vp, _i64, _dbl, _dbl, _vp, _i64]
+                             + [_vp] * 3 + [_i64, _vp, _vp, _vp, _sz, _vp]),
+    "rr_gr4j_simulate": (ctypes.c_int,
+                         [_f64p, _f64p, _i64, _dbl, _dbl, _f64p, _i64]
+                         + [_f64p] * 5),
+    "rr_cemaneige_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "rr_cemaneige_simulate_dev": (ctypes.c_int,
+                                  [_vp] * 3 + [_i64, _i64, _dbl, _dbl, _vp,
+                                               _i64] + [_vp] * 3
+                                  + [_i64, _vp, _vp, _vp, _sz, _vp]),
+    "rr_cemaneige_simulate": (ctypes.c_int,
+                              [_f64p] * 3 + [_i64, _i64, _dbl, _dbl, _f64p,
+                                             _i64] + [_f64p] * 5),
+    "rr_cemaneigegr4j_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "rr_cemaneigegr4j_simulate_dev": (ctypes.c_int,
+                                      [_vp] * 4 + [_i64, _i64] + [_dbl] * 4
+                                      + [_vp, _i64] + [_vp] * 5
+                                      + [_i64, _vp, _vp, _vp, _sz, _vp]),
+    "rr_cemaneigegr4j_simulate": (ctypes.c_int,
+                                  [_f64p] * 4 + [_i64, _i64] + [_dbl] * 4
+                                  + [_f64p, _i64] + [_f64p] * 7),
+}
+
+_lib = None
+
+
+def exported_names():
+    """Every entry point include/rrhip.h declares."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load librrhip.so (once).  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "librrhip.so is not built (%s). Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C rrmpg_amd/csrc`. There is no CPU fallback."
+                % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().rr_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != RR_OK:
+        raise RuntimeError("%s failed with %s: %s"
+                           % (what, ERROR_NAMES.get(rc, rc), last_error()))
+
+
+def device_count():
+    return int(load().rr_device_count())
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise RuntimeError("rrmpg_amd needs an AMD MI355X (gfx950) GPU: no "
+                           "HIP device is visible and there is no CPU path.")
+
+
+def f64(a):
+    """C-contiguous float64 view/copy + its pointer (None passes NULL)."""
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_f64p)
+
+
+def params_block(params, k):
+    """The structured parameter array as the C-ABI's double[N][k] block.
+
+    The reference's _dtype is a packed all-float64 record, so its buffer
+    already is that block; this only makes it
+    contiguous and reinterprets it.
+    """
+    p = np.ascontiguousarray(params)
+    if p.dtype.itemsize != 8 * k:
+        raise TypeError("parameter records must hold %d float64 fields" % k)
+    flat = p.view(np.float64).reshape(-1, k)
+    return flat, flat.ctypes.data_as(_f64p), flat.shape[0]

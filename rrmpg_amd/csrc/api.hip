@@ -1,0 +1,234 @@
+// api.hip -- error plumbing, device queries and the host-pointer entry points
+// (rr_<model>_simulate) of the C-ABI declared in include/rrhip.h.
+//
+// The host-pointer family is the drop-in for the reference's seam, where
+// Model.simulate() hands numpy arrays to run_* and gets numpy arrays back
+// (reference: rrmpg/models/hbvedu.py:190-214).  It owns no state between
+// calls: it uploads the (small, shared) forcing and the parameter block,
+// sweeps the parameter-set axis in column blocks sized to the free HBM, runs
+// the *_simulate_dev entry point on each block and copies each [T][nc] device
+// slab into the caller's [T][N] array with a pitched copy.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void rr_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *rr_last_error(void) { return g_err; }
+extern "C" int rr_version(void) { return 100; }
+
+extern "C" int rr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int rr_check_common(const char *who, int64_t T, int64_t N, int64_t ld,
+                    const void *params, const void *qobs, const void *sse)
+{
+    g_err[0] = 0;
+    if (T < 0 || N < 0) {
+        rr_set_error("%s: negative size (T=%lld, N=%lld)", who, (long long)T,
+                     (long long)N);
+        return RR_E_SIZE;
+    }
+    if (ld < N) {
+        rr_set_error("%s: ld=%lld < N=%lld", who, (long long)ld, (long long)N);
+        return RR_E_SIZE;
+    }
+    if (N > 0 && !params) {
+        rr_set_error("%s: params is NULL", who);
+        return RR_E_NULL;
+    }
+    if ((qobs == nullptr) != (sse == nullptr)) {
+        rr_set_error("%s: qobs and sse must be given together", who);
+        return RR_E_NULL;
+    }
+    return RR_OK;
+}
+
+// --------------------------------------------------------------------------
+// host-pointer family
+// --------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    int alloc(size_t bytes)
+    {
+        if (bytes == 0) bytes = 8;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            rr_set_error("hipMalloc(%zu) failed: %s", bytes,
+                         hipGetErrorString(e));
+            return RR_E_HIP;
+        }
+        return RR_OK;
+    }
+    int upload(const void *src, size_t bytes)
+    {
+        int rc = alloc(bytes);
+        if (rc != RR_OK) return rc;
+        if (bytes) RR_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return RR_OK;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+int require_device()
+{
+    if (rr_device_count() < 1) {
+        rr_set_error("no HIP device visible: librrhip has no CPU path");
+        return RR_E_NODEVICE;
+    }
+    return RR_OK;
+}
+
+// One host output array [T][rows_per_t][N] mirrored by a device slab
+// [T][rows_per_t][nc].
+struct OutSpec {
+    double *host;          // may be NULL (not requested)
+    int64_t rows_per_t;    // 1, or L for the [T][L][N] storages
+};
+
+// Column-block width so that all requested slabs fit in a fraction of the
+// free device memory.
+int64_t pick_block(int64_t T, int64_t N, const std::vector<OutSpec> &outs)
+{
+    size_t per_col = 0;
+    for (const OutSpec &o : outs)
+        if (o.host) per_col += (size_t)T * (size_t)o.rows_per_t * 8;
+    if (per_col == 0) return N;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+    size_t budget = free_b / 2;
+    int64_t nc = (int64_t)(budget / per_col);
+    nc = (nc / 256) * 256;
+    if (nc < 256) nc = 256;
+    return nc < N ? nc : N;
+}
+
+// Runs `launch(i0, nc, slabs, d_sse)` for every column block and gathers the
+// slabs into the host arrays.
+template <class Launch>
+int sweep_blocks(int64_t T, int64_t N, const std::vector<OutSpec> &outs,
+                 double *sse_host, Launch launch)
+{
+    const int64_t nc_max = pick_block(T, N, outs);
+    std::vector<DevBuf> slabs(outs.size());
+    for (size_t k = 0; k < outs.size(); ++k)
+        if (outs[k].host) {
+            int rc = slabs[k].alloc((size_t)T * outs[k].rows_per_t * nc_max * 8);
+            if (rc != RR_OK) return rc;
+        }
+    DevBuf d_sse;
+    if (sse_host) {
+        int rc = d_sse.alloc((size_t)nc_max * 8);
+        if (rc != RR_OK) return rc;
+    }
+    std::vector<double *> ptrs(outs.size());
+    for (size_t k = 0; k < outs.size(); ++k) ptrs[k] = slabs[k].as<double>();
+
+    for (int64_t i0 = 0; i0 < N; i0 += nc_max) {
+        const int64_t nc = (N - i0 < nc_max) ? (N - i0) : nc_max;
+        int rc = launch(i0, nc, ptrs.data(), d_sse.as<double>());
+        if (rc != RR_OK) return rc;
+        RR_HIP(hipStreamSynchronize(nullptr));
+        for (size_t k = 0; k < outs.size(); ++k) {
+            if (!outs[k].host) continue;
+            RR_HIP(hipMemcpy2D(outs[k].host + i0, (size_t)N * 8, ptrs[k],
+                               (size_t)nc * 8, (size_t)nc * 8,
+                               (size_t)T * outs[k].rows_per_t,
+                               hipMemcpyDeviceToHost));
+        }
+        if (sse_host)
+            RR_HIP(hipMemcpy(sse_host + i0, d_sse.p, (size_t)nc * 8,
+                             hipMemcpyDeviceToHost));
+    }
+    return RR_OK;
+}
+
+}  // namespace
+
+extern "C" int rr_abc_simulate(const double *prec, int64_t T,
+                               double initial_state, const double *params,
+                               int64_t N, double *qsim, double *storage,
+                               const double *qobs, double *sse)
+{
+    int rc = rr_check_common("rr_abc_simulate", T, N, N, params, qobs, sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if (!prec) { rr_set_error("rr_abc_simulate: prec is NULL"); return RR_E_NULL; }
+    if ((rc = require_device()) != RR_OK) return rc;
+    DevBuf d_prec, d_par, d_qobs, ws;
+    if ((rc = d_prec.upload(prec, (size_t)T * 8)) != RR_OK) return rc;
+    if ((rc = d_par.upload(params, (size_t)N * 3 * 8)) != RR_OK) return rc;
+    if (qobs && (rc = d_qobs.upload(qobs, (size_t)T * 8)) != RR_OK) return rc;
+    const size_t wsb = rr_abc_workspace_bytes(T, N);
+    if ((rc = ws.alloc(wsb)) != RR_OK) return rc;
+    std::vector<OutSpec> outs = {{qsim, 1}, {storage, 1}};
+    return sweep_blocks(T, N, outs, sse,
+        [&](int64_t i0, int64_t nc, double **o, double *d_sse) {
+            return rr_abc_simulate_dev(
+                d_prec.as<double>(), T, initial_state,
+                d_par.as<double>() + i0 * 3, nc, o[0], o[1], nc,
+                qobs ? d_qobs.as<double>() : nullptr, qobs ? d_sse : nullptr,
+                ws.p, wsb, nullptr);
+        });
+}
+
+extern "C" int rr_hbvedu_simulate(
+    const double *temp, const double *prec, const int8_t *month,
+    const double *PE_m, const double *T_m, int64_t T, double snow_init,
+    double soil_init, double s1_init, double s2_init, const double *params,
+    int64_t N, double *qsim, double *snow, double *soil, double *s1,
+    double *s2, const double *qobs, double *sse)
+{
+    int rc = rr_check_common("rr_hbvedu_simulate", T, N, N, params, qobs, sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if (!temp || !prec || !month || !PE_m || !T_m) {
+        rr_set_error("rr_hbvedu_simulate: NULL forcing pointer");
+        return RR_E_NULL;
+    }
+    if ((rc = require_device()) != RR_OK) return rc;
+    DevBuf d_temp, d_prec, d_month, d_pe, d_tm, d_par, d_qobs, ws;
+    if ((rc = d_temp.upload(temp, (size_t)T * 8)) != RR_OK) return rc;
+    if ((rc = d_prec.upload(prec, (size_t)T * 8)) != RR_OK) return rc;
+    if ((rc = d_month.upload(month, (size_t)T)) != RR_OK) return rc;
+    if ((rc = d_pe.upload(PE_m, 12 * 8)) != RR_OK) return rc;
+    if ((rc = d_tm.upload(T_m, 12 * 8)) != RR_OK) return rc;
+    if ((rc = d_par.upload(params, (size_t)N * 11 * 8)) != RR_OK) return rc;
+    if (qobs && (rc = d_qobs.upload(qobs, (size_t)T * 8)) != RR_OK) return rc;
+    const size_t wsb = rr_hbvedu_workspace_bytes(T, N);
+    if ((rc = ws.alloc(wsb)) != RR_OK) return rc;
+    std::vector<OutSpec> outs = {{qsim, 1}, {snow, 1}, {soil, 1}, {s1, 1},
+                                 {s2, 1}};
+    return sweep_blocks(T, N, outs, sse,
+        [&](int64_t i0, int64_t nc, double **o, double *d_sse) {
+            return rr_hbvedu_simulate_dev(
+                d_temp.as<double>(), d_prec.as<double>(),
+                d_month.as<int8_t>(), d_pe.as<double>(), d_tm.as<double>(), T,
+                snow_init, soil_init, s1_init, s2_init,
+                d_par.as<double>() + i0 * 11, nc, o[0], o[1], o[2], o[3],
+                o[4], nc, qobs ? d_qobs.as<double>() : nullptr,
+                qobs ? d_sse : nullptr, ws.p, wsb, nullptr);
+        });
+}

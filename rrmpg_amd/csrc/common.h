@@ -1,0 +1,45 @@
+// common.h -- shared helpers for the gfx950 kernels and the C-ABI layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/rrhip.h"
+
+// One parameter set per lane.  64 = one wavefront per workgroup: the time
+// loop needs no workgroup-level cooperation (the shared forcing arrives
+// through the scalar cache), so single-wave workgroups give the
+// dispatcher the finest granule to spread over 256 CUs x 4 SIMDs.
+#define RR_BLOCK 64
+
+// numba's max(a, b) / min(a, b): select(b > a, b, a) / select(b < a, b, a)
+// (numba/cpython/builtins.py do_minmax) -- so max(0, NaN) == 0.
+__device__ __forceinline__ double nb_max(double a, double b) {
+    return (b > a) ? b : a;
+}
+__device__ __forceinline__ double nb_min(double a, double b) {
+    return (b < a) ? b : a;
+}
+
+// ---- error plumbing (host) ------------------------------------------------
+void rr_set_error(const char *fmt, ...);
+
+#define RR_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) {                                             \
+            rr_set_error("%s failed: %s (%s:%d)", #call,                    \
+                         hipGetErrorString(_e), __FILE__, __LINE__);        \
+            return RR_E_HIP;                                                \
+        }                                                                   \
+    } while (0)
+
+static inline int64_t rr_ceil_div(int64_t a, int64_t b) {
+    return (a + b - 1) / b;
+}
+static inline size_t rr_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Common argument checks of the *_simulate_dev entry points.
+int rr_check_common(const char *who, int64_t T, int64_t N, int64_t ld,
+                    const void *params, const void *qobs, const void *sse);

@@ -1,0 +1,205 @@
+// hbvedu.hip -- HBV-Edu ensemble kernel for gfx950.
+//
+// Replaces run_hbvedu (reference: rrmpg/models/hbvedu_model.py:15-129) and
+// the per-parameter-set Python loop around it (reference:
+// rrmpg/models/hbvedu.py:199-209): one lane per parameter set, the four
+// reservoir states (snow, soil, s1, s2) live in registers for the whole
+// 30-year scan, the time loop runs inside the kernel.
+//
+// Data layout
+//   forcing  : a packed per-day record {temp, prec, temp - T_m[month],
+//              PE_m[month]} (32 B) built once by hbv_pack_forcing -- the
+//              month lookup and the (temp - T_m) subtraction are parameter
+//              independent, so they are hoisted out of the N-fold sweep with
+//              the identical fp64 operation the reference performs per set.
+//              The record address is wave-uniform, so it is fetched with ONE
+//              scalar s_load_dwordx8 per day into SGPRs (scalar cache ->
+//              L2), never through the vector memory path.
+//   params   : the reference's AoS double[N][11]; each lane reads its 11
+//              values once (88 B per set, amortised over T steps).
+//   outputs  : [T][ld] row-major, lane i <-> column i, so each wave stores
+//              512 contiguous bytes per output per day.
+//
+// Arithmetic follows the reference statement by statement in fp64 without
+// FMA contraction (-ffp-contract=off); only pow() is OCML's instead of libm's.
+#include "common.h"
+
+struct __attribute__((aligned(32))) HbvDay {
+    double temp;   // temp[t]
+    double prec;   // prec[t]
+    double dtemp;  // temp[t] - T_m[month[t]]        (hbvedu_model.py:102)
+    double pe_m;   // PE_m[month[t]]
+};
+
+__global__ void hbv_pack_forcing(const double *__restrict__ temp,
+                                 const double *__restrict__ prec,
+                                 const int8_t *__restrict__ month,
+                                 const double *__restrict__ PE_m,
+                                 const double *__restrict__ T_m, int64_t T,
+                                 HbvDay *__restrict__ days)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    int m = month[t];
+    m = m < 0 ? 0 : (m > 11 ? 11 : m);   // memory safety only; the wrapper
+                                         // has already validated 1..12
+    HbvDay d;
+    d.temp = temp[t];
+    d.prec = prec[t];
+    d.dtemp = temp[t] - T_m[m];
+    d.pe_m = PE_m[m];
+    days[t] = d;
+}
+
+template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE>
+__global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
+    const HbvDay *__restrict__ days, int64_t T, double snow_init,
+    double soil_init, double s1_init, double s2_init,
+    const double *__restrict__ params, int64_t N, double *__restrict__ qsim,
+    double *__restrict__ snow_out, double *__restrict__ soil_out,
+    double *__restrict__ s1_out, double *__restrict__ s2_out, int64_t ld,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = i < N;
+    // tail lanes recompute the last set and simply do not store
+    const double *p = params + (active ? i : N - 1) * 11;
+    const double T_t = p[0], DD = p[1], FC = p[2], Beta = p[3], C = p[4],
+                 PWP = p[5], K_0 = p[6], K_1 = p[7], K_2 = p[8], K_p = p[9],
+                 L = p[10];
+
+    double snow = snow_init, soil = soil_init, s1 = s1_init, s2 = s2_init;
+    double acc = 0.0;
+    int64_t off = i;   // t * ld + i
+
+    // t = 0: qsim[0] = 0, state[0] = init (hbvedu_model.py:71-81)
+    if (active) {
+        if (WRITE_Q) qsim[off] = 0.0;
+        if (WRITE_S) {
+            snow_out[off] = snow;
+            soil_out[off] = soil;
+            s1_out[off] = s1;
+            s2_out[off] = s2;
+        }
+    }
+    if (WITH_SSE) {
+        const double d = qobs[0] - 0.0;
+        acc = d * d;
+    }
+
+    for (int64_t t = 1; t < T; ++t) {
+        const HbvDay f = days[t];          // wave-uniform -> s_load_dwordx8
+        off += ld;
+
+        // snow routine (hbvedu_model.py:87-96)
+        const double melt = DD * (f.temp - T_t);
+        const bool cold = f.temp < T_t;
+        const double snow_n = cold ? snow + f.prec : nb_max(0.0, snow - melt);
+        const double liquid_water = cold ? 0.0 : f.prec + nb_min(snow, melt);
+
+        // effective precipitation (:99)
+        const double prec_eff = liquid_water * pow(soil / FC, Beta);
+
+        // potential / actual evapotranspiration (:102-108)
+        const double pe = (1 + C * f.dtemp) * f.pe_m;
+        const double ea = (soil > PWP) ? pe : pe * (soil / PWP);
+
+        // soil moisture (:111)
+        const double soil_n = soil + liquid_water - prec_eff - ea;
+
+        // near-surface reservoir (:114-118)
+        const double over = nb_max(0.0, s1 - L) * K_0;
+        const double s1_n = s1 + prec_eff - over - s1 * K_1 - s1 * K_p;
+
+        // base-flow reservoir (:121-123)
+        const double s2_n = s2 + s1 * K_p - s2 * K_2;
+
+        // discharge mixes old and new states (:125-127)
+        const double q = over + s1_n * K_1 + s2_n * K_2;
+
+        snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
+
+        if (active) {
+            if (WRITE_Q) qsim[off] = q;
+            if (WRITE_S) {
+                snow_out[off] = snow;
+                soil_out[off] = soil;
+                s1_out[off] = s1;
+                s2_out[off] = s2;
+            }
+        }
+        if (WITH_SSE) {
+            const double d = qobs[t] - q;  // wave-uniform scalar load
+            acc += d * d;
+        }
+    }
+    if (WITH_SSE && active) sse[i] = acc;
+}
+
+extern "C" size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N)
+{
+    (void)N;
+    if (T < 0) T = 0;
+    return rr_align256((size_t)(T > 0 ? T : 1) * sizeof(HbvDay));
+}
+
+template <bool Q, bool S, bool E>
+static void launch_hbv(dim3 grid, hipStream_t st, const HbvDay *days,
+                       int64_t T, double a, double b, double c, double d,
+                       const double *params, int64_t N, double *qsim,
+                       double *snow, double *soil, double *s1, double *s2,
+                       int64_t ld, const double *qobs, double *sse)
+{
+    hipLaunchKernelGGL((hbvedu_kernel<Q, S, E>), grid, dim3(RR_BLOCK), 0, st,
+                       days, T, a, b, c, d, params, N, qsim, snow, soil, s1,
+                       s2, ld, qobs, sse);
+}
+
+extern "C" int rr_hbvedu_simulate_dev(
+    const double *temp, const double *prec, const int8_t *month,
+    const double *PE_m, const double *T_m, int64_t T, double snow_init,
+    double soil_init, double s1_init, double s2_init, const double *params,
+    int64_t N, double *qsim, double *snow, double *soil, double *s1,
+    double *s2, int64_t ld, const double *qobs, double *sse, void *workspace,
+    size_t workspace_bytes, void *stream)
+{
+    int rc = rr_check_common("rr_hbvedu_simulate_dev", T, N, ld, params, qobs,
+                             sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if (!temp || !prec || !month || !PE_m || !T_m) {
+        rr_set_error("rr_hbvedu_simulate_dev: NULL forcing pointer");
+        return RR_E_NULL;
+    }
+    const bool any_s = snow || soil || s1 || s2;
+    if (any_s && !(snow && soil && s1 && s2)) {
+        rr_set_error("rr_hbvedu_simulate_dev: pass all four storage outputs "
+                     "or none");
+        return RR_E_NULL;
+    }
+    if (!workspace || workspace_bytes < rr_hbvedu_workspace_bytes(T, N)) {
+        rr_set_error("rr_hbvedu_simulate_dev: workspace too small");
+        return RR_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HbvDay *days = (HbvDay *)workspace;
+    hipLaunchKernelGGL(hbv_pack_forcing, dim3((unsigned)rr_ceil_div(T, 256)),
+                       dim3(256), 0, st, temp, prec, month, PE_m, T_m, T,
+                       days);
+    const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK));
+    const bool e = qobs && sse;
+#define HBV_GO(Q, S, E)                                                     \
+    launch_hbv<Q, S, E>(grid, st, days, T, snow_init, soil_init, s1_init,   \
+                        s2_init, params, N, qsim, snow, soil, s1, s2, ld,   \
+                        qobs, sse)
+    if (qsim) {
+        if (any_s) { if (e) HBV_GO(true, true, true); else HBV_GO(true, true, false); }
+        else       { if (e) HBV_GO(true, false, true); else HBV_GO(true, false, false); }
+    } else {
+        if (any_s) { if (e) HBV_GO(false, true, true); else HBV_GO(false, true, false); }
+        else       { if (e) HBV_GO(false, false, true); else HBV_GO(false, false, false); }
+    }
+#undef HBV_GO
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
