@@ -121,6 +121,16 @@ def f64(a):
     return a, a.ctypes.data_as(_f64p)
 
 
+def f64s(*arrays):
+    """Contiguous float64 versions of `arrays` and their pointers.
+
+    Returns (keepalive, pointers): hold `keepalive` for as long as the
+    pointers are in use.
+    """
+    keep = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays]
+    return keep, [a.ctypes.data_as(_f64p) for a in keep]
+
+
 def params_block(params, k):
     """The structured parameter array as the C-ABI's double[N][k] block.
 

@@ -9,6 +9,7 @@
 // the *_simulate_dev entry point on each block and copies each [T][nc] device
 // slab into the caller's [T][N] array with a pitched copy.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -122,6 +123,11 @@ int64_t pick_block(int64_t T, int64_t N, const std::vector<OutSpec> &outs)
     int64_t nc = (int64_t)(budget / per_col);
     nc = (nc / 256) * 256;
     if (nc < 256) nc = 256;
+    // test hook: force a small column block to exercise the pitched gather
+    if (const char *env = getenv("RRHIP_MAX_BLOCK_COLS")) {
+        const long v = atol(env);
+        if (v > 0 && v < nc) nc = v;
+    }
     return nc < N ? nc : N;
 }
 
@@ -229,6 +235,116 @@ extern "C" int rr_hbvedu_simulate(
                 snow_init, soil_init, s1_init, s2_init,
                 d_par.as<double>() + i0 * 11, nc, o[0], o[1], o[2], o[3],
                 o[4], nc, qobs ? d_qobs.as<double>() : nullptr,
+                qobs ? d_sse : nullptr, ws.p, wsb, nullptr);
+        });
+}
+
+extern "C" int rr_gr4j_simulate(const double *prec, const double *etp,
+                                int64_t T, double s_init, double r_init,
+                                const double *params, int64_t N, double *qsim,
+                                double *s_store, double *r_store,
+                                const double *qobs, double *sse)
+{
+    int rc = rr_check_common("rr_gr4j_simulate", T, N, N, params, qobs, sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if (!prec || !etp) {
+        rr_set_error("rr_gr4j_simulate: NULL forcing pointer");
+        return RR_E_NULL;
+    }
+    if ((rc = require_device()) != RR_OK) return rc;
+    DevBuf d_prec, d_etp, d_par, d_qobs, ws;
+    if ((rc = d_prec.upload(prec, (size_t)T * 8)) != RR_OK) return rc;
+    if ((rc = d_etp.upload(etp, (size_t)T * 8)) != RR_OK) return rc;
+    if ((rc = d_par.upload(params, (size_t)N * 4 * 8)) != RR_OK) return rc;
+    if (qobs && (rc = d_qobs.upload(qobs, (size_t)T * 8)) != RR_OK) return rc;
+    const size_t wsb = rr_gr4j_workspace_bytes(T, N);
+    if ((rc = ws.alloc(wsb)) != RR_OK) return rc;
+    std::vector<OutSpec> outs = {{qsim, 1}, {s_store, 1}, {r_store, 1}};
+    return sweep_blocks(T, N, outs, sse,
+        [&](int64_t i0, int64_t nc, double **o, double *d_sse) {
+            return rr_gr4j_simulate_dev(
+                d_prec.as<double>(), d_etp.as<double>(), T, s_init, r_init,
+                d_par.as<double>() + i0 * 4, nc, o[0], o[1], o[2], nc,
+                qobs ? d_qobs.as<double>() : nullptr, qobs ? d_sse : nullptr,
+                ws.p, wsb, nullptr);
+        });
+}
+
+extern "C" int rr_cemaneige_simulate(
+    const double *prec, const double *mean_temp, const double *frac_solid_prec,
+    int64_t T, int64_t L, double snow_pack_init, double thermal_state_init,
+    const double *params, int64_t N, double *outflow, double *G, double *eTG,
+    const double *qobs, double *sse)
+{
+    int rc = rr_check_common("rr_cemaneige_simulate", T, N, N, params, qobs,
+                             sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if (L < 1) { rr_set_error("rr_cemaneige_simulate: L < 1"); return RR_E_PARAM; }
+    if (!prec || !mean_temp || !frac_solid_prec) {
+        rr_set_error("rr_cemaneige_simulate: NULL forcing pointer");
+        return RR_E_NULL;
+    }
+    if ((rc = require_device()) != RR_OK) return rc;
+    DevBuf d_prec, d_temp, d_frac, d_par, d_qobs, ws;
+    const size_t tl = (size_t)T * (size_t)L * 8;
+    if ((rc = d_prec.upload(prec, tl)) != RR_OK) return rc;
+    if ((rc = d_temp.upload(mean_temp, tl)) != RR_OK) return rc;
+    if ((rc = d_frac.upload(frac_solid_prec, tl)) != RR_OK) return rc;
+    if ((rc = d_par.upload(params, (size_t)N * 2 * 8)) != RR_OK) return rc;
+    if (qobs && (rc = d_qobs.upload(qobs, (size_t)T * 8)) != RR_OK) return rc;
+    const size_t wsb = rr_cemaneige_workspace_bytes(T, L, N);
+    if ((rc = ws.alloc(wsb)) != RR_OK) return rc;
+    std::vector<OutSpec> outs = {{outflow, 1}, {G, L}, {eTG, L}};
+    return sweep_blocks(T, N, outs, sse,
+        [&](int64_t i0, int64_t nc, double **o, double *d_sse) {
+            return rr_cemaneige_simulate_dev(
+                d_prec.as<double>(), d_temp.as<double>(), d_frac.as<double>(),
+                T, L, snow_pack_init, thermal_state_init,
+                d_par.as<double>() + i0 * 2, nc, o[0], o[1], o[2], nc,
+                qobs ? d_qobs.as<double>() : nullptr, qobs ? d_sse : nullptr,
+                ws.p, wsb, nullptr);
+        });
+}
+
+extern "C" int rr_cemaneigegr4j_simulate(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_solid_prec, int64_t T, int64_t L,
+    double snow_pack_init, double thermal_state_init, double s_init,
+    double r_init, const double *params, int64_t N, double *qsim, double *G,
+    double *eTG, double *s_store, double *r_store, const double *qobs,
+    double *sse)
+{
+    int rc = rr_check_common("rr_cemaneigegr4j_simulate", T, N, N, params,
+                             qobs, sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if (L < 1) { rr_set_error("rr_cemaneigegr4j_simulate: L < 1"); return RR_E_PARAM; }
+    if (!prec || !mean_temp || !etp || !frac_solid_prec) {
+        rr_set_error("rr_cemaneigegr4j_simulate: NULL forcing pointer");
+        return RR_E_NULL;
+    }
+    if ((rc = require_device()) != RR_OK) return rc;
+    DevBuf d_prec, d_temp, d_etp, d_frac, d_par, d_qobs, ws;
+    const size_t tl = (size_t)T * (size_t)L * 8;
+    if ((rc = d_prec.upload(prec, tl)) != RR_OK) return rc;
+    if ((rc = d_temp.upload(mean_temp, tl)) != RR_OK) return rc;
+    if ((rc = d_etp.upload(etp, (size_t)T * 8)) != RR_OK) return rc;
+    if ((rc = d_frac.upload(frac_solid_prec, tl)) != RR_OK) return rc;
+    if ((rc = d_par.upload(params, (size_t)N * 6 * 8)) != RR_OK) return rc;
+    if (qobs && (rc = d_qobs.upload(qobs, (size_t)T * 8)) != RR_OK) return rc;
+    const size_t wsb = rr_cemaneigegr4j_workspace_bytes(T, L, N);
+    if ((rc = ws.alloc(wsb)) != RR_OK) return rc;
+    std::vector<OutSpec> outs = {{qsim, 1}, {G, L}, {eTG, L}, {s_store, 1},
+                                 {r_store, 1}};
+    return sweep_blocks(T, N, outs, sse,
+        [&](int64_t i0, int64_t nc, double **o, double *d_sse) {
+            return rr_cemaneigegr4j_simulate_dev(
+                d_prec.as<double>(), d_temp.as<double>(), d_etp.as<double>(),
+                d_frac.as<double>(), T, L, snow_pack_init, thermal_state_init,
+                s_init, r_init, d_par.as<double>() + i0 * 6, nc, o[0], o[1],
+                o[2], o[3], o[4], nc, qobs ? d_qobs.as<double>() : nullptr,
                 qobs ? d_sse : nullptr, ws.p, wsb, nullptr);
         });
 }

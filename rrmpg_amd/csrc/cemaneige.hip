@@ -1,0 +1,372 @@
+// cemaneige.hip -- Cemaneige snow routine and the fused Cemaneige->GR4J
+// ensemble kernels for gfx950.
+//
+// Replaces run_cemaneige (reference: rrmpg/models/cemaneige_model.py:15-126),
+// run_cemaneigegr4j (reference: rrmpg/models/cemaneigegr4j_model.py:16-63)
+// and the per-set Python loops around them (reference:
+// rrmpg/models/cemaneige.py:218-245, rrmpg/models/cemaneigegr4j.py:238-273).
+//
+// One lane per parameter set.  Per elevation layer the snow pack G and its
+// thermal state eTG live in registers (L <= 8 layers, kernels are
+// instantiated per L so the layer loop is fully unrolled).  Everything that
+// does not depend on the parameters is hoisted out of the N-fold sweep by two
+// small pre-pass kernels, with the very operations the reference performs
+// per set:
+//   cema_pack    snow = prec * frac, rain = prec - snow     (:76-77)
+//   cema_gtresh  G_tresh[l] = 0.9 * 365.25 * mean_t(snow)   (:80), summed
+//                strictly left to right like numba's np.mean.
+// The per-day record {snow[L], rain[L], temp[L] (, etp)} is wave-uniform and
+// arrives through the scalar cache.
+//
+// In the coupled kernel the layer-mean outflow of the snow routine feeds
+// GR4J's precipitation in registers the same day; the [T] liquid-water
+// intermediate of the reference (cemaneigegr4j_model.py:57-62) never exists.
+#include "gr4j_core.h"
+
+// defined in gr4j.hip
+int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
+                 int *d_scan, hipStream_t st, int *n1cap, int *n2cap);
+
+// days: [T][D] doubles, D = 3*L + (with_etp ? 1 : 0):
+//   [0,L) snow, [L,2L) rain, [2L,3L) mean_temp, [3L] etp
+__global__ void cema_pack(const double *__restrict__ prec,
+                          const double *__restrict__ mean_temp,
+                          const double *__restrict__ frac,
+                          const double *__restrict__ etp, int64_t T, int L,
+                          int D, double *__restrict__ days)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= T * L) return;
+    const int64_t t = g / L;
+    const int l = (int)(g - t * L);
+    const double p = prec[g];
+    const double snow = p * frac[g];            // cemaneige_model.py:76
+    const double rain = p - snow;               // :77
+    double *d = days + t * D;
+    d[l] = snow;
+    d[L + l] = rain;
+    d[2 * L + l] = mean_temp[g];
+    if (etp && l == 0) d[3 * L] = etp[t];
+}
+
+// One workgroup per layer: the wave stages 256 days of snow in LDS, lane 0
+// adds them strictly in time order (numba's np.mean is a sequential sum).
+__global__ __launch_bounds__(256) void cema_gtresh(
+    const double *__restrict__ days, int64_t T, int D,
+    double *__restrict__ gtresh)
+{
+    __shared__ double buf[256];
+    const int l = blockIdx.x;
+    double c = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += 256) {
+        const int64_t t = t0 + threadIdx.x;
+        buf[threadIdx.x] = (t < T) ? days[t * D + l] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n = (int)((T - t0 < 256) ? (T - t0) : 256);
+            for (int k = 0; k < n; ++k) c += buf[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        gtresh[l] = 0.9 * 365.25 * (c / (double)T);       // :80
+}
+
+// One day of the snow routine for all L layers of one parameter set
+// (cemaneige_model.py:83-125).  Returns the layer-mean liquid outflow.
+template <int L>
+__device__ __forceinline__ double cema_day(
+    const double *__restrict__ day, const double *__restrict__ gtresh,
+    bool first, double snow_pack_init, double thermal_state_init, double CTG,
+    double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L])
+{
+    double c = 0.0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const double snow = day[l], rain = day[L + l], temp = day[2 * L + l];
+        double g, e;
+        if (first) {                                       // :85-96
+            g = snow_pack_init;
+            e = thermal_state_init;
+        } else {
+            g = G[l] + snow;
+            e = CTG * eTG[l] + one_minus_CTG * temp;
+        }
+        if (e > 0) e = 0.0;
+        double pot_melt = 0.0;                             // :99-106
+        if (e == 0 && temp > 0) {
+            pot_melt = Kf * temp;
+            if (pot_melt > g) pot_melt = g;
+        }
+        const double gt = gtresh[l];
+        const double ratio = (g < gt) ? g / gt : 1.0;      // :109-112
+        const double melt = (0.9 * ratio + 0.1) * pot_melt; // :115
+        g = g - melt;                                      // :118
+        G[l] = g;
+        eTG[l] = e;
+        c += rain + melt;                                  // :121, :125
+    }
+    return c / (double)L;
+}
+
+template <int L>
+__global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
+    const double *__restrict__ days, const double *__restrict__ gtresh,
+    int64_t T, double snow_pack_init, double thermal_state_init,
+    const double *__restrict__ params, int64_t N,
+    double *__restrict__ outflow, double *__restrict__ G_out,
+    double *__restrict__ eTG_out, int64_t ld,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = i < N;
+    const double *p = params + (active ? i : N - 1) * 2;
+    const double CTG = p[0], Kf = p[1];
+    const double omc = 1 - CTG;
+    double G[L], eTG[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
+    double acc = 0.0;
+    const bool wq = outflow != nullptr, ws = G_out != nullptr,
+               we = sse != nullptr;
+    for (int64_t t = 0; t < T; ++t) {
+        const double q = cema_day<L>(days + t * (3 * L), gtresh, t == 0,
+                                     snow_pack_init, thermal_state_init, CTG,
+                                     omc, Kf, G, eTG);
+        if (active) {
+            if (wq) outflow[t * ld + i] = q;
+            if (ws) {
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    G_out[(t * L + l) * ld + i] = G[l];
+                    eTG_out[(t * L + l) * ld + i] = eTG[l];
+                }
+            }
+        }
+        if (we) {
+            const double d = qobs[t] - q;
+            acc += d * d;
+        }
+    }
+    if (we && active) sse[i] = acc;
+}
+
+template <int L, class UH>
+__global__ __launch_bounds__(RR_BLOCK) void cemaneigegr4j_kernel(
+    const double *__restrict__ days, const double *__restrict__ gtresh,
+    int64_t T, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *__restrict__ params,
+    int64_t N, int n1cap, int n2cap, double *__restrict__ qsim,
+    double *__restrict__ G_out, double *__restrict__ eTG_out,
+    double *__restrict__ s_store, double *__restrict__ r_store, int64_t ld,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = i < N;
+    const double *p = params + (active ? i : N - 1) * 6;
+    const double CTG = p[0], Kf = p[1];
+    Gr4jPar P;
+    P.x1 = p[2]; P.x2 = p[3]; P.x3 = p[4]; P.x4 = p[5];
+    const double omc = 1 - CTG;
+    double G[L], eTG[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
+    UH uh;
+    if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
+    else uh.init(P.x4);
+    double s = s_init * P.x1, r = r_init * P.x3;
+    double acc = 0.0;
+    const bool wq = qsim != nullptr, ws = G_out != nullptr, we = sse != nullptr;
+    constexpr int D = 3 * L + 1;
+    for (int64_t t = 0; t < T; ++t) {
+        const double *day = days + t * D;
+        const double liquid = cema_day<L>(day, gtresh, t == 0, snow_pack_init,
+                                          thermal_state_init, CTG, omc, Kf, G,
+                                          eTG);
+        const double q = gr4j_step(P, s, r, uh, liquid, day[3 * L]);
+        if (active) {
+            if (wq) qsim[t * ld + i] = q;
+            if (ws) {
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    G_out[(t * L + l) * ld + i] = G[l];
+                    eTG_out[(t * L + l) * ld + i] = eTG[l];
+                }
+                s_store[t * ld + i] = s;
+                r_store[t * ld + i] = r;
+            }
+        }
+        if (we) {
+            const double d = qobs[t] - q;
+            acc += d * d;
+        }
+    }
+    if (we && active) sse[i] = acc;
+}
+
+// workspace: [0,256) x4 scan | [256,512) G_tresh[8] | days
+static size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp)
+{
+    if (T < 1) T = 1;
+    if (L < 1) L = 1;
+    return 512 + rr_align256((size_t)T * (size_t)(3 * L + (with_etp ? 1 : 0)) * 8);
+}
+
+extern "C" size_t rr_cemaneige_workspace_bytes(int64_t T, int64_t L, int64_t N)
+{
+    (void)N;
+    return cema_ws_bytes(T, L, false);
+}
+
+extern "C" size_t rr_cemaneigegr4j_workspace_bytes(int64_t T, int64_t L,
+                                                   int64_t N)
+{
+    (void)N;
+    return cema_ws_bytes(T, L, true);
+}
+
+static int cema_prepass(const double *prec, const double *mean_temp,
+                        const double *frac, const double *etp, int64_t T,
+                        int L, void *workspace, hipStream_t st,
+                        double **days_out, double **gt_out)
+{
+    const int D = 3 * L + (etp ? 1 : 0);
+    double *gt = (double *)((char *)workspace + 256);
+    double *days = (double *)((char *)workspace + 512);
+    hipLaunchKernelGGL(cema_pack, dim3((unsigned)rr_ceil_div(T * L, 256)),
+                       dim3(256), 0, st, prec, mean_temp, frac, etp, T, L, D,
+                       days);
+    hipLaunchKernelGGL(cema_gtresh, dim3((unsigned)L), dim3(256), 0, st, days,
+                       T, D, gt);
+    *days_out = days;
+    *gt_out = gt;
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+static int cema_check_layers(const char *who, int64_t L)
+{
+    if (L < 1 || L > RR_CEMANEIGE_MAX_LAYERS) {
+        rr_set_error("%s: %lld elevation layers; supported: 1..%d", who,
+                     (long long)L, RR_CEMANEIGE_MAX_LAYERS);
+        return RR_E_PARAM;
+    }
+    return RR_OK;
+}
+
+// calls f(std::integral_constant<int, L>) for the runtime L in 1..8
+template <class F>
+static inline void dispatch_layers(int L, F &&f)
+{
+    switch (L) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 5: f(std::integral_constant<int, 5>{}); break;
+    case 6: f(std::integral_constant<int, 6>{}); break;
+    case 7: f(std::integral_constant<int, 7>{}); break;
+    default: f(std::integral_constant<int, 8>{}); break;
+    }
+}
+
+extern "C" int rr_cemaneige_simulate_dev(
+    const double *prec, const double *mean_temp, const double *frac_solid_prec,
+    int64_t T, int64_t L, double snow_pack_init, double thermal_state_init,
+    const double *params, int64_t N, double *outflow, double *G, double *eTG,
+    int64_t ld, const double *qobs, double *sse, void *workspace,
+    size_t workspace_bytes, void *stream)
+{
+    int rc = rr_check_common("rr_cemaneige_simulate_dev", T, N, ld, params,
+                             qobs, sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if ((rc = cema_check_layers("rr_cemaneige_simulate_dev", L)) != RR_OK)
+        return rc;
+    if (!prec || !mean_temp || !frac_solid_prec) {
+        rr_set_error("rr_cemaneige_simulate_dev: NULL forcing pointer");
+        return RR_E_NULL;
+    }
+    if ((G == nullptr) != (eTG == nullptr)) {
+        rr_set_error("rr_cemaneige_simulate_dev: pass both G and eTG or none");
+        return RR_E_NULL;
+    }
+    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, false)) {
+        rr_set_error("rr_cemaneige_simulate_dev: workspace too small");
+        return RR_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double *days, *gt;
+    rc = cema_prepass(prec, mean_temp, frac_solid_prec, nullptr, T, (int)L,
+                      workspace, st, &days, &gt);
+    if (rc != RR_OK) return rc;
+    const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
+    const double *qo = (qobs && sse) ? qobs : nullptr;
+    dispatch_layers((int)L, [&](auto LL) {
+        cemaneige_kernel<LL.value><<<grid, block, 0, st>>>(
+            days, gt, T, snow_pack_init, thermal_state_init, params, N,
+            outflow, G, eTG, ld, qo, sse);
+    });
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+extern "C" int rr_cemaneigegr4j_simulate_dev(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_solid_prec, int64_t T, int64_t L,
+    double snow_pack_init, double thermal_state_init, double s_init,
+    double r_init, const double *params, int64_t N, double *qsim, double *G,
+    double *eTG, double *s_store, double *r_store, int64_t ld,
+    const double *qobs, double *sse, void *workspace, size_t workspace_bytes,
+    void *stream)
+{
+    int rc = rr_check_common("rr_cemaneigegr4j_simulate_dev", T, N, ld, params,
+                             qobs, sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if ((rc = cema_check_layers("rr_cemaneigegr4j_simulate_dev", L)) != RR_OK)
+        return rc;
+    if (!prec || !mean_temp || !etp || !frac_solid_prec) {
+        rr_set_error("rr_cemaneigegr4j_simulate_dev: NULL forcing pointer");
+        return RR_E_NULL;
+    }
+    const int ns = (G != nullptr) + (eTG != nullptr) + (s_store != nullptr)
+                   + (r_store != nullptr);
+    if (ns != 0 && ns != 4) {
+        rr_set_error("rr_cemaneigegr4j_simulate_dev: pass all four storage "
+                     "outputs or none");
+        return RR_E_NULL;
+    }
+    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true)) {
+        rr_set_error("rr_cemaneigegr4j_simulate_dev: workspace too small");
+        return RR_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int n1cap = 0, n2cap = 0;
+    rc = rr_gr4j_plan(params, N, 6, 5, (int *)workspace, st, &n1cap, &n2cap);
+    if (rc != RR_OK) return rc;
+    double *days, *gt;
+    rc = cema_prepass(prec, mean_temp, frac_solid_prec, etp, T, (int)L,
+                      workspace, st, &days, &gt);
+    if (rc != RR_OK) return rc;
+    const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
+    const double *qo = (qobs && sse) ? qobs : nullptr;
+    const size_t lds_bytes =
+        (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
+    dispatch_layers((int)L, [&](auto LL) {
+        if (n1cap == 0)
+            cemaneigegr4j_kernel<LL.value, UhRegs<3>><<<grid, block, 0, st>>>(
+                days, gt, T, snow_pack_init, thermal_state_init, s_init,
+                r_init, params, N, 0, 0, qsim, G, eTG, s_store, r_store, ld,
+                qo, sse);
+        else
+            cemaneigegr4j_kernel<LL.value, UhLds>
+                <<<grid, block, lds_bytes, st>>>(
+                    days, gt, T, snow_pack_init, thermal_state_init, s_init,
+                    r_init, params, N, n1cap, n2cap, qsim, G, eTG, s_store,
+                    r_store, ld, qo, sse);
+    });
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}

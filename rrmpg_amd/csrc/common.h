@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "../../include/rrhip.h"
 
 // One parameter set per lane.  64 = one wavefront per workgroup: the time
@@ -43,3 +45,19 @@ static inline size_t rr_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Common argument checks of the *_simulate_dev entry points.
 int rr_check_common(const char *who, int64_t T, int64_t N, int64_t ld,
                     const void *params, const void *qobs, const void *sse);
+
+// Turns three runtime flags into compile-time template arguments:
+// f(std::bool_constant<a>, std::bool_constant<b>, std::bool_constant<c>).
+template <class F>
+static inline void rr_dispatch3(bool a, bool b, bool c, F &&f)
+{
+    const std::true_type Y{};
+    const std::false_type N{};
+    if (a) {
+        if (b) { if (c) f(Y, Y, Y); else f(Y, Y, N); }
+        else   { if (c) f(Y, N, Y); else f(Y, N, N); }
+    } else {
+        if (b) { if (c) f(N, Y, Y); else f(N, Y, N); }
+        else   { if (c) f(N, N, Y); else f(N, N, N); }
+    }
+}

@@ -1,0 +1,191 @@
+// gr4j.hip -- GR4J ensemble kernel for gfx950.
+//
+// Replaces run_gr4j (reference: rrmpg/models/gr4j_model.py:15-157) and the
+// per-set Python loop in GR4J.simulate (reference: rrmpg/models/gr4j.py:
+// 162-183; its early `return` after the first set, gr4j.py:176-178, is NOT
+// reproduced -- every column is filled).
+//
+// One lane per parameter set; S and R in registers; the unit-hydrograph
+// convolution state in registers (x4 <= 3 launch-wide) or staged in LDS
+// (gr4j_core.h).  The shared {prec, etp} day record is wave-uniform and is
+// fetched with one scalar s_load_dwordx4 per day.
+#include "gr4j_core.h"
+
+struct __attribute__((aligned(16))) GrDay {
+    double prec;
+    double etp;
+};
+
+__global__ void gr4j_pack_forcing(const double *__restrict__ prec,
+                                  const double *__restrict__ etp, int64_t T,
+                                  GrDay *__restrict__ days)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    GrDay d;
+    d.prec = prec[t];
+    d.etp = etp[t];
+    days[t] = d;
+}
+
+// scan[0] = max over sets of ceil(x4) (as int, saturated), scan[1] = number
+// of sets whose x4 gives no ordinates (ceil(x4) < 1 or NaN).
+__global__ void gr4j_scan_x4(const double *__restrict__ params, int64_t N,
+                             int stride, int x4_index, int *__restrict__ scan)
+{
+    int mx = 0, bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double x4 = params[i * stride + x4_index];
+        const int n1 = gr4j_num_uh1(x4);
+        if (n1 < 1) bad++;
+        mx = n1 > mx ? n1 : mx;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int o = __shfl_xor(mx, m, 64);
+        mx = o > mx ? o : mx;
+        bad += __shfl_xor(bad, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&scan[0], mx);
+        if (bad) atomicAdd(&scan[1], bad);
+    }
+}
+
+template <class UH, bool Q, bool S, bool E>
+__global__ __launch_bounds__(RR_BLOCK) void gr4j_kernel(
+    const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
+    const double *__restrict__ params, int64_t N, int n1cap, int n2cap,
+    double *__restrict__ qsim, double *__restrict__ s_store,
+    double *__restrict__ r_store, int64_t ld,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = i < N;
+    const double *p = params + (active ? i : N - 1) * 4;
+    Gr4jPar P;
+    P.x1 = p[0]; P.x2 = p[1]; P.x3 = p[2]; P.x4 = p[3];
+
+    UH uh;
+    if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
+    else uh.init(P.x4);
+
+    double s = s_init * P.x1;   // gr4j_model.py:64
+    double r = r_init * P.x3;   // gr4j_model.py:65
+    double acc = 0.0;
+    int64_t off = i;
+
+    for (int64_t k = 0; k < T; ++k) {
+        const GrDay f = days[k];    // wave-uniform -> s_load_dwordx4
+        const double q = gr4j_step(P, s, r, uh, f.prec, f.etp);
+        if (active) {
+            if (Q) qsim[off] = q;
+            if (S) {
+                s_store[off] = s;
+                r_store[off] = r;
+            }
+        }
+        if (E) {
+            const double d = qobs[k] - q;
+            acc += d * d;
+        }
+        off += ld;
+    }
+    if (E && active) sse[i] = acc;
+}
+
+extern "C" size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N)
+{
+    (void)N;
+    if (T < 1) T = 1;
+    return 256 + rr_align256((size_t)T * sizeof(GrDay));
+}
+
+// Shared by gr4j.hip and cemaneige.hip: scans x4, returns the LDS capacities
+// (n1cap == 0 selects the register tier).  Synchronises the stream once.
+int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
+                 int *d_scan, hipStream_t st, int *n1cap, int *n2cap)
+{
+    RR_HIP(hipMemsetAsync(d_scan, 0, 2 * sizeof(int), st));
+    int blocks = (int)rr_ceil_div(N, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(gr4j_scan_x4, dim3(blocks), dim3(256), 0, st, params, N,
+                       stride, x4_index, d_scan);
+    int h[2] = {0, 0};
+    RR_HIP(hipMemcpyAsync(h, d_scan, sizeof(h), hipMemcpyDeviceToHost, st));
+    RR_HIP(hipStreamSynchronize(st));
+    if (h[1] > 0) {
+        rr_set_error("GR4J: %d parameter set(s) have ceil(x4) < 1 (or NaN): "
+                     "the unit hydrograph would have no ordinates (the "
+                     "reference raises IndexError there)", h[1]);
+        return RR_E_PARAM;
+    }
+    if ((double)h[0] > RR_GR4J_MAX_X4) {
+        rr_set_error("GR4J: x4 up to %d exceeds RR_GR4J_MAX_X4 = %g", h[0],
+                     (double)RR_GR4J_MAX_X4);
+        return RR_E_PARAM;
+    }
+    if (h[0] <= 3) {
+        *n1cap = 0;
+        *n2cap = 0;
+    } else {
+        *n1cap = h[0];
+        *n2cap = 2 * h[0] + 1;
+    }
+    return RR_OK;
+}
+
+extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
+                                    int64_t T, double s_init, double r_init,
+                                    const double *params, int64_t N,
+                                    double *qsim, double *s_store,
+                                    double *r_store, int64_t ld,
+                                    const double *qobs, double *sse,
+                                    void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    int rc = rr_check_common("rr_gr4j_simulate_dev", T, N, ld, params, qobs,
+                             sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if (!prec || !etp) {
+        rr_set_error("rr_gr4j_simulate_dev: NULL forcing pointer");
+        return RR_E_NULL;
+    }
+    if ((s_store == nullptr) != (r_store == nullptr)) {
+        rr_set_error("rr_gr4j_simulate_dev: pass both storage outputs or none");
+        return RR_E_NULL;
+    }
+    if (!workspace || workspace_bytes < rr_gr4j_workspace_bytes(T, N)) {
+        rr_set_error("rr_gr4j_simulate_dev: workspace too small");
+        return RR_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int *d_scan = (int *)workspace;
+    GrDay *days = (GrDay *)((char *)workspace + 256);
+    int n1cap = 0, n2cap = 0;
+    rc = rr_gr4j_plan(params, N, 4, 3, d_scan, st, &n1cap, &n2cap);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(gr4j_pack_forcing, dim3((unsigned)rr_ceil_div(T, 256)),
+                       dim3(256), 0, st, prec, etp, T, days);
+    const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
+    const bool q = qsim != nullptr, s = s_store != nullptr, e = qobs && sse;
+    const size_t lds_bytes =
+        (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
+    rr_dispatch3(q, s, e, [&](auto Q, auto S, auto E) {
+        if (n1cap == 0)
+            gr4j_kernel<UhRegs<3>, Q.value, S.value, E.value>
+                <<<grid, block, 0, st>>>(days, T, s_init, r_init, params, N, 0,
+                                         0, qsim, s_store, r_store, ld, qobs,
+                                         sse);
+        else
+            gr4j_kernel<UhLds, Q.value, S.value, E.value>
+                <<<grid, block, lds_bytes, st>>>(days, T, s_init, r_init,
+                                                 params, N, n1cap, n2cap, qsim,
+                                                 s_store, r_store, ld, qobs,
+                                                 sse);
+    });
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}

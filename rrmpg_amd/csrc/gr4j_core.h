@@ -1,0 +1,249 @@
+// gr4j_core.h -- per-lane GR4J state machine shared by the GR4J kernel and
+// the fused Cemaneige->GR4J kernel.
+//
+// Restates run_gr4j / _s_curve1 / _s_curve2 (reference:
+// rrmpg/models/gr4j_model.py:15-192) for one parameter set per lane.
+// Production store S and routing store R live in registers.  The two unit
+// hydrographs have a DATA-DEPENDENT length per lane (ceil(x4) and
+// ceil(2*x4+1) ordinates, gr4j_model.py:68-69), handled by two storage tiers
+// with identical arithmetic:
+//
+//   UhRegs<3>  x4 <= 3 for every set of the launch (the reference's default
+//              bounds, rrmpg/models/gr4j.py:51-54): 3 + 7 ordinates and
+//              3 + 7 convolution slots in registers, loops fully unrolled.
+//   UhLds      any x4 <= RR_GR4J_MAX_X4: ordinates and slots are staged in
+//              LDS as [slot][lane] (8-byte elements, lane-contiguous ->
+//              ds_read_b64 / ds_write_b64 are bank-conflict free) and the
+//              slot loop runs to the wave-uniform maximum length.
+//
+// In both, a slot j of a lane with n ordinates is updated as the reference
+// does (gr4j_model.py:130-136):  uh[j] = uh[j+1] + ord[j]*p  for j < n-1,
+// uh[n-1] = ord[n-1]*p; slots >= n are never read.
+#pragma once
+
+#include "common.h"
+
+struct Gr4jPar {
+    double x1, x2, x3, x4;
+};
+
+// _s_curve1 (gr4j_model.py:159-173); t is the integer ordinate index
+__device__ __forceinline__ double gr4j_s_curve1(int t, double x4)
+{
+    const double tf = (double)t;
+    if (t <= 0) return 0.0;
+    else if (tf < x4) return pow(tf / x4, 2.5);
+    else return 1.0;
+}
+
+// _s_curve2 (gr4j_model.py:176-192)
+__device__ __forceinline__ double gr4j_s_curve2(int t, double x4)
+{
+    const double tf = (double)t;
+    if (t <= 0) return 0.0;
+    else if (tf <= x4) return 0.5 * pow(tf / x4, 2.5);
+    else if (tf < 2 * x4) return 1 - 0.5 * pow(2 - tf / x4, 2.5);
+    else return 1.0;
+}
+
+// num_uh1 = ceil(x4), num_uh2 = ceil(2*x4+1) (gr4j_model.py:68-69), clamped
+// into int range; NaN gives 0 (invalid, rejected by the host scan).
+__device__ __forceinline__ int gr4j_num_uh1(double x4)
+{
+    const double c = ceil(x4);
+    return (c >= 1.0) ? ((c > 1e6) ? 1000000 : (int)c) : 0;
+}
+__device__ __forceinline__ int gr4j_num_uh2(double x4)
+{
+    const double c = ceil(2 * x4 + 1);
+    return (c >= 1.0) ? ((c > 2e6) ? 2000000 : (int)c) : 0;
+}
+
+// ---- register tier ---------------------------------------------------------
+template <int N1MAX>
+struct UhRegs {
+    static constexpr int N2MAX = 2 * N1MAX + 1;
+    double u1[N1MAX], u2[N2MAX], o1[N1MAX], o2[N2MAX];
+    int n1, n2;
+
+    __device__ __forceinline__ void init(double x4)
+    {
+        n1 = gr4j_num_uh1(x4);
+        n2 = gr4j_num_uh2(x4);
+        // ordinate j = S(j+1) - S(j) (gr4j_model.py:75-79); S(j) is carried
+        // over from the previous ordinate instead of being re-evaluated.
+        // Ordinates j >= n are never used.
+        double prev = 0.0;
+#pragma unroll
+        for (int j = 0; j < N1MAX; ++j) {
+            const double cur = gr4j_s_curve1(j + 1, x4);
+            o1[j] = cur - prev;
+            prev = cur;
+            u1[j] = 0.0;
+        }
+        prev = 0.0;
+#pragma unroll
+        for (int j = 0; j < N2MAX; ++j) {
+            const double cur = gr4j_s_curve2(j + 1, x4);
+            o2[j] = cur - prev;
+            prev = cur;
+            u2[j] = 0.0;
+        }
+    }
+
+    // shift-and-add both hydrographs; returns uh1[0], uh2[0]
+    __device__ __forceinline__ void route(double p1, double p2, double &head1,
+                                          double &head2)
+    {
+#pragma unroll
+        for (int j = 0; j < N1MAX; ++j) {
+            const double v = o1[j] * p1;
+            const double nxt = (j + 1 < N1MAX) ? u1[(j + 1 < N1MAX) ? j + 1 : j]
+                                               : 0.0;
+            u1[j] = (j + 1 < n1) ? nxt + v : v;
+        }
+#pragma unroll
+        for (int j = 0; j < N2MAX; ++j) {
+            const double v = o2[j] * p2;
+            const double nxt = (j + 1 < N2MAX) ? u2[(j + 1 < N2MAX) ? j + 1 : j]
+                                               : 0.0;
+            u2[j] = (j + 1 < n2) ? nxt + v : v;
+        }
+        head1 = u1[0];
+        head2 = u2[0];
+    }
+};
+
+// ---- LDS tier ---------------------------------------------------------------
+// Layout inside the workgroup's dynamic LDS (doubles, RR_BLOCK lanes wide):
+//   [0,         n1cap)           uh1 slots
+//   [n1cap,     n1cap+n2cap)     uh2 slots
+//   then the same again for the ordinates.
+struct UhLds {
+    double *base;        // this lane's column: base[slot * RR_BLOCK]
+    int n1cap, n2cap;    // launch-wide capacities (host scan of max x4)
+    int n1, n2;          // this lane's lengths
+    int n1w, n2w;        // wave-uniform loop bounds
+
+    __device__ __forceinline__ double &U1(int j) { return base[j * RR_BLOCK]; }
+    __device__ __forceinline__ double &U2(int j) {
+        return base[(n1cap + j) * RR_BLOCK];
+    }
+    __device__ __forceinline__ double &O1(int j) {
+        return base[(n1cap + n2cap + j) * RR_BLOCK];
+    }
+    __device__ __forceinline__ double &O2(int j) {
+        return base[(2 * n1cap + n2cap + j) * RR_BLOCK];
+    }
+
+    static __device__ __forceinline__ int wave_max(int v)
+    {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int o = __shfl_xor(v, m, 64);
+            v = o > v ? o : v;
+        }
+        return v;
+    }
+
+    __device__ __forceinline__ void init(double *lds, int n1cap_, int n2cap_,
+                                         double x4)
+    {
+        base = lds + threadIdx.x;
+        n1cap = n1cap_;
+        n2cap = n2cap_;
+        n1 = gr4j_num_uh1(x4);
+        n2 = gr4j_num_uh2(x4);
+        n1 = n1 > n1cap ? n1cap : n1;     // cannot happen after the host scan
+        n2 = n2 > n2cap ? n2cap : n2;
+        n1w = __builtin_amdgcn_readfirstlane(wave_max(n1));
+        n2w = __builtin_amdgcn_readfirstlane(wave_max(n2));
+        double prev = 0.0;
+        for (int j = 0; j < n1w; ++j) {
+            const double cur = gr4j_s_curve1(j + 1, x4);
+            O1(j) = cur - prev;
+            prev = cur;
+            U1(j) = 0.0;
+        }
+        prev = 0.0;
+        for (int j = 0; j < n2w; ++j) {
+            const double cur = gr4j_s_curve2(j + 1, x4);
+            O2(j) = cur - prev;
+            prev = cur;
+            U2(j) = 0.0;
+        }
+    }
+
+    __device__ __forceinline__ void route(double p1, double p2, double &head1,
+                                          double &head2)
+    {
+        // each slot is read once (as the "next" of its left neighbour) and
+        // written once per day
+        for (int j = 0; j < n1w; ++j) {
+            const double nxt = (j + 1 < n1w) ? U1(j + 1) : 0.0;
+            const double v = O1(j) * p1;
+            const double nv = (j + 1 < n1) ? nxt + v : v;
+            U1(j) = nv;
+            if (j == 0) head1 = nv;
+        }
+        for (int j = 0; j < n2w; ++j) {
+            const double nxt = (j + 1 < n2w) ? U2(j + 1) : 0.0;
+            const double v = O2(j) * p2;
+            const double nv = (j + 1 < n2) ? nxt + v : v;
+            U2(j) = nv;
+            if (j == 0) head2 = nv;
+        }
+    }
+};
+
+// One day of GR4J (gr4j_model.py:86-154).  s, r: production / routing store
+// (in/out).  Returns the simulated discharge of the day.
+template <class UH>
+__device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
+                                            double &r, UH &uh, double prec,
+                                            double etp)
+{
+    // net rainfall or net evapotranspiration (:89-111).  Both branches of the
+    // reference share one shape: a tanh of the net amount over x1, one
+    // quotient; only the branch that applies is evaluated.
+    const bool wet = prec >= etp;
+    const double net = wet ? prec - etp : etp - prec;
+    const double sx = s / P.x1;
+    const double th = tanh(net / P.x1);
+    double num, den;
+    if (wet) {
+        num = P.x1 * (1 - sx * sx) * th;            // eq. 3 (:95-96)
+        den = 1 + sx * th;
+    } else {
+        num = s * (2 - sx) * th;                    // eq. 4 (:107-108)
+        den = 1 + (1 - sx) * th;
+    }
+    const double frac = num / den;
+    const double p_n = wet ? net : 0.0;
+    const double p_s = wet ? frac : 0.0;
+    const double e_s = wet ? 0.0 : frac;
+
+    double sn = s - e_s + p_s;                                  // :114
+    // percolation (:117); **4 is two squarings
+    const double v = 4.0 / 9.0 * sn / P.x1;
+    const double v2 = v * v;
+    const double perc = sn * (1 - pow(1 + v2 * v2, -0.25));
+    sn = sn - perc;                                             // :120
+    const double p_r = perc + (p_n - p_s);                      // :123
+    const double p_r_uh1 = 0.9 * p_r;                           // :126-127
+    const double p_r_uh2 = 0.1 * p_r;
+
+    double head1, head2;
+    uh.route(p_r_uh1, p_r_uh2, head1, head2);                   // :130-136
+
+    const double gw_exchange = P.x2 * pow(r / P.x3, 3.5);       // :139
+    double rn = nb_max(0.0, r + head1 + gw_exchange);           // :142
+    const double w = rn / P.x3;
+    const double w2 = w * w;
+    const double q_r = rn * (1 - pow(1 + w2 * w2, -0.25));      // :145
+    rn = rn - q_r;                                              // :148
+    const double q_d = nb_max(0.0, head2 + gw_exchange);        // :151
+    s = sn;
+    r = rn;
+    return q_r + q_d;                                           // :154
+}

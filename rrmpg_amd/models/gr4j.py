@@ -1,0 +1,162 @@
+"""Interface to the GR4J hydrological model (GPU ensemble engine).
+
+Same class surface as the reference's rrmpg/models/gr4j.py (GR4J :24-249,
+_loss :252-275); ``simulate`` evaluates ALL parameter sets with one call into
+librrhip (rr_gr4j_simulate) instead of a Python loop over run_gr4j.
+
+Documented deviation: the reference's ``simulate`` with
+``return_storage=False`` returns from inside its loop after the FIRST
+parameter set (gr4j.py:176-178), leaving all other columns zero.  Here every
+column is simulated.
+"""
+
+import numbers
+
+import numpy as np
+from scipy import optimize
+
+from .. import _lib
+from ..utils.array_checks import check_for_negatives, validate_array_input
+from .basemodel import BaseModel, new_outputs, out_ptr
+
+
+class GR4J(BaseModel):
+    """Interface to the GR4J hydrological model.
+
+    Perrin, Michel & Andreassian, "Improvement of a parsimonious model for
+    streamflow simulation", J. Hydrol. 279 (2003).  Daily data only.  If no
+    model parameters are passed upon initialization, a random parameter set
+    is generated.
+
+    Args:
+        params: (optional) Dictionary containing all model parameters as
+            separate key/value pairs.
+    """
+
+    _param_list = ['x1', 'x2', 'x3', 'x4']
+
+    _default_bounds = {'x1': (100, 1200),
+                       'x2': (-5, 3),
+                       'x3': (20, 300),
+                       'x4': (1.1, 2.9)}
+
+    _dtype = np.dtype([('x1', np.float64),
+                       ('x2', np.float64),
+                       ('x3', np.float64),
+                       ('x4', np.float64)])
+
+    def __init__(self, params=None):
+        super().__init__(params=params)
+
+    def simulate(self, prec, etp, s_init=0., r_init=0., return_storage=False,
+                 params=None):
+        """Simulate rainfall-runoff process for given input.
+
+        Args:
+            prec: Array of daily precipitation sum [mm]
+            etp: Array of mean potential evapotranspiration [mm]
+            s_init: (optional) Initial production storage as fraction of x1.
+            r_init: (optional) Initial routing storage as fraction of x3.
+            return_storage: (optional) also return the two storages.
+            params: (optional) Numpy array of parameter sets of the model's
+                custom dtype; all are evaluated at once on the GPU.
+
+        Returns:
+            qsim [timesteps, sets] and optionally s_store, r_store.
+
+        Raises:
+            ValueError: If one of the inputs contains invalid values.
+            TypeError: If one of the inputs has an incorrect datatype.
+            RuntimeError: If precipitation and evapotranspiration differ in
+                size.
+        """
+        prec, etp = _validate_forcing(prec, etp)
+        if not isinstance(s_init, numbers.Number):
+            raise TypeError("'s1_init' must be a Number.")
+        if not isinstance(r_init, numbers.Number):
+            raise TypeError("'r_init' must be a Number.")
+        s_init, r_init = _validate_inits(s_init, r_init)
+        params = self._resolve_params(params)
+        out, _ = _run(prec, etp, s_init, r_init, params, True,
+                      bool(return_storage), None)
+        if return_storage:
+            return tuple(out)
+        return out[0]
+
+    def fit(self, qobs, prec, etp, s_init=0., r_init=0.):
+        """Fit the GR4J model to a timeseries of discharge.
+
+        scipy differential evolution over the default bounds, as in the
+        reference (gr4j.py:185-249).
+
+        Returns:
+            res: A scipy OptimizeResult class object.
+        """
+        prec, etp = _validate_forcing(prec, etp)
+        qobs = validate_array_input(qobs, np.float64, 'observed discharge')
+        s_init, r_init = _validate_inits(s_init, r_init)
+        args = (qobs, prec, etp, s_init, r_init, self._dtype)
+        bnds = tuple([self._default_bounds[p] for p in self._param_list])
+        return optimize.differential_evolution(_loss, bounds=bnds, args=args)
+
+    def _sweep(self, params, qobs, want_qsim, prec, etp, s_init=0.,
+               r_init=0.):
+        prec, etp = _validate_forcing(prec, etp)
+        s_init, r_init = _validate_inits(s_init, r_init)
+        params = self._resolve_params(params)
+        out, sse = _run(prec, etp, s_init, r_init, params, want_qsim, False,
+                        qobs)
+        return out[0], sse
+
+
+def _validate_forcing(prec, etp):
+    prec = validate_array_input(prec, np.float64, 'precipitation')
+    etp = validate_array_input(etp, np.float64, 'pot. evapotranspiration')
+    if check_for_negatives(prec):
+        raise ValueError("The precipitation array contains negative values.")
+    if len(prec) != len(etp):
+        raise RuntimeError("The arrays of precipitation and pot. "
+                           "evapotranspiration, must be of the same size.")
+    return prec, etp
+
+
+def _validate_inits(s_init, r_init):
+    s_init = float(s_init)
+    r_init = float(r_init)
+    if (s_init < 0) or (s_init > 1):
+        raise ValueError("The initial value of the production storage must be "
+                         "in the range [0,1].")
+    if (r_init < 0) or (r_init > 1):
+        raise ValueError("The initial value of the routing storage must be in "
+                         "the range [0,1].")
+    return s_init, r_init
+
+
+def _run(prec, etp, s_init, r_init, params, want_qsim, want_storage, qobs):
+    """One batched GPU call (include/rrhip.h: rr_gr4j_simulate)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    block, p_ptr, n = _lib.params_block(params, 4)
+    t = prec.shape[0]
+    out = new_outputs((t, n), (want_qsim, want_storage, want_storage))
+    qobs_arr, qobs_ptr = _lib.f64(qobs)
+    if qobs is not None and qobs_arr.shape[0] != t:
+        raise ValueError("Arrays must have the same size.")
+    sse = np.zeros(n) if qobs is not None else None
+    keep, (p_prec, p_etp) = _lib.f64s(prec, etp)
+    rc = lib.rr_gr4j_simulate(p_prec, p_etp, t, s_init, r_init, p_ptr, n,
+                              *[out_ptr(a) for a in out], qobs_ptr,
+                              out_ptr(sse))
+    del keep
+    _lib.check(rc, "rr_gr4j_simulate")
+    return out, sse
+
+
+def _loss(X, *args):
+    """Return the loss value (MSE) for the current parameter set."""
+    qobs, prec, etp, s_init, r_init, dtype = args
+    params = np.zeros(1, dtype=dtype)
+    params['x1'], params['x2'] = X[0], X[1]
+    params['x3'], params['x4'] = X[2], X[3]
+    _, sse = _run(prec, etp, s_init, r_init, params, False, False, qobs)
+    return sse[0] / prec.shape[0]

@@ -1,0 +1,67 @@
+"""Evaluation metrics used on the hot path.
+
+Mirror of the functions of rrmpg/utils/metrics.py that the Monte-Carlo sweep
+and the optimiser's loss use (reference: calc_nse :29-77, calc_rmse :81-107,
+calc_mse :110-136).  The per-set squared-error sums of a sweep are produced
+on the GPU (the kernels' fused `sse` output); `mse_from_sse` / `nse_from_sse`
+turn them into the same scores without touching qsim.
+"""
+
+import numpy as np
+
+from .array_checks import validate_array_input
+
+
+def _pair(obs, sim):
+    obs = validate_array_input(obs, np.float64, 'obs')
+    sim = validate_array_input(sim, np.float64, 'sim')
+    if len(obs) != len(sim):
+        raise ValueError("Arrays must have the same size.")
+    return obs, sim
+
+
+def _nse_denominator(obs):
+    denominator = np.sum((obs - np.mean(obs)) ** 2)
+    if denominator == 0:
+        raise RuntimeError(
+            "The Nash-Sutcliffe-Efficiency coefficient is not defined for the "
+            "case, that all values in the observations are equal. Maybe you "
+            "should use the Mean-Squared-Error instead.")
+    return denominator
+
+
+def calc_nse(obs, sim):
+    """Nash-Sutcliffe model efficiency: 1 - sum((sim-obs)^2)/sum((obs-mean)^2).
+
+    Raises:
+        ValueError: arrays of unequal size or non-numeric values.
+        TypeError: unsupported array type.
+        RuntimeError: all observations equal (NSE undefined).
+    """
+    obs, sim = _pair(obs, sim)
+    denominator = _nse_denominator(obs)
+    numerator = np.sum((sim - obs) ** 2)
+    return 1 - numerator / denominator
+
+
+def calc_rmse(obs, sim):
+    """Root mean squared error."""
+    obs, sim = _pair(obs, sim)
+    return np.sqrt(np.mean((obs - sim) ** 2))
+
+
+def calc_mse(obs, sim):
+    """Mean squared error."""
+    obs, sim = _pair(obs, sim)
+    return np.mean((obs - sim) ** 2)
+
+
+def mse_from_sse(sse, num_timesteps):
+    """Per-set MSE from the kernels' fused squared-error sums."""
+    return np.asarray(sse, dtype=np.float64) / num_timesteps
+
+
+def nse_from_sse(sse, obs):
+    """Per-set NSE from the kernels' fused squared-error sums."""
+    obs = validate_array_input(obs, np.float64, 'obs')
+    return 1 - np.asarray(sse, dtype=np.float64) / _nse_denominator(obs)

@@ -1,0 +1,466 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle
+and the committed golden fixtures.
+
+Tolerances (BASELINE.json north_star: fp64 discharge within 1e-10 relative):
+  * ABC and Cemaneige contain no transcendental -> asserted BIT-EXACT;
+  * HBV-Edu, GR4J, CemaneigeGR4J call pow/tanh (OCML on the GPU, glibc in the
+    oracle/numba) -> asserted at RTOL = 1e-10 relative (abs floor 1e-9 of the
+    unit, mm/day); observed deviations are ~1e-14.
+The model classes call librrhip's host-pointer entry points; the *_dev entry
+points are exercised with torch-owned device memory.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from .conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def models():
+    from rrmpg_amd import _lib
+    _lib.load()
+    _lib.require_gpu()
+    import rrmpg_amd.models as m
+    return m
+
+
+def _records(cls, flat):
+    p = np.zeros(flat.shape[0], dtype=cls._dtype)
+    for k, name in enumerate(cls._param_list):
+        p[name] = flat[:, k]
+    return p
+
+
+def _flat(p, cls):
+    return np.stack([p[n] for n in cls._param_list], axis=1)
+
+
+def _layers(g):
+    from rrmpg_amd.models import cemaneige_utils as cu
+    lp = cu.extrapolate_precipitation(g["prec"], g["altitudes"], g["station"])
+    lmin, lmean, lmax = cu.extrapolate_temperature(
+        g["min_temp"], g["mean_temp"], g["max_temp"], g["altitudes"],
+        g["station"])
+    frac = cu.calculate_solid_fraction(lp, g["altitudes"], lmean, lmin, lmax)
+    return lp, lmean, frac
+
+
+# ------------------------------------------------------------------- ABC
+def test_abc_bit_exact_vs_oracle_and_golden(models, oracle):
+    g = golden("syn_abc")
+    p = _records(models.ABCModel, g["params"])
+    q, s = models.ABCModel().simulate(g["prec"], float(g["initial_state"]),
+                                      return_storage=True, params=p)
+    assert np.array_equal(q, g["qsim"])
+    assert np.array_equal(s, g["storage"])
+    # odd N, N = 1 (single record), qsim only
+    q1 = models.ABCModel().simulate(g["prec"], 2.5, params=p[:7])
+    assert np.array_equal(q1, g["qsim"][:, :7])
+    q2 = models.ABCModel().simulate(g["prec"], 2.5, params=p[3])
+    assert q2.shape == (g["prec"].size, 1)
+    assert np.array_equal(q2[:, 0], g["qsim"][:, 3])
+    # 1001 random sets against the oracle
+    rng = np.random.default_rng(5)
+    flat = rng.random((1001, 3)) * np.array([1, .3, 1.])
+    ref = oracle.simulate_abc(g["prec"], 1.0, flat, return_storage=True)
+    out = models.ABCModel().simulate(g["prec"], 1.0, return_storage=True,
+                                     params=_records(models.ABCModel, flat))
+    assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+
+
+def test_abc_zero_rain_and_model_params(models):
+    m = models.ABCModel()
+    assert np.sum(m.simulate(np.zeros(100))) == 0
+    # parameters stored in the model object are used when params is None
+    m = models.ABCModel(params={'a': 0.3, 'b': 0.2, 'c': 0.1})
+    q = m.simulate([0., 1., 2., 3.], initial_state=1.0)
+    # hand-evaluated recurrence (abcmodel_model.py:53-59)
+    s, exp = 1.0, [0.0]
+    for pr in (1., 2., 3.):
+        exp.append((1 - 0.3 - 0.2) * pr + 0.1 * s)
+        s = (1 - 0.1) * s + 0.3 * pr
+    assert np.array_equal(q[:, 0], np.array(exp))
+
+
+# --------------------------------------------------------------- HBV-Edu
+def test_hbvedu_kat_matlab(models):
+    g = golden("kat_hbvedu")
+    m = models.HBVEdu(params=dict(zip(models.HBVEdu._param_list,
+                                      g["params"].tolist())))
+    qsim = m.simulate(temp=g["temp"], prec=g["prec"], month=g["month"],
+                      PE_m=g["PE_m"], T_m=g["T_m"], snow_init=0,
+                      soil_init=100, s1_init=3, s2_init=10,
+                      return_storage=False)
+    q = (qsim * g["area"] * 1000) / (24 * 60 * 60)
+    assert np.allclose(q.flatten(), g["qsim_matlab"])   # the reference's test
+    assert rel_err(qsim, g["ref_qsim"]) < RTOL
+
+
+def test_hbvedu_golden_and_oracle(models, oracle):
+    g = golden("syn_hbvedu")
+    p = _records(models.HBVEdu, g["params"])
+    i = g["inits"]
+    out = models.HBVEdu().simulate(g["temp"], g["prec"], g["month"], g["PE_m"],
+                                   g["T_m"], i[0], i[1], i[2], i[3],
+                                   return_storage=True, params=p)
+    idx = g["stride_idx"]
+    for a, name in zip(out, ["qsim", "snow", "soil", "s1", "s2"]):
+        assert rel_err(a[idx], g[name + "_strided"]) < RTOL, name
+        assert rel_err(a[:, :4], g[name + "_full"]) < RTOL, name
+        assert rel_err(a[-1], g[name + "_last"]) < RTOL, name
+    ref = oracle.simulate_hbvedu(g["temp"], g["prec"], g["month"] - 1,
+                                 g["PE_m"], g["T_m"], i, g["params"],
+                                 return_storage=True)
+    for a, b in zip(out, ref):
+        assert rel_err(a, b) < RTOL
+    # snow has no transcendental in its recurrence
+    assert np.array_equal(out[1], ref[1])
+
+
+def test_hbvedu_ragged_sizes_vs_oracle(models, oracle):
+    g = golden("syn_hbvedu")
+    rng = np.random.default_rng(11)
+    lo = np.array([-1, 3, 100, 1, .01, 90, .05, .01, .01, .01, 2.])
+    hi = np.array([1, 7, 200, 7, .07, 180, .2, .1, .05, .05, 5.])
+    for n, t in [(1, 1), (1, 2), (63, 3), (64, 400), (65, 400), (333, 1500)]:
+        flat = lo + (hi - lo) * rng.random((n, 11))
+        ref = oracle.simulate_hbvedu(g["temp"][:t], g["prec"][:t],
+                                     g["month"][:t] - 1, g["PE_m"], g["T_m"],
+                                     (1., 90., 2., 8.), flat,
+                                     return_storage=True)
+        out = models.HBVEdu().simulate(
+            g["temp"][:t], g["prec"][:t], g["month"][:t], g["PE_m"], g["T_m"],
+            1., 90., 2., 8., return_storage=True,
+            params=_records(models.HBVEdu, flat))
+        for a, b in zip(out, ref):
+            assert a.shape == (t, n)
+            assert rel_err(a, b) < RTOL, (n, t)
+
+
+def test_hbvedu_zero_rain(models):
+    m = models.HBVEdu()
+    qsim = m.simulate(temp=np.random.uniform(-15, 25, 100), prec=np.zeros(100),
+                      month=np.random.randint(1, 12, 100),
+                      PE_m=np.random.uniform(0, 4, 12),
+                      T_m=np.random.uniform(-5, 15, 12))
+    assert np.sum(qsim) == 0
+
+
+def test_nan_propagation_matches_reference(models):
+    g = golden("edge")
+    syn = golden("syn_hbvedu")
+    p = _records(models.HBVEdu, g["hbv_nan_params"])
+    q, _, soil, _, _ = models.HBVEdu().simulate(
+        g["temp40"], g["prec40"], g["month40"], syn["PE_m"], syn["T_m"], 0.,
+        100., 3., 10., return_storage=True, params=p)
+    assert rel_err(q.ravel(), g["hbv_nan_qsim"]) < RTOL     # same NaN pattern
+    assert rel_err(soil.ravel(), g["hbv_nan_soil"]) < RTOL
+    assert np.isnan(q).any()
+    # GR4J with x3 < 0: pow NaN swallowed by max(0, .) as numba does
+    p = _records(models.GR4J, g["gr4j_nan_params"])
+    q, s, r = models.GR4J().simulate(g["prec40"], g["etp40"], 0.6, 0.7,
+                                     return_storage=True, params=p)
+    assert rel_err(q.ravel(), g["gr4j_nan_qsim"]) < RTOL
+    assert rel_err(r.ravel(), g["gr4j_nan_r"]) < RTOL
+    kat = golden("kat_hbvedu")
+    for tt in (1, 2, 3):
+        q, snow, *_ = models.HBVEdu().simulate(
+            g["temp40"][:tt], g["prec40"][:tt], g["month40"][:tt], syn["PE_m"],
+            syn["T_m"], 1., 100., 3., 10., return_storage=True,
+            params=_records(models.HBVEdu, kat["params"][None, :]))
+        assert rel_err(q.ravel(), g["hbv_T%d_qsim" % tt]) < RTOL
+        assert rel_err(snow.ravel(), g["hbv_T%d_snow" % tt]) < RTOL
+
+
+# ------------------------------------------------------------------ GR4J
+def test_gr4j_kat_excel(models):
+    g = golden("kat_gr4j")
+    m = models.GR4J(params=dict(zip(models.GR4J._param_list,
+                                    g["params"].tolist())))
+    qsim = m.simulate(g["prec"], g["etp"], s_init=0.6, r_init=0.7,
+                      return_storage=False)
+    assert np.allclose(qsim.flatten(), g["qsim_excel"])  # the reference's test
+    assert rel_err(qsim, g["ref_qsim"]) < RTOL
+
+
+def test_gr4j_golden_both_uh_tiers(models, oracle):
+    g = golden("syn_gr4j")
+    flat = g["params"]
+    i = g["inits"]
+    idx = g["stride_idx"]
+    # sets 0..15 have x4 <= 3 (register tier); all 32 together force the LDS
+    # tier (x4 up to 9.9); both must agree with the reference
+    for sl in (slice(0, 16), slice(0, 32), slice(16, 32)):
+        out = models.GR4J().simulate(g["prec"], g["etp"], i[0], i[1],
+                                     return_storage=True,
+                                     params=_records(models.GR4J, flat[sl]))
+        for a, name in zip(out, ["qsim", "s_store", "r_store"]):
+            assert rel_err(a[idx], g[name + "_strided"][:, sl]) < RTOL, name
+            assert rel_err(a[-1], g[name + "_last"][sl]) < RTOL, name
+    out = models.GR4J().simulate(g["prec"], g["etp"], i[0], i[1],
+                                 return_storage=True,
+                                 params=_records(models.GR4J, flat[:4]))
+    for a, name in zip(out, ["qsim", "s_store", "r_store"]):
+        assert rel_err(a, g[name + "_full"]) < RTOL, name
+    # every column is filled (the reference wrapper's early return, quirk Q1,
+    # is not reproduced)
+    q = models.GR4J().simulate(g["prec"][:500], g["etp"][:500], i[0], i[1],
+                               params=_records(models.GR4J, flat[:8]))
+    ref = oracle.simulate_gr4j(g["prec"][:500], g["etp"][:500], i, flat[:8])
+    assert rel_err(q, ref) < RTOL
+    assert (q.sum(0) > 0).all()
+
+
+def test_gr4j_random_vs_oracle_and_limits(models, oracle):
+    g = golden("syn_gr4j")
+    rng = np.random.default_rng(21)
+    lo, hi = np.array([100, -5, 20, 1.1]), np.array([1200, 3, 300, 2.9])
+    flat = lo + (hi - lo) * rng.random((257, 4))
+    t = 2000
+    ref = oracle.simulate_gr4j(g["prec"][:t], g["etp"][:t], (0.3, 0.5), flat,
+                               return_storage=True)
+    out = models.GR4J().simulate(g["prec"][:t], g["etp"][:t], 0.3, 0.5,
+                                 return_storage=True,
+                                 params=_records(models.GR4J, flat))
+    for a, b in zip(out, ref):
+        assert rel_err(a, b) < RTOL
+    # long unit hydrographs (LDS tier up to RR_GR4J_MAX_X4 = 20)
+    flat[:, 3] = rng.uniform(0.2, 20.0, 257)
+    ref = oracle.simulate_gr4j(g["prec"][:t], g["etp"][:t], (0.3, 0.5), flat)
+    out = models.GR4J().simulate(g["prec"][:t], g["etp"][:t], 0.3, 0.5,
+                                 params=_records(models.GR4J, flat))
+    assert rel_err(out, ref) < RTOL
+    # x4 that gives no ordinates / exceeds the LDS tier: loud error
+    bad = flat[:3].copy()
+    bad[1, 3] = -0.5
+    with pytest.raises(RuntimeError, match="RR_E_PARAM"):
+        models.GR4J().simulate(g["prec"][:50], g["etp"][:50],
+                               params=_records(models.GR4J, bad))
+    bad[1, 3] = 25.0
+    with pytest.raises(RuntimeError, match="RR_E_PARAM"):
+        models.GR4J().simulate(g["prec"][:50], g["etp"][:50],
+                               params=_records(models.GR4J, bad))
+
+
+def test_gr4j_zero_rain(models):
+    m = models.GR4J()
+    qsim = m.simulate(prec=np.zeros(100), etp=np.random.uniform(0, 3, 100),
+                      s_init=0, r_init=0)
+    assert np.sum(qsim) == 0
+
+
+# ------------------------------------------------------------- Cemaneige
+def test_cemaneige_kat_excel(models):
+    g = golden("kat_cemaneige")
+    m = models.Cemaneige(params={'CTG': 0.25, 'Kf': 3.74})
+    qsim = m.simulate(g["prec"], g["mean_temp"], g["min_temp"], g["max_temp"],
+                      met_station_height=495,
+                      altitudes=[550, 620, 700, 785, 920])
+    assert np.allclose(qsim.flatten(), g["liquid_outflow_excel"])
+    assert rel_err(qsim, g["ref_outflow"]) < 1e-12
+
+
+def test_cemaneige_bit_exact_vs_oracle(models, oracle):
+    g = golden("syn_cemaneige")
+    p = golden("syn_cemaneige_prep")
+    flat = g["params"]
+    i = g["inits"]
+    from rrmpg_amd.utils import synthetic as syn
+    out = models.Cemaneige().simulate(
+        p["prec"], p["temp"], p["tmin"], p["tmax"], syn.STATION_HEIGHT, i[0],
+        i[1], altitudes=syn.ALTITUDES, return_storages=True,
+        params=_records(models.Cemaneige, flat))
+    ref = oracle.simulate_cemaneige(g["layer_prec"], g["layer_mean"],
+                                    g["frac_solid"], i, flat,
+                                    return_storages=True)
+    for a, b in zip(out, ref):
+        assert np.array_equal(a, b)
+    idx = g["stride_idx"]
+    assert rel_err(out[0], g["outflow"]) < 1e-12
+    assert rel_err(out[1][idx], g["G_strided"]) < 1e-12
+    # L = 1 (no altitudes)
+    g1 = golden("syn_cemaneige_l1")
+    o1 = models.Cemaneige().simulate(
+        p["prec"], p["temp"], p["tmin"], p["tmax"], syn.STATION_HEIGHT,
+        params=_records(models.Cemaneige, g1["params"]))
+    assert rel_err(o1, g1["outflow"]) < 1e-12
+    # every supported layer count, ragged N
+    rng = np.random.default_rng(2)
+    for nl in range(1, 9):
+        alts = list(np.linspace(520, 2400, nl))
+        n = 70 + nl
+        fl = rng.random((n, 2)) * np.array([1., 10.])
+        out = models.Cemaneige().simulate(
+            p["prec"][:900], p["temp"][:900], p["tmin"][:900], p["tmax"][:900],
+            500, 3.0, -1.0, altitudes=alts, return_storages=True,
+            params=_records(models.Cemaneige, fl))
+        from rrmpg_amd.models import cemaneige_utils as cu
+        lp = cu.extrapolate_precipitation(p["prec"][:900], alts, 500)
+        lmin, lmean, lmax = cu.extrapolate_temperature(
+            p["tmin"][:900], p["temp"][:900], p["tmax"][:900], alts, 500)
+        fr = cu.calculate_solid_fraction(lp, np.array(alts), lmean, lmin, lmax)
+        ref = oracle.simulate_cemaneige(lp, lmean, fr, (3.0, -1.0), fl,
+                                        return_storages=True)
+        for a, b in zip(out, ref):
+            assert np.array_equal(a, b), nl
+    with pytest.raises(RuntimeError, match="RR_E_PARAM"):
+        models.Cemaneige().simulate(
+            p["prec"][:50], p["temp"][:50], p["tmin"][:50], p["tmax"][:50],
+            500, altitudes=list(np.linspace(500, 3000, 9)))
+
+
+# --------------------------------------------------------- CemaneigeGR4J
+def test_cemaneigegr4j_kat_excel(models):
+    g = golden("kat_cemaneigegr4j")
+    m = models.CemaneigeGR4J(params=dict(zip(models.CemaneigeGR4J._param_list,
+                                             g["params"].tolist())))
+    qsim = m.simulate(g["prec"], g["mean_temp"], g["min_temp"], g["max_temp"],
+                      g["etp"], met_station_height=495,
+                      altitudes=[550, 620, 700, 785, 920], s_init=0.6,
+                      r_init=0.7)
+    assert np.allclose(qsim.flatten(), g["qsim_excel"])
+    assert rel_err(qsim, g["ref_qsim"]) < RTOL
+
+
+def test_cemaneigegr4j_golden_and_oracle(models, oracle):
+    g = golden("syn_cemaneigegr4j")
+    p = golden("syn_cemaneige_prep")
+    from rrmpg_amd.utils import synthetic as syn
+    i = g["inits"]
+    out = models.CemaneigeGR4J().simulate(
+        p["prec"], p["temp"], p["tmin"], p["tmax"], g["etp"],
+        syn.STATION_HEIGHT, i[0], i[1], i[2], i[3], altitudes=syn.ALTITUDES,
+        return_storages=True, params=_records(models.CemaneigeGR4J,
+                                              g["params"]))
+    idx = g["stride_idx"]
+    assert rel_err(out[0], g["qsim"]) < RTOL
+    assert rel_err(out[1][idx], g["G_strided"]) < 1e-12
+    assert rel_err(out[3][idx], g["s_store_strided"]) < RTOL
+    assert rel_err(out[4][idx], g["r_store_strided"]) < RTOL
+    ref = oracle.simulate_cemaneigegr4j(
+        g["layer_prec"], g["layer_mean"], g["etp"], g["frac_solid"], i,
+        g["params"], return_storages=True)
+    assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2])
+    for a, b in zip(out, ref):
+        assert rel_err(a, b, floor=1e-9) < RTOL
+    # LDS unit-hydrograph tier in the fused kernel
+    flat = g["params"].copy()
+    flat[:, 5] = np.random.default_rng(4).uniform(0.4, 12.0, flat.shape[0])
+    t = 1200
+    ref = oracle.simulate_cemaneigegr4j(
+        g["layer_prec"][:t], g["layer_mean"][:t], g["etp"][:t],
+        g["frac_solid"][:t], i, flat)
+    out = models.CemaneigeGR4J().simulate(
+        p["prec"][:t], p["temp"][:t], p["tmin"][:t], p["tmax"][:t],
+        g["etp"][:t], syn.STATION_HEIGHT, i[0], i[1], i[2], i[3],
+        altitudes=syn.ALTITUDES, params=_records(models.CemaneigeGR4J, flat))
+    assert rel_err(out, ref) < RTOL
+
+
+# ------------------------------------------ fused metric, sweeps, boundary
+def test_fused_sse_matches_calc_mse(models):
+    from rrmpg_amd.utils.metrics import calc_mse, calc_nse, nse_from_sse
+    g = golden("syn_hbvedu")
+    p = _records(models.HBVEdu, g["params"])
+    i = g["inits"]
+    m = models.HBVEdu()
+    kw = dict(temp=g["temp"], prec=g["prec"], month=g["month"], PE_m=g["PE_m"],
+              T_m=g["T_m"], snow_init=i[0], soil_init=i[1], s1_init=i[2],
+              s2_init=i[3])
+    qsim, sse = m._sweep(p, g["qobs"], True, **kw)
+    _, sse_only = m._sweep(p, g["qobs"], False, **kw)
+    assert np.array_equal(sse, sse_only)
+    mse = sse / g["qobs"].size
+    assert rel_err(mse, g["mse"]) < RTOL          # vs reference calc_mse
+    assert rel_err(nse_from_sse(sse, g["qobs"]), g["nse"], floor=1e-6) < RTOL
+    for n in range(4):
+        assert abs(calc_mse(g["qobs"], qsim[:, n]) - mse[n]) <= 1e-12 * mse[n]
+        assert abs(calc_nse(g["qobs"], qsim[:, n]) - g["nse"][n]) < 1e-9
+    gg = golden("syn_gr4j")
+    mg = models.GR4J()
+    _, sse = mg._sweep(_records(models.GR4J, gg["params"]), gg["qobs"], False,
+                       prec=gg["prec"], etp=gg["etp"], s_init=0.6, r_init=0.7)
+    assert rel_err(sse / gg["qobs"].size, gg["mse"]) < RTOL
+    gc = golden("syn_cemaneigegr4j")
+    pc = golden("syn_cemaneige_prep")
+    from rrmpg_amd.utils import synthetic as syn
+    ic = gc["inits"]
+    _, sse = models.CemaneigeGR4J()._sweep(
+        _records(models.CemaneigeGR4J, gc["params"]), gc["qobs"], False,
+        prec=pc["prec"], mean_temp=pc["temp"], min_temp=pc["tmin"],
+        max_temp=pc["tmax"], etp=gc["etp"],
+        met_station_height=syn.STATION_HEIGHT, snow_pack_init=ic[0],
+        thermal_state_init=ic[1], s_init=ic[2], r_init=ic[3],
+        altitudes=syn.ALTITUDES)
+    assert rel_err(sse / gc["qobs"].size, gc["mse"]) < RTOL
+    assert rel_err(nse_from_sse(sse, gc["qobs"]), gc["nse"], floor=1e-6) < RTOL
+
+
+def test_monte_carlo_matches_reference_run(models):
+    from rrmpg_amd.tools import monte_carlo
+    g = golden("sampling")
+    np.random.seed(99)
+    mdl = models.ABCModel()
+    np.random.seed(100)
+    res = monte_carlo(mdl, 24, qobs=g["mc_abc_qobs"], prec=g["mc_abc_rain"])
+    assert res['qsim'].shape[1] == 24                   # the reference's test
+    assert np.array_equal(_flat(res['params'], models.ABCModel),
+                          g["mc_abc_params"])
+    assert np.array_equal(res['qsim'], g["mc_abc_qsim"])
+    assert rel_err(res['mse'], g["mc_abc_mse"]) < 1e-12
+    np.random.seed(100)
+    res2 = monte_carlo(mdl, 24, qobs=g["mc_abc_qobs"], return_qsim=False,
+                       prec=g["mc_abc_rain"])
+    assert 'qsim' not in res2 and np.array_equal(res2['mse'], res['mse'])
+    res3 = monte_carlo(mdl, 5, prec=g["mc_abc_rain"])
+    assert set(res3) == {'params', 'qsim'}
+
+
+def test_host_path_column_blocks(models, oracle, monkeypatch):
+    """The host entry point sweeps N in column blocks with a pitched gather;
+    force tiny blocks and compare with one-block results."""
+    g = golden("syn_hbvedu")
+    rng = np.random.default_rng(8)
+    lo = np.array([-1, 3, 100, 1, .01, 90, .05, .01, .01, .01, 2.])
+    hi = np.array([1, 7, 200, 7, .07, 180, .2, .1, .05, .05, 5.])
+    flat = lo + (hi - lo) * rng.random((700, 11))
+    p = _records(models.HBVEdu, flat)
+    t = 300
+    args = (g["temp"][:t], g["prec"][:t], g["month"][:t], g["PE_m"], g["T_m"])
+    whole = models.HBVEdu().simulate(*args, 0., 100., 3., 10.,
+                                     return_storage=True, params=p)
+    monkeypatch.setenv("RRHIP_MAX_BLOCK_COLS", "256")
+    blocks = models.HBVEdu().simulate(*args, 0., 100., 3., 10.,
+                                      return_storage=True, params=p)
+    for a, b in zip(whole, blocks):
+        assert np.array_equal(a, b)
+    pc = golden("syn_cemaneige_prep")
+    fl = rng.random((600, 2)) * np.array([1., 10.])
+    kw = dict(met_station_height=500, altitudes=[550, 620, 700],
+              return_storages=True, params=_records(models.Cemaneige, fl))
+    blocks = models.Cemaneige().simulate(pc["prec"][:t], pc["temp"][:t],
+                                         pc["tmin"][:t], pc["tmax"][:t], **kw)
+    monkeypatch.delenv("RRHIP_MAX_BLOCK_COLS")
+    whole = models.Cemaneige().simulate(pc["prec"][:t], pc["temp"][:t],
+                                        pc["tmin"][:t], pc["tmax"][:t], **kw)
+    for a, b in zip(whole, blocks):
+        assert np.array_equal(a, b)
+
+
+def test_fit_recovers_known_parameters(models):
+    """fit() = scipy differential evolution over GPU-evaluated losses."""
+    rng = np.random.default_rng(0)
+    prec = rng.gamma(0.8, 6.0, 150) * (rng.random(150) < 0.5)
+    truth = models.ABCModel(params={'a': 0.35, 'b': 0.15, 'c': 0.4})
+    qobs = truth.simulate(prec, initial_state=1.0).ravel()
+    np.random.seed(0)
+    res = models.ABCModel().fit(qobs, prec, initial_state=1.0)
+    assert res.fun < 1e-6
+    assert np.allclose(res.x, [0.35, 0.15, 0.4], atol=1e-2)
