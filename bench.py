@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: model-timesteps/s of an ensemble sweep.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full Monte-Carlo sweep of the workload on every rank: all of
+the rank's parameter sets x all daily timesteps, with the [T, N] discharge
+array materialised in HBM AND the per-set squared error accumulated in the
+kernel (what rrmpg.tools.monte_carlo computes: simulate + per-set MSE),
+followed (N > 1) by the single all-gather of the per-set scores over RCCL.
+Inputs (forcing, parameter block, output buffers) are resident in HBM before
+the timed region starts.  Weak scaling: every rank owns its own block of
+--sets parameter sets.
+
+Default workload = the one BASELINE.json's metric is quoted on: HBV-Edu,
+1,000,000 parameter sets per GPU, 10,957 daily steps (30 years), fp64.
+Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# algorithmic bytes per model-timestep written to HBM (DESIGN.md, section
+# "Roofline"): qsim only.  Forcing (32 B/day shared by all sets) and the
+# parameter block (88 B/set, read once) amortise to ~0.
+BYTES_PER_STEP = {"qsim": 8, "metric": 0, "storages": None}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="hbvedu",
+                    choices=["hbvedu", "abc", "gr4j", "cemaneigegr4j"])
+    ap.add_argument("--sets", type=int, default=1_000_000,
+                    help="parameter sets per GPU")
+    ap.add_argument("--days", type=int, default=10957)
+    ap.add_argument("--mode", default="qsim", choices=["qsim", "metric"],
+                    help="qsim: materialise qsim[T,N] + fused per-set SSE "
+                         "(default); metric: fused per-set SSE only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_workload(args, device, rank):
+    """Resident ensemble + parameter block + output buffers for one rank."""
+    import torch
+    from rrmpg_amd import device as rrdev
+    from rrmpg_amd import models
+    from rrmpg_amd.utils import synthetic as syn
+
+    f = syn.make_forcing(args.days)
+    np.random.seed(1 + rank)            # each rank: its own block of sets
+    n = args.sets
+    if args.model == "hbvedu":
+        cls = models.HBVEdu
+        ens = rrdev.HBVEduEnsemble(f["temp"], f["prec"], f["month"], f["PE_m"],
+                                   f["T_m"], device=device, **syn.HBV_INITS)
+        name = "HBV-Edu"
+    elif args.model == "abc":
+        cls = models.ABCModel
+        ens = rrdev.ABCEnsemble(f["prec"], 2.5, device=device)
+        name = "ABC"
+    elif args.model == "gr4j":
+        cls = models.GR4J
+        ens = rrdev.GR4JEnsemble(f["prec"], f["etp"], device=device,
+                                 **syn.GR4J_INITS)
+        name = "GR4J"
+    else:
+        cls = models.CemaneigeGR4J
+        from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+        layers, inits = prepare_snow_inputs(
+            f["prec"], f["temp"], f["tmin"], f["tmax"], syn.STATION_HEIGHT, 0,
+            0, list(syn.ALTITUDES), etp=f["etp"])
+        ens = rrdev.CemaneigeGR4JEnsemble(layers[0], layers[1], layers[2],
+                                          layers[3], 0., 0., 0.6, 0.7,
+                                          device=device)
+        name = "CemaneigeGR4J(L=5)"
+    params_host = cls().get_random_params(n)
+    params = ens.upload_params(params_host)
+    # synthetic observations: the first set's run + 10 % noise
+    q0 = ens.new_output(1)
+    ens.run(params[:1].contiguous(), q0)
+    torch.cuda.synchronize(device)
+    qobs = torch.from_numpy(syn.make_qobs(q0.cpu().numpy())).to(device)
+    qsim = ens.new_output(n) if args.mode == "qsim" else None
+    sse = torch.empty(n, dtype=torch.float64, device=device)
+    return ens, params, params_host, qsim, qobs, sse, name, f
+
+
+def cpu_baseline(args, f, params_host):
+    """The CPU oracle (oracle/rr_oracle.c, kind "port") timed on this box's
+    host cores on a bounded sample of the same workload.  Checker code: it is
+    only timed here, never used to produce the GPU result."""
+    from oracle import pyoracle
+    from rrmpg_amd.models import HBVEdu
+    from rrmpg_amd.utils import synthetic as syn
+    if args.model != "hbvedu":
+        return None
+    cores = pyoracle.max_threads()
+    flat = np.stack([params_host[k] for k in HBVEdu._param_list], 1)
+    m0 = (f["month"] - 1).astype(np.int8)
+    inits = [syn.HBV_INITS[k] for k in ("snow_init", "soil_init", "s1_init",
+                                        "s2_init")]
+
+    def timed(nsets, nthreads):
+        t0 = time.perf_counter()
+        pyoracle.simulate_hbvedu(f["temp"], f["prec"], m0, f["PE_m"], f["T_m"],
+                                 inits, flat[:nsets], nthreads=nthreads)
+        return time.perf_counter() - t0
+
+    # single thread, reference-shaped (one call per set, fresh arrays,
+    # column scatter): ~2-3 s
+    n1 = min(2000, flat.shape[0])
+    t1 = timed(n1, 1)
+    rate1 = n1 * args.days / t1
+    # all host cores: calibrate, then ~10 s of work
+    ncal = min(flat.shape[0], 250 * cores)
+    tcal = timed(ncal, cores)
+    nall = int(min(flat.shape[0], max(ncal, ncal * 10.0 / max(tcal, 1e-3))))
+    tall = timed(nall, cores) if nall > ncal else tcal
+    return {
+        "value": nall * args.days / tall,
+        "unit": "model-timesteps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d HBV-Edu parameter sets x %d days, all %d host threads "
+                  "(OpenMP over sets), reference-shaped: one run per set, "
+                  "fresh [T] arrays, column scatter into qsim[T,N]; %.1f s"
+                  % (nall, args.days, cores, tall),
+        "value_1thread": rate1,
+        "sample_1thread": "%d sets x %d days, 1 thread, %.1f s"
+                          % (n1, args.days, t1),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from rrmpg_amd.sharding import allgather_scores
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE"
+              % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    ens, params, params_host, qsim, qobs, sse, name, f = build_workload(
+        args, device, rank)
+    n, t = args.sets, args.days
+    total_sets = n * world
+
+    def step():
+        ens.run(params, qsim, qobs=qobs, sse=sse)
+        # per-set MSE of this rank's block, then the one collective of the
+        # whole job: all-gather of the scores (8 B per set)
+        mse = sse / t
+        return allgather_scores(mse, total_sets)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        scores = step()
+    fence()
+
+    # kernel time: HIP events on the stream the kernel is launched on (torch's
+    # current stream), bracketing only the library call of each step
+    ev = [(torch.cuda.Event(enable_timing=True),
+           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        ens.run(params, qsim, qobs=qobs, sse=sse)
+        ev[k][1].record()
+        mse = sse / t
+        scores = allgather_scores(mse, total_sets)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    assert scores.numel() == total_sets
+    finite = bool(torch.isfinite(scores).all().item())
+
+    if rank == 0:
+        value = total_sets * t * args.steps / elapsed
+        bytes_per_step = 8 if args.mode == "qsim" else 0
+        achieved = bytes_per_step * n * t / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        key = "%s:%s:%d:%d" % (args.model, args.mode, n, t)
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get(key)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "model-timesteps/s",
+            "value": value,
+            "unit": "model-timesteps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s Monte-Carlo sweep, %d parameter sets per GPU x "
+                            "%d daily steps, %s, RCCL all-gather of per-set "
+                            "MSE" % (name, n, t,
+                                     "qsim[T,N] written to HBM + fused "
+                                     "per-set MSE" if args.mode == "qsim"
+                                     else "fused per-set MSE only"),
+                "model": args.model,
+                "sets_per_gpu": n,
+                "timesteps": t,
+                "mode": args.mode,
+                "sharding": "parameter sets, one contiguous block per GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "kernel_ms": kernel_ms,
+                "kernel": "%s ensemble kernel, %d B/model-timestep "
+                          "algorithmic" % (name, bytes_per_step),
+            },
+            "scores_finite": finite,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, f, params_host)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,255 @@
+"""HBM-resident sweeps: the *_simulate_dev family of the C-ABI driven with
+torch-owned device memory.
+
+The model classes (rrmpg_amd.models) keep the reference's host-array seam:
+numpy in, numpy out, one PCIe round trip per call.  For million-set sweeps the
+[timesteps, sets] discharge array (87.7 GB at 1M x 30 yr) should not cross
+PCIe at all, so this module keeps forcing, parameters, outputs and the
+per-set scores on the GPU.  torch is used only as the allocator / stream
+owner; every kernel is librrhip's.
+
+One process drives one GPU; several GPUs = several processes, each with its
+own shard of the parameter-set axis (rrmpg_amd.sharding).
+"""
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _dev_tensor(a, device, dtype=torch.float64):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    np_dtype = {torch.float64: np.float64, torch.int8: np.int8}[dtype]
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(device)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _Ensemble:
+    """Common plumbing: resident forcing, workspace, stream, launch."""
+
+    NUM_PARAMS = 0
+
+    def __init__(self, device):
+        self.lib = _lib.load()
+        _lib.require_gpu()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("rrmpg_amd.device needs a GPU device")
+        self._ws = None
+        self.num_timesteps = 0
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8,
+                                   device=self.device)
+        return self._ws
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def upload_params(self, params):
+        """Structured numpy parameter array (or [N, k] float array) -> device
+        block double[N][k]."""
+        if isinstance(params, torch.Tensor):
+            return params.to(self.device, torch.float64).contiguous()
+        if params.dtype.names:
+            flat, _, _ = _lib.params_block(params, self.NUM_PARAMS)
+        else:
+            flat = np.ascontiguousarray(params, dtype=np.float64)
+        return torch.from_numpy(flat.copy()).to(self.device)
+
+    def new_output(self, num_sets, rows_per_t=1):
+        shape = ((self.num_timesteps, num_sets) if rows_per_t == 1 else
+                 (self.num_timesteps, rows_per_t, num_sets))
+        return torch.empty(shape, dtype=torch.float64, device=self.device)
+
+    def _common(self, params, qobs, sse):
+        if params.dim() != 2 or params.shape[1] != self.NUM_PARAMS:
+            raise ValueError("params must be [N, %d]" % self.NUM_PARAMS)
+        n = params.shape[0]
+        if qobs is not None and sse is None:
+            sse = torch.empty(n, dtype=torch.float64, device=self.device)
+        return n, sse
+
+
+class HBVEduEnsemble(_Ensemble):
+    """HBV-Edu over N parameter sets, everything resident in HBM
+    (rr_hbvedu_simulate_dev)."""
+
+    NUM_PARAMS = 11
+
+    def __init__(self, temp, prec, month, PE_m, T_m, snow_init=0., soil_init=0.,
+                 s1_init=0., s2_init=0., device="cuda:0"):
+        """month: 1..12 as in HBVEdu.simulate; it is decremented here."""
+        super().__init__(device)
+        self.temp = _dev_tensor(temp, self.device)
+        self.prec = _dev_tensor(prec, self.device)
+        month0 = np.asarray(month, dtype=np.int64) - 1
+        if month0.min() < 0 or month0.max() > 11:
+            raise ValueError("The month array must be between an integer1 "
+                             "(Jan) and 12 (Dec).")
+        self.month0 = _dev_tensor(month0.astype(np.int8), self.device,
+                                  torch.int8)
+        self.PE_m = _dev_tensor(PE_m, self.device)
+        self.T_m = _dev_tensor(T_m, self.device)
+        self.inits = tuple(float(v) for v in (snow_init, soil_init, s1_init,
+                                              s2_init))
+        self.num_timesteps = int(self.prec.numel())
+
+    def run(self, params, qsim=None, storages=None, qobs=None, sse=None):
+        """Enqueue one sweep on the current stream (asynchronous).
+
+        params: device tensor [N, 11]; qsim: optional [T, N] output tensor;
+        storages: optional 4-tuple of [T, N] tensors; qobs: optional [T]
+        device tensor -> returns the per-set squared-error sums [N].
+        """
+        n, sse = self._common(params, qobs, sse)
+        t = self.num_timesteps
+        wsb = self.lib.rr_hbvedu_workspace_bytes(t, n)
+        ws = self._workspace(wsb)
+        st = storages or (None,) * 4
+        ld = qsim.stride(0) if qsim is not None else (
+            st[0].stride(0) if st[0] is not None else n)
+        rc = self.lib.rr_hbvedu_simulate_dev(
+            _ptr(self.temp), _ptr(self.prec), _ptr(self.month0),
+            _ptr(self.PE_m), _ptr(self.T_m), t, *self.inits, _ptr(params), n,
+            _ptr(qsim), *[_ptr(x) for x in st], ld, _ptr(qobs),
+            _ptr(sse) if qobs is not None else None, _ptr(ws), wsb,
+            self._stream())
+        _lib.check(rc, "rr_hbvedu_simulate_dev")
+        return sse if qobs is not None else None
+
+
+class ABCEnsemble(_Ensemble):
+    """ABC model over N parameter sets (rr_abc_simulate_dev)."""
+
+    NUM_PARAMS = 3
+
+    def __init__(self, prec, initial_state=0., device="cuda:0"):
+        super().__init__(device)
+        self.prec = _dev_tensor(prec, self.device)
+        self.initial_state = float(initial_state)
+        self.num_timesteps = int(self.prec.numel())
+
+    def run(self, params, qsim=None, storage=None, qobs=None, sse=None):
+        n, sse = self._common(params, qobs, sse)
+        t = self.num_timesteps
+        wsb = self.lib.rr_abc_workspace_bytes(t, n)
+        ws = self._workspace(wsb)
+        ld = qsim.stride(0) if qsim is not None else (
+            storage.stride(0) if storage is not None else n)
+        rc = self.lib.rr_abc_simulate_dev(
+            _ptr(self.prec), t, self.initial_state, _ptr(params), n,
+            _ptr(qsim), _ptr(storage), ld, _ptr(qobs),
+            _ptr(sse) if qobs is not None else None, _ptr(ws), wsb,
+            self._stream())
+        _lib.check(rc, "rr_abc_simulate_dev")
+        return sse if qobs is not None else None
+
+
+class GR4JEnsemble(_Ensemble):
+    """GR4J over N parameter sets (rr_gr4j_simulate_dev)."""
+
+    NUM_PARAMS = 4
+
+    def __init__(self, prec, etp, s_init=0., r_init=0., device="cuda:0"):
+        super().__init__(device)
+        self.prec = _dev_tensor(prec, self.device)
+        self.etp = _dev_tensor(etp, self.device)
+        self.inits = (float(s_init), float(r_init))
+        self.num_timesteps = int(self.prec.numel())
+
+    def run(self, params, qsim=None, storages=None, qobs=None, sse=None):
+        n, sse = self._common(params, qobs, sse)
+        t = self.num_timesteps
+        wsb = self.lib.rr_gr4j_workspace_bytes(t, n)
+        ws = self._workspace(wsb)
+        st = storages or (None,) * 2
+        ld = qsim.stride(0) if qsim is not None else (
+            st[0].stride(0) if st[0] is not None else n)
+        rc = self.lib.rr_gr4j_simulate_dev(
+            _ptr(self.prec), _ptr(self.etp), t, *self.inits, _ptr(params), n,
+            _ptr(qsim), *[_ptr(x) for x in st], ld, _ptr(qobs),
+            _ptr(sse) if qobs is not None else None, _ptr(ws), wsb,
+            self._stream())
+        _lib.check(rc, "rr_gr4j_simulate_dev")
+        return sse if qobs is not None else None
+
+
+class CemaneigeEnsemble(_Ensemble):
+    """Cemaneige snow routine over N parameter sets
+    (rr_cemaneige_simulate_dev).  Forcing: [T, L] layer arrays as produced by
+    rrmpg_amd.models.cemaneige.prepare_snow_inputs."""
+
+    NUM_PARAMS = 2
+
+    def __init__(self, layer_prec, layer_mean_temp, frac_solid_prec,
+                 snow_pack_init=0., thermal_state_init=0., device="cuda:0"):
+        super().__init__(device)
+        self.prec = _dev_tensor(layer_prec, self.device)
+        self.temp = _dev_tensor(layer_mean_temp, self.device)
+        self.frac = _dev_tensor(frac_solid_prec, self.device)
+        self.inits = (float(snow_pack_init), float(thermal_state_init))
+        self.num_timesteps, self.num_layers = (int(x) for x in
+                                               self.prec.shape)
+
+    def run(self, params, outflow=None, storages=None, qobs=None, sse=None):
+        n, sse = self._common(params, qobs, sse)
+        t, nl = self.num_timesteps, self.num_layers
+        wsb = self.lib.rr_cemaneige_workspace_bytes(t, nl, n)
+        ws = self._workspace(wsb)
+        st = storages or (None,) * 2
+        ld = outflow.stride(0) if outflow is not None else (
+            st[0].stride(1) if st[0] is not None else n)
+        rc = self.lib.rr_cemaneige_simulate_dev(
+            _ptr(self.prec), _ptr(self.temp), _ptr(self.frac), t, nl,
+            *self.inits, _ptr(params), n, _ptr(outflow),
+            *[_ptr(x) for x in st], ld, _ptr(qobs),
+            _ptr(sse) if qobs is not None else None, _ptr(ws), wsb,
+            self._stream())
+        _lib.check(rc, "rr_cemaneige_simulate_dev")
+        return sse if qobs is not None else None
+
+
+class CemaneigeGR4JEnsemble(_Ensemble):
+    """Fused Cemaneige -> GR4J over N parameter sets
+    (rr_cemaneigegr4j_simulate_dev)."""
+
+    NUM_PARAMS = 6
+
+    def __init__(self, layer_prec, layer_mean_temp, frac_solid_prec, etp,
+                 snow_pack_init=0., thermal_state_init=0., s_init=0.,
+                 r_init=0., device="cuda:0"):
+        super().__init__(device)
+        self.prec = _dev_tensor(layer_prec, self.device)
+        self.temp = _dev_tensor(layer_mean_temp, self.device)
+        self.frac = _dev_tensor(frac_solid_prec, self.device)
+        self.etp = _dev_tensor(etp, self.device)
+        self.inits = tuple(float(v) for v in (snow_pack_init,
+                                              thermal_state_init, s_init,
+                                              r_init))
+        self.num_timesteps, self.num_layers = (int(x) for x in
+                                               self.prec.shape)
+
+    def run(self, params, qsim=None, storages=None, qobs=None, sse=None):
+        """storages: optional (G, eTG, s_store, r_store)."""
+        n, sse = self._common(params, qobs, sse)
+        t, nl = self.num_timesteps, self.num_layers
+        wsb = self.lib.rr_cemaneigegr4j_workspace_bytes(t, nl, n)
+        ws = self._workspace(wsb)
+        st = storages or (None,) * 4
+        ld = qsim.stride(0) if qsim is not None else (
+            st[2].stride(0) if st[2] is not None else n)
+        rc = self.lib.rr_cemaneigegr4j_simulate_dev(
+            _ptr(self.prec), _ptr(self.temp), _ptr(self.etp), _ptr(self.frac),
+            t, nl, *self.inits, _ptr(params), n, _ptr(qsim),
+            *[_ptr(x) for x in st], ld, _ptr(qobs),
+            _ptr(sse) if qobs is not None else None, _ptr(ws), wsb,
+            self._stream())
+        _lib.check(rc, "rr_cemaneigegr4j_simulate_dev")
+        return sse if qobs is not None else None
