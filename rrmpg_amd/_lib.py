@@ -5,7 +5,9 @@ MI355X is visible when a simulation is requested, a RuntimeError is raised.
 """
 
 import ctypes
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -74,10 +76,38 @@ def exported_names():
     return sorted(_SIGNATURES)
 
 
+def _share_hip_runtime_with_torch():
+    """Make librrhip and PyTorch use ONE HIP runtime in this process.
+
+    The PyTorch ROCm wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7) and asks for it as "libamdhip64.so".  If librrhip pulled
+    in the system runtime first, a later `import torch` would load a second
+    copy and see no GPU.  Loading torch's copy first makes librrhip's
+    libamdhip64.so.7 dependency resolve to it.  Without torch installed the
+    system runtime is used.
+    """
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib",
+                        "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load librrhip.so (once).  Raises RuntimeError if it is not built."""
     global _lib
     if _lib is None:
+        _share_hip_runtime_with_torch()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "librrhip.so is not built (%s). Run "

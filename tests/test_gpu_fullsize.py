@@ -1,0 +1,186 @@
+"""GPU tests at BASELINE.json's sizes through the HBM-resident *_dev entry
+points: size-independent properties plus oracle spot checks.
+
+configs[0] ABC 1 set x 10 yr          -> bit-exact vs oracle
+configs[1] HBV-Edu 100k sets x 30 yr  -> column permutation invariance,
+                                         block-split invariance (ld > N),
+                                         fused SSE == SSE of the written qsim,
+                                         64 random columns vs the oracle
+configs[2] GR4J 1M sets x 30 yr       -> score-only sweep; block-split
+                                         invariance; random columns vs oracle
+configs[3] CemaneigeGR4J, one GPU's shard (125k sets) of the 1M-set sweep,
+           per-set NSE                 -> random columns vs oracle
+"""
+
+import numpy as np
+import pytest
+
+from .conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from rrmpg_amd import _lib, device, models
+    from rrmpg_amd.utils import synthetic as syn
+    _lib.load()
+    _lib.require_gpu()
+    return dict(torch=torch, device=device, models=models, syn=syn,
+                f=syn.make_forcing(syn.T_30YR))
+
+
+def _flat(p, cls):
+    return np.stack([p[n] for n in cls._param_list], axis=1)
+
+
+def test_config0_abc_single_set(env, oracle):
+    syn, torch = env["syn"], env["torch"]
+    f = env["f"]
+    prec = f["prec"][:syn.T_10YR]
+    ens = env["device"].ABCEnsemble(prec, 1.5)
+    flat = np.array([[0.3, 0.2, 0.1]])
+    q, s = ens.new_output(1), ens.new_output(1)
+    ens.run(ens.upload_params(flat), q, s)
+    ref = oracle.simulate_abc(prec, 1.5, flat, return_storage=True)
+    assert np.array_equal(q.cpu().numpy(), ref[0])
+    assert np.array_equal(s.cpu().numpy(), ref[1])
+
+
+def test_config1_hbv_100k_properties(env, oracle):
+    torch, syn, f = env["torch"], env["syn"], env["f"]
+    HBV = env["models"].HBVEdu
+    n, t = 100_000, syn.T_30YR
+    np.random.seed(1)
+    flat = _flat(HBV().get_random_params(n), HBV)
+    ens = env["device"].HBVEduEnsemble(f["temp"], f["prec"], f["month"],
+                                       f["PE_m"], f["T_m"], **syn.HBV_INITS)
+    params = ens.upload_params(flat)
+    qsim = ens.new_output(n)
+    inits = [syn.HBV_INITS[k] for k in ("snow_init", "soil_init", "s1_init",
+                                        "s2_init")]
+    truth = oracle.simulate_hbvedu(f["temp"], f["prec"], f["month"] - 1,
+                                   f["PE_m"], f["T_m"], inits, flat[:1])
+    qobs = torch.from_numpy(syn.make_qobs(truth)).cuda()
+    sse = ens.run(params, qsim, qobs=qobs)
+    torch.cuda.synchronize()
+    assert qsim.shape == (t, n)
+    assert bool((qsim[0] == 0).all())                   # quirk Q3
+    assert bool(torch.isfinite(qsim).all())
+    # (a) fused SSE == SSE recomputed from the qsim that was written
+    sse2 = ((qobs[:, None] - qsim) ** 2).sum(0)
+    assert float(((sse - sse2).abs() / sse2).max()) < 1e-12
+    # (b) 64 random columns against the oracle
+    rng = np.random.default_rng(0)
+    cols = np.sort(rng.choice(n, 64, replace=False))
+    ref = oracle.simulate_hbvedu(f["temp"], f["prec"], f["month"] - 1,
+                                 f["PE_m"], f["T_m"], inits, flat[cols],
+                                 nthreads=8)
+    got = qsim[:, torch.from_numpy(cols).cuda()].cpu().numpy()
+    assert rel_err(got, ref) < RTOL
+    # (c) permuting the parameter sets permutes the columns, bit for bit
+    perm = torch.randperm(n, device="cuda")
+    q2 = ens.new_output(n)
+    sse_p = ens.run(params[perm].contiguous(), q2, qobs=qobs)
+    torch.cuda.synchronize()
+    assert torch.equal(q2, qsim[:, perm])
+    assert torch.equal(sse_p, sse[perm])
+    # (d) two column blocks written into one [T, N] array through ld > N give
+    # the same array as one launch (how several GPUs / host blocks assemble)
+    q3 = ens.new_output(n)
+    h = 37_001                                       # odd split point
+    left = q3[:, :h]
+    right = q3[:, h:]
+    assert left.stride(0) == n and right.stride(0) == n
+    ens.run(params[:h].contiguous(), left)
+    ens.run(params[h:].contiguous(), right)
+    torch.cuda.synchronize()
+    assert torch.equal(q3, qsim)
+    # (e) score-only mode gives the same scores
+    sse_only = ens.run(params, None, qobs=qobs)
+    torch.cuda.synchronize()
+    assert torch.equal(sse_only, sse)
+    # (f) all four storages, 5k sets: final states vs oracle
+    m = 5_000
+    st = tuple(ens.new_output(m) for _ in range(4))
+    qm = ens.new_output(m)
+    ens.run(params[:m].contiguous(), qm, st)
+    torch.cuda.synchronize()
+    assert torch.equal(qm, qsim[:, :m])
+    ref = oracle.simulate_hbvedu(f["temp"], f["prec"], f["month"] - 1,
+                                 f["PE_m"], f["T_m"], inits, flat[:32],
+                                 return_storage=True)
+    for a, b in zip(st, ref[1:]):
+        assert rel_err(a[:, :32].cpu().numpy(), b) < RTOL
+
+
+def test_config2_gr4j_1m_scores(env, oracle):
+    torch, syn, f = env["torch"], env["syn"], env["f"]
+    GR4J = env["models"].GR4J
+    n = 1_000_000
+    np.random.seed(1)
+    flat = _flat(GR4J().get_random_params(n), GR4J)
+    ens = env["device"].GR4JEnsemble(f["prec"], f["etp"], **syn.GR4J_INITS)
+    params = ens.upload_params(flat)
+    truth = oracle.simulate_gr4j(f["prec"], f["etp"], (0.6, 0.7), flat[:1])
+    qobs_h = syn.make_qobs(truth)
+    qobs = torch.from_numpy(qobs_h).cuda()
+    sse = ens.run(params, None, qobs=qobs)
+    torch.cuda.synchronize()
+    assert sse.shape == (n,) and bool(torch.isfinite(sse).all())
+    # block-split invariance of the scores
+    a, b = 123_457, 123_457 + 4_099
+    part = ens.run(params[a:b].contiguous(), None, qobs=qobs)
+    torch.cuda.synchronize()
+    assert torch.equal(part, sse[a:b])
+    # random columns vs oracle (scores and series)
+    rng = np.random.default_rng(1)
+    cols = np.sort(rng.choice(n, 32, replace=False))
+    ref = oracle.simulate_gr4j(f["prec"], f["etp"], (0.6, 0.7), flat[cols],
+                               nthreads=8)
+    ref_sse = ((qobs_h[:, None] - ref) ** 2).sum(0)
+    got = sse[torch.from_numpy(cols).cuda()].cpu().numpy()
+    assert rel_err(got, ref_sse) < RTOL
+    q = ens.new_output(32)
+    ens.run(ens.upload_params(flat[cols]), q)
+    assert rel_err(q.cpu().numpy(), ref) < RTOL
+
+
+def test_config3_cemaneigegr4j_shard_nse(env, oracle):
+    torch, syn, f = env["torch"], env["syn"], env["f"]
+    from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+    from rrmpg_amd.sharding import shard_bounds
+    from rrmpg_amd.utils.metrics import calc_nse, nse_from_sse
+    CG = env["models"].CemaneigeGR4J
+    total = 1_000_000
+    a, b = shard_bounds(total, 8, 3)                # the shard of GPU 3 of 8
+    n = b - a
+    assert n == 125_000
+    np.random.seed(1)
+    flat_all = _flat(CG().get_random_params(total), CG)
+    flat = flat_all[a:b]
+    layers, inits = prepare_snow_inputs(
+        f["prec"], f["temp"], f["tmin"], f["tmax"], syn.STATION_HEIGHT, 0., 0.,
+        list(syn.ALTITUDES), etp=f["etp"])
+    ens = env["device"].CemaneigeGR4JEnsemble(*layers, 0., 0., 0.6, 0.7)
+    params = ens.upload_params(flat)
+    truth = oracle.simulate_cemaneigegr4j(layers[0], layers[1], layers[3],
+                                          layers[2], (0., 0., 0.6, 0.7),
+                                          flat_all[:1])
+    qobs_h = syn.make_qobs(truth)
+    qobs = torch.from_numpy(qobs_h).cuda()
+    sse = ens.run(params, None, qobs=qobs)
+    torch.cuda.synchronize()
+    nse = nse_from_sse(sse.cpu().numpy(), qobs_h)
+    assert nse.shape == (n,) and np.isfinite(nse).all()
+    rng = np.random.default_rng(2)
+    cols = np.sort(rng.choice(n, 16, replace=False))
+    ref = oracle.simulate_cemaneigegr4j(layers[0], layers[1], layers[3],
+                                        layers[2], (0., 0., 0.6, 0.7),
+                                        flat[cols], nthreads=8)
+    for j, c in enumerate(cols):
+        want = calc_nse(qobs_h, ref[:, j])
+        assert abs(nse[c] - want) <= 1e-10 * max(1.0, abs(want))

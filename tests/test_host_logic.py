@@ -1,0 +1,322 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol
+include/rrhip.h declares, the host mirror of the reference's interface
+(validation, errors, parameter handling, sampling, preprocessing, metrics)
+behaves like the reference, and nothing falls back to a CPU compute path.
+
+The expectations follow the reference's own unit tests
+(reference: test/test_models.py:20-140, test/test_utils.py:19-97,
+test/test_tools.py:26-29).
+"""
+
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from .conftest import REPO, golden
+
+from rrmpg_amd import _lib
+from rrmpg_amd.models import (ABCModel, HBVEdu, GR4J, Cemaneige,
+                              CemaneigeGR4J)
+from rrmpg_amd.models import cemaneige_utils as cu
+from rrmpg_amd.models.basemodel import BaseModel
+from rrmpg_amd.tools import monte_carlo
+from rrmpg_amd.utils.array_checks import (check_for_negatives,
+                                          validate_array_input)
+from rrmpg_amd.utils.metrics import (calc_mse, calc_nse, calc_rmse,
+                                     mse_from_sse, nse_from_sse)
+
+NO_GPU = _lib.device_count() == 0
+
+
+# ------------------------------------------------------------- the C-ABI
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(REPO, "include", "rrhip.h")).read()
+    declared = set(re.findall(r"\b(rr_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.exported_names())
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.rr_version() >= 100
+    assert isinstance(lib.rr_device_count(), int)
+
+
+def test_workspace_queries_need_no_gpu():
+    lib = _lib.load()
+    assert lib.rr_hbvedu_workspace_bytes(10957, 1000) >= 10957 * 32
+    assert lib.rr_gr4j_workspace_bytes(10957, 1000) >= 10957 * 16
+    assert lib.rr_cemaneige_workspace_bytes(10957, 5, 10) >= 10957 * 15 * 8
+    assert lib.rr_cemaneigegr4j_workspace_bytes(10957, 5, 10) >= 10957 * 16 * 8
+    assert lib.rr_abc_workspace_bytes(10, 10) > 0
+
+
+def test_argument_errors_are_reported_without_gpu():
+    lib = _lib.load()
+    # negative size / qobs without sse are caught before any HIP call
+    rc = lib.rr_abc_simulate(None, -1, 0.0, None, 0, None, None, None, None)
+    assert rc == -2 and b"negative size" in lib.rr_last_error()
+    x = np.zeros(4)
+    p = x.ctypes.data_as(_lib._f64p)
+    rc = lib.rr_abc_simulate(p, 4, 0.0, p, 1, p, None, p, None)
+    assert rc == -1 and b"qobs and sse" in lib.rr_last_error()
+    # empty problems succeed trivially
+    assert lib.rr_abc_simulate(p, 0, 0.0, p, 1, p, None, None, None) == 0
+
+
+@pytest.mark.skipif(not NO_GPU, reason="needs a box without a GPU")
+def test_no_cpu_fallback():
+    """Without a GPU every simulation must fail loudly."""
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ABCModel().simulate(np.ones(10))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        monte_carlo(ABCModel(), 4, prec=np.ones(10))
+    x = np.ones(4)
+    p = x.ctypes.data_as(_lib._f64p)
+    lib = _lib.load()
+    rc = lib.rr_abc_simulate(p, 4, 0.0, p, 1, p, None, None, None)
+    assert rc == -5 and b"no CPU path" in lib.rr_last_error()
+
+
+def test_product_never_touches_the_oracle():
+    """rrmpg_amd/ must not import, load or mention the oracle."""
+    for root, _, files in os.walk(os.path.join(REPO, "rrmpg_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
+                text = open(os.path.join(root, fn), errors="replace").read()
+                assert "oracle" not in text.lower(), os.path.join(root, fn)
+
+
+# ------------------------------------------------ BaseModel (test_models.py)
+class TestBaseModelFunctions:
+    param_names = ['a', 'b', 'c']
+    default_bounds = {'a': (0, 1), 'b': (0, 1), 'c': (0, 1)}
+    dtype = np.dtype([('a', np.float64), ('b', np.float64),
+                      ('c', np.float64)])
+
+    def test_accessors(self):
+        model = ABCModel()
+        assert issubclass(model.__class__, BaseModel)
+        assert model.get_parameter_names() == self.param_names
+        assert model.get_default_bounds() == self.default_bounds
+        assert model.get_dtype() == self.dtype
+        for p in self.param_names:
+            assert p in model.get_params()
+
+    def test_random_params_in_default_bounds(self):
+        model = ABCModel()
+        params = model.get_random_params()
+        for p in self.param_names:
+            lo, hi = self.default_bounds[p]
+            assert lo <= params[p][0] <= hi
+        many = model.get_random_params(num=24)
+        assert many.size == 24
+        assert (many['a'] + many['b'] <= 1).all()
+
+    def test_set_params(self):
+        model = ABCModel()
+        rand = model.get_random_params()
+        params = {p: rand[p][0] for p in self.param_names}
+        model.set_params(params)
+        assert params == model.get_params()
+        model.set_params(rand)            # ndarray of the model dtype
+        model.set_params(rand[0])         # single record
+        assert model.get_params()['a'] == rand['a'][0]
+        with pytest.raises(AttributeError, match="Unknow parameter"):
+            model.set_params({'zz': 1.0})
+        with pytest.raises(ValueError, match="must be numerical"):
+            model.set_params({'a': 'x'})
+        with pytest.raises(TypeError, match="wrong data type"):
+            model.set_params(np.zeros(1, dtype=GR4J._dtype))
+        with pytest.raises(TypeError, match="Wrong input data type"):
+            model.set_params([1, 2, 3])
+        with pytest.raises(AttributeError, match="Missing the following"):
+            ABCModel(params={'a': 0.1})
+
+    def test_dtypes_are_packed_f64_records(self):
+        for cls, k in [(ABCModel, 3), (HBVEdu, 11), (GR4J, 4), (Cemaneige, 2),
+                       (CemaneigeGR4J, 6)]:
+            assert cls._dtype.itemsize == 8 * k
+            assert list(cls._dtype.names) == cls._param_list
+            p = cls().get_random_params(5)
+            flat, _, n = _lib.params_block(p, k)
+            assert n == 5 and flat.shape == (5, k)
+            for j, name in enumerate(cls._param_list):
+                assert np.array_equal(flat[:, j], p[name])
+
+
+def test_sampling_reproduces_the_reference_stream():
+    g = golden("sampling")
+    for name, cls in [("abc", ABCModel), ("hbvedu", HBVEdu), ("gr4j", GR4J),
+                      ("cemaneige", Cemaneige),
+                      ("cemaneigegr4j", CemaneigeGR4J)]:
+        np.random.seed(1234)
+        mdl = cls()
+        pp = mdl.get_random_params(7)
+        ctor = np.array([mdl.get_params()[k]
+                         for k in mdl.get_parameter_names()])
+        assert np.array_equal(ctor, g[name + "_ctor"]), name
+        flat = np.stack([pp[k] for k in mdl.get_parameter_names()], 1)
+        assert np.array_equal(flat, g[name + "_rand7"]), name
+
+
+# ---------------------------------------------- input validation & errors
+def test_negative_rain_messages():
+    with pytest.raises(ValueError,
+                       match="In the precipitation array are negative values."):
+        ABCModel().simulate([-1, 1, 1])
+    with pytest.raises(ValueError,
+                       match="In the precipitation array are negative values."):
+        HBVEdu().simulate(temp=np.random.uniform(-15, 25, 100),
+                          prec=np.arange(-1, 99),
+                          month=np.random.randint(1, 12, 100),
+                          PE_m=np.random.uniform(0, 4, 12),
+                          T_m=np.random.uniform(-5, 15, 12))
+    with pytest.raises(ValueError, match="contains negative values"):
+        GR4J().simulate([-1., 2.], [1., 1.])
+    with pytest.raises(ValueError, match="contains negative values"):
+        Cemaneige().simulate([-1., 2.], [1., 1.], [0., 0.], [2., 2.], 500)
+
+
+def test_hbvedu_validation():
+    ok = dict(temp=np.zeros(10), prec=np.ones(10), month=np.ones(10),
+              PE_m=np.ones(12), T_m=np.ones(12))
+    m = HBVEdu()
+    with pytest.raises(RuntimeError, match="must be of equal size"):
+        m.simulate(**{**ok, "prec": np.ones(9)})
+    with pytest.raises(RuntimeError, match="must be of length 12"):
+        m.simulate(**{**ok, "PE_m": np.ones(11)})
+    with pytest.raises(ValueError, match="month array must be between"):
+        m.simulate(**{**ok, "month": np.zeros(10)})
+    with pytest.raises(ValueError, match="month array must be between"):
+        m.simulate(**{**ok, "month": np.full(10, 13)})
+    with pytest.raises(TypeError, match="models own custom data type"):
+        m.simulate(**ok, params=np.zeros(2, dtype=GR4J._dtype))
+    with pytest.raises(TypeError, match="must be either a list"):
+        m.simulate(**{**ok, "temp": (1, 2, 3)})
+    with pytest.raises(ValueError, match="purely numerical"):
+        m.simulate(**{**ok, "temp": ['a'] * 10})
+    # the caller's month array is never modified (quirk Q7)
+    month = np.full(10, 3)
+    try:
+        m.simulate(**{**ok, "month": month})
+    except RuntimeError:
+        pass
+    assert (month == 3).all()
+
+
+def test_gr4j_and_abc_validation():
+    m = GR4J()
+    with pytest.raises(RuntimeError, match="must be of the same size"):
+        m.simulate([1., 2.], [1.])
+    with pytest.raises(TypeError, match="'s1_init' must be a Number"):
+        m.simulate([1., 2.], [1., 1.], s_init="a")
+    with pytest.raises(ValueError, match="production storage must be in"):
+        m.simulate([1., 2.], [1., 1.], s_init=1.5)
+    with pytest.raises(ValueError, match="routing storage must be in"):
+        m.simulate([1., 2.], [1., 1.], r_init=-0.1)
+    a = ABCModel()
+    with pytest.raises(TypeError, match="initial_state"):
+        a.simulate([1., 2.], initial_state=-1)
+    with pytest.raises(TypeError, match="return_storage arg must be a boolean"):
+        a.simulate([1., 2.], return_storage=1)
+
+
+def test_cemaneige_validation():
+    m = CemaneigeGR4J()
+    s = [1., 2., 3.]
+    with pytest.raises(RuntimeError, match="must have the same length"):
+        m.simulate(s, s, s, s, [1., 2.], 500)
+    with pytest.raises(TypeError, match="'altitudes' must be a list"):
+        m.simulate(s, s, s, s, s, 500, altitudes=(1, 2))
+    with pytest.raises(TypeError, match="must be numbers"):
+        m.simulate(s, s, s, s, s, 500, altitudes=['a'])
+    with pytest.raises(TypeError, match="'met_station_height' must be a"):
+        m.simulate(s, s, s, s, s, None)
+    with pytest.raises(TypeError, match="'snow_pack_init' must be a Number"):
+        m.simulate(s, s, s, s, s, 500, snow_pack_init="x")
+    with pytest.raises(TypeError, match="'r_init' must be a Number"):
+        m.simulate(s, s, s, s, s, 500, r_init="x")
+    with pytest.raises(TypeError, match="'thermal_state_init'"):
+        Cemaneige().simulate(s, s, s, s, 500, thermal_state_init=[1])
+
+
+def test_monte_carlo_argument_checks():
+    with pytest.raises(TypeError, match="must be one of the models"):
+        monte_carlo(object(), 3, prec=[1.])
+    with pytest.raises(TypeError, match="positive integer"):
+        monte_carlo(ABCModel(), 0, prec=[1.])
+    with pytest.raises(TypeError, match="positive integer"):
+        monte_carlo(ABCModel(), 2.5, prec=[1.])
+    with pytest.raises(ValueError, match="needs qobs"):
+        monte_carlo(ABCModel(), 3, return_qsim=False, prec=[1.])
+
+
+# ----------------------------------------------- preprocessing & metrics
+def test_cemaneige_preprocessing_matches_reference():
+    p = golden("syn_cemaneige_prep")
+    lp = cu.extrapolate_precipitation(p["prec"], p["altitudes"], p["station"])
+    lmin, lmean, lmax = cu.extrapolate_temperature(
+        p["tmin"], p["temp"], p["tmax"], p["altitudes"], p["station"])
+    assert np.array_equal(lp, p["layer_prec"])
+    assert np.array_equal(lmin, p["layer_min"])
+    assert np.array_equal(lmean, p["layer_mean"])
+    assert np.array_equal(lmax, p["layer_max"])
+    assert np.array_equal(
+        cu.calculate_solid_fraction(lp, p["altitudes"], lmean, lmin, lmax),
+        p["frac_solid"])
+    # >= 1500 m and > 4000 m branches
+    lp = cu.extrapolate_precipitation(p["prec"], p["altitudes_hi"],
+                                      p["station_hi"])
+    lmin, lmean, lmax = cu.extrapolate_temperature(
+        p["tmin"], p["temp"], p["tmax"], p["altitudes_hi"], p["station_hi"])
+    assert np.array_equal(lp, p["layer_prec_hi"])
+    assert np.array_equal(lmean, p["layer_mean_hi"])
+    assert np.array_equal(
+        cu.calculate_solid_fraction(lp, p["altitudes_hi"], lmean, lmin, lmax),
+        p["frac_solid_hi"])
+    assert np.array_equal(
+        cu.extrapolate_precipitation(p["prec"][:64], p["altitudes_hi"],
+                                     p["station_vhi"]), p["layer_prec_vhi"])
+
+
+def test_metrics_known_answers():
+    assert calc_nse(obs=[1, 2, 3], sim=[1, 2, 3]) == 1
+    assert calc_nse(obs=[1, 2, 3], sim=[2, 2, 2]) == 0
+    with pytest.raises(RuntimeError, match="Maybe you should use the "
+                                           "Mean-Squared-Error instead."):
+        calc_nse(obs=[2, 2, 2], sim=[1, 2, 3])
+    assert calc_rmse(obs=[1, 2, 3], sim=[1, 2, 3]) == 0
+    assert calc_rmse(obs=[1, 1, 1], sim=[3, 3, 3]) == 2
+    assert calc_mse(obs=[1, 2, 3], sim=[1, 2, 3]) == 0
+    assert calc_mse(obs=[1, 1, 1], sim=[3, 3, 3]) == 4
+    with pytest.raises(ValueError, match="same size"):
+        calc_mse([1, 2], [1, 2, 3])
+    obs = np.array([1., 2., 4.])
+    sim = np.array([[1., 2.], [2., 2.], [3., 5.]])
+    sse = ((obs[:, None] - sim) ** 2).sum(0)
+    assert np.allclose(mse_from_sse(sse, 3),
+                       [calc_mse(obs, sim[:, 0]), calc_mse(obs, sim[:, 1])])
+    assert np.allclose(nse_from_sse(sse, obs),
+                       [calc_nse(obs, sim[:, 0]), calc_nse(obs, sim[:, 1])])
+
+
+def test_array_checks():
+    assert not check_for_negatives(np.array([1, 2, 3, 4, 5], dtype=np.float64))
+    assert check_for_negatives(np.array([1, 2, -3, 4, 5], dtype=np.float64))
+    vals = [1, 2, 3, 4]
+    arr = validate_array_input(pd.Series(data=vals, dtype=np.float64),
+                               np.float64, 'arr')
+    assert arr.tolist() == np.array(vals, np.float64).tolist()
+    assert validate_array_input([1., 2.], np.float64, 'arr').tolist() == [1., 2.]
+    with pytest.raises(ValueError, match="The data in the parameter array "
+                                         "'arr' must be purely numerical."):
+        validate_array_input(['a', 'b', 1], np.float64, 'arr')
+    with pytest.raises(TypeError, match="The array arr must be either a list, "
+                                        "numpy.ndarray or pandas.Series"):
+        validate_array_input((1, 2, 3), np.float64, 'arr')
+    # always a flattened copy
+    src = np.ones((2, 3))
+    out = validate_array_input(src, np.float64, 'arr')
+    assert out.shape == (6,) and out is not src
