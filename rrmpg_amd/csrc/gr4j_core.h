@@ -196,6 +196,24 @@ struct UhLds {
     }
 };
 
+// The three float powers of the daily step have fixed exponents, so they are
+// evaluated with correctly rounded sqrt / divide / multiply instead of the
+// general pow (224 VALU instructions in OCML): each is within ~2 ulp of the
+// exact power (libm's pow is within 1 ulp), far inside the 1e-10 parity
+// tolerance, and IEEE special cases come out as pow's do:
+//   b**(-0.25), b = 1 + v^4 >= 1 (or inf/NaN): 1/sqrt(sqrt(b));
+//   inf -> 0, NaN -> NaN.
+//   x**3.5: x*x*x*sqrt(x); 0 -> 0, inf -> inf, x < 0 -> NaN (as pow for a
+//   negative base with a non-integer exponent), NaN -> NaN.
+__device__ __forceinline__ double inv_fourth_root(double b)
+{
+    return 1.0 / sqrt(sqrt(b));
+}
+__device__ __forceinline__ double pow_3_5(double x)
+{
+    return x * x * x * sqrt(x);
+}
+
 // One day of GR4J (gr4j_model.py:86-154).  s, r: production / routing store
 // (in/out).  Returns the simulated discharge of the day.
 template <class UH>
@@ -227,7 +245,7 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
     // percolation (:117); **4 is two squarings
     const double v = 4.0 / 9.0 * sn / P.x1;
     const double v2 = v * v;
-    const double perc = sn * (1 - pow(1 + v2 * v2, -0.25));
+    const double perc = sn * (1 - inv_fourth_root(1 + v2 * v2));
     sn = sn - perc;                                             // :120
     const double p_r = perc + (p_n - p_s);                      // :123
     const double p_r_uh1 = 0.9 * p_r;                           // :126-127
@@ -236,11 +254,11 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
     double head1, head2;
     uh.route(p_r_uh1, p_r_uh2, head1, head2);                   // :130-136
 
-    const double gw_exchange = P.x2 * pow(r / P.x3, 3.5);       // :139
+    const double gw_exchange = P.x2 * pow_3_5(r / P.x3);        // :139
     double rn = nb_max(0.0, r + head1 + gw_exchange);           // :142
     const double w = rn / P.x3;
     const double w2 = w * w;
-    const double q_r = rn * (1 - pow(1 + w2 * w2, -0.25));      // :145
+    const double q_r = rn * (1 - inv_fourth_root(1 + w2 * w2)); // :145
     rn = rn - q_r;                                              // :148
     const double q_d = nb_max(0.0, head2 + gw_exchange);        // :151
     s = sn;

@@ -68,6 +68,8 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
                  PWP = p[5], K_0 = p[6], K_1 = p[7], K_2 = p[8], K_p = p[9],
                  L = p[10];
 
+    const bool beta_small = fabs(Beta) <= 64.0;
+
     double snow = snow_init, soil = soil_init, s1 = s1_init, s2 = s2_init;
     double acc = 0.0;
     int64_t off = i;   // t * ld + i
@@ -97,8 +99,22 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         const double snow_n = cold ? snow + f.prec : nb_max(0.0, snow - melt);
         const double liquid_water = cold ? 0.0 : f.prec + nb_min(snow, melt);
 
-        // effective precipitation (:99)
-        const double prec_eff = liquid_water * pow(soil / FC, Beta);
+        // effective precipitation (:99): liquid_water * (soil/FC)**Beta.
+        // On dry or frozen days liquid_water is exactly 0 for every lane of
+        // the wave (the forcing is shared), and 0 * pow(..) is 0 whenever
+        // pow(..) is finite -- guaranteed when the base lies in [2^-10, 2^10]
+        // and |Beta| <= 64 -- so the wave skips pow altogether.  Outside that
+        // box (NaN/inf/zero/negative base, huge Beta) pow is evaluated and
+        // 0 * inf / 0 * NaN propagate exactly as in the reference.
+        const double wetness = soil / FC;
+        const bool need_pow =
+            (liquid_water != 0.0) ||
+            !(wetness >= 0x1p-10 && wetness <= 0x1p10 && beta_small);
+        double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
+        if (__any(need_pow)) {
+            const double pw = pow(wetness, Beta);
+            prec_eff = need_pow ? liquid_water * pw : liquid_water;
+        }
 
         // potential / actual evapotranspiration (:102-108)
         const double pe = (1 + C * f.dtemp) * f.pe_m;
