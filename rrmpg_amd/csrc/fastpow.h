@@ -1,0 +1,155 @@
+// fastpow.h -- x**y for the ensemble kernels, fp64, ~1 ulp, ~75 VALU
+// instructions instead of the ~224 of OCML's general pow.
+//
+// Why: after the scalar forcing loads and coalesced stores, the HBV-Edu step
+// is fp64-VALU-issue bound and (soil/FC)**Beta (reference:
+// rrmpg/models/hbvedu_model.py:99) was two thirds of its instructions
+// (profiles/README.md, r01a).  The reference evaluates that power with the
+// platform libm (numba -> llvm.pow.f64), which is itself only faithful to
+// <1 ulp, so any implementation of comparable accuracy is an equally valid
+// realisation of the same statement; parity is asserted at 1e-10 relative on
+// the discharge (observed ~1e-14).
+//
+// Method (x > 0 finite, the fast path):
+//   x = 2^k * m, m in [sqrt(1/2), sqrt(2));  s = (m-1)/(m+1) as a
+//   double-double (s_hi + s_lo; the division residual is taken with FMA);
+//   ln m = 2 atanh(s) = 2 s + 2 s^3 (1/3 + s^2/5 + ... + s^20/23): leading
+//   term in double-double, tail (<= 1 % of it) in double;  log2 x = k +
+//   ln m * log2(e) in double-double;  z = y * log2 x in double-double;
+//   2^z = 2^n * 2^r, n = rint(z), |r| <= 1/2, 2^r by its degree-13 Taylor
+//   polynomial (truncation 4e-18).
+// Everything else (x <= 0, inf, NaN, |z| >= 1000 i.e. over/underflow range,
+// non-finite y) is not handled here: fastpow_ok() is false and the caller
+// falls back to the general pow for the wave, so IEEE special cases stay
+// exactly those of pow().
+//
+// The same source compiles for the host (tests/test_fastpow_cpu.py builds a
+// small harness with g++ and checks it against 80-bit powl): only the five
+// primitives below differ.
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FP_FN __device__ __forceinline__
+#define FP_RCP(g) __builtin_amdgcn_rcp(g)
+#define FP_FMA(a, b, c) __builtin_fma((a), (b), (c))
+// Horner step a*b + CONSTANT as ONE v_fma_f64 with the constant in an SGPR
+// pair.  Left to itself hipcc keeps each polynomial coefficient in a VGPR pair
+// (42 VGPRs for the two polynomials) and issues v_mov_b64 + v_fmac_f64 per
+// step; this form halves the instructions of both Horner chains and frees
+// the VGPRs.  Register-only VALU: no wait states or counters involved.
+static __device__ __forceinline__ double fp_fma_sconst_(double a, double b,
+                                                        double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+#define FP_FMA_C(a, b, c) fp_fma_sconst_((a), (b), (c))
+#define FP_RINT(v) __builtin_rint(v)
+#define FP_FREXP_MANT(x) __builtin_amdgcn_frexp_mant(x)
+#define FP_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
+#define FP_LDEXP(v, n) __builtin_amdgcn_ldexp((v), (n))
+#elif defined(__HIPCC__)
+// host pass of a .hip translation unit: the function is never called there
+#define FP_FN __device__ __forceinline__
+#define FP_RCP(g) (1.0 / (g))
+#define FP_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define FP_FMA_C(a, b, c) __builtin_fma((a), (b), (c))
+#define FP_RINT(v) __builtin_rint(v)
+#define FP_FREXP_MANT(x) (x)
+#define FP_FREXP_EXP(x) 0
+#define FP_LDEXP(v, n) (v)
+#else
+#define FP_FN static inline
+#define FP_RCP(g) (1.0 / (g))
+#define FP_FMA(a, b, c) fma((a), (b), (c))
+#define FP_FMA_C(a, b, c) fma((a), (b), (c))
+#define FP_RINT(v) rint(v)
+static inline double fp_frexp_mant_(double x) { int e; return frexp(x, &e); }
+static inline int fp_frexp_exp_(double x) { int e; (void)frexp(x, &e); return e; }
+#define FP_FREXP_MANT(x) fp_frexp_mant_(x)
+#define FP_FREXP_EXP(x) fp_frexp_exp_(x)
+#define FP_LDEXP(v, n) ldexp((v), (n))
+#endif
+
+// Core: valid for finite x > 0.  Returns x**y if |y*log2 x| < 1000; *z_out
+// receives y*log2(x) (rounded) for the caller's range guard.
+FP_FN double fastpow_core(double x, double y, double *z_out)
+{
+    double m = FP_FREXP_MANT(x);               // [0.5, 1)
+    int e = FP_FREXP_EXP(x);
+    const bool low = m < 0.70710678118654757;
+    m = low ? m * 2.0 : m;                      // [sqrt(.5), sqrt(2))
+    e = low ? e - 1 : e;
+    const double k = (double)e;
+
+    // s = (m - 1) / (m + 1) as s_hi + s_lo
+    const double f = m - 1.0;                   // exact
+    const double g = m + 1.0;                   // may round ...
+    const double g_lo = m - (g - 1.0);          // ... by exactly this much
+    double rg = FP_RCP(g);
+    rg = FP_FMA(FP_FMA(-g, rg, 1.0), rg, rg);   // Newton: ~1 ulp reciprocal
+    rg = FP_FMA(FP_FMA(-g, rg, 1.0), rg, rg);
+    const double s_hi = f * rg;
+    double res = FP_FMA(-s_hi, g, f);           // f - s_hi*(g + g_lo)
+    res = FP_FMA(-s_hi, g_lo, res);
+    const double s_lo = res * rg;
+
+    // atanh(s) = s + s^3 (1/3 + s^2/5 + ... + s^18/21); s^2 <= 0.02944
+    const double s2 = s_hi * s_hi;
+    double p = 1.0 / 21.0;
+    p = FP_FMA_C(p, s2, 1.0 / 19.0);
+    p = FP_FMA_C(p, s2, 1.0 / 17.0);
+    p = FP_FMA_C(p, s2, 1.0 / 15.0);
+    p = FP_FMA_C(p, s2, 1.0 / 13.0);
+    p = FP_FMA_C(p, s2, 1.0 / 11.0);
+    p = FP_FMA_C(p, s2, 1.0 / 9.0);
+    p = FP_FMA_C(p, s2, 1.0 / 7.0);
+    p = FP_FMA_C(p, s2, 1.0 / 5.0);
+    p = FP_FMA_C(p, s2, 1.0 / 3.0);
+    // low part: s_lo * (1 + s^2) (first-order effect of s_lo) + tail
+    const double lo = FP_FMA(s_hi * s2, p, FP_FMA(s_lo, s2, s_lo));
+
+    // log2(m) = 2 (s_hi + lo) * log2(e), double-double
+    const double a_hi = 2.0 * s_hi, a_lo = 2.0 * lo;
+    const double L_hi = 1.4426950408889634, L_lo = 2.0355273740931033e-17;
+    const double p_hi = a_hi * L_hi;
+    const double p_lo =
+        FP_FMA(a_hi, L_hi, -p_hi) + FP_FMA(a_lo, L_hi, a_hi * L_lo);
+    // + k  (|k| >= 1 > |p_hi| or k == 0: fast two-sum is exact)
+    const double t_hi = k + p_hi;
+    const double t_lo = ((k - t_hi) + p_hi) + p_lo;
+    // * y
+    const double z_hi = y * t_hi;
+    const double z_lo = FP_FMA(y, t_hi, -z_hi) + y * t_lo;
+    *z_out = z_hi;
+
+    // 2^(z_hi + z_lo)
+    const double n = FP_RINT(z_hi);
+    const double r = (z_hi - n) + z_lo;         // |r| <= 0.5 (+ tiny)
+    double q = 1.3691488853904128e-12;          // ln2^13 / 13!
+    q = FP_FMA_C(q, r, 2.5678435993488206e-11);
+    q = FP_FMA_C(q, r, 4.4455382718708116e-10);
+    q = FP_FMA_C(q, r, 7.054911620801123e-09);
+    q = FP_FMA_C(q, r, 1.01780860092397e-07);
+    q = FP_FMA_C(q, r, 1.321548679014431e-06);
+    q = FP_FMA_C(q, r, 1.5252733804059841e-05);
+    q = FP_FMA_C(q, r, 0.0001540353039338161);
+    q = FP_FMA_C(q, r, 0.0013333558146428443);
+    q = FP_FMA_C(q, r, 0.009618129107628477);
+    q = FP_FMA_C(q, r, 0.05550410866482158);
+    q = FP_FMA_C(q, r, 0.24022650695910072);
+    q = FP_FMA_C(q, r, 0.6931471805599453);
+    q = FP_FMA_C(q, r, 1.0);
+    return FP_LDEXP(q, (int)n);
+}
+
+// True where fastpow_core's result may be used.
+FP_FN bool fastpow_ok(double x, double z)
+{
+    // x > 0 and finite (NaN fails both compares); |z| < 1000 keeps 2^z normal
+    // and rejects NaN / inf coming from a non-finite y
+    return (x > 0.0) && (x < __builtin_inf()) && (__builtin_fabs(z) < 1000.0);
+}

@@ -21,8 +21,10 @@
 //              512 contiguous bytes per output per day.
 //
 // Arithmetic follows the reference statement by statement in fp64 without
-// FMA contraction (-ffp-contract=off); only pow() is OCML's instead of libm's.
+// FMA contraction (-ffp-contract=off); only the power (soil/FC)**Beta is not
+// libm's: it is fastpow.h's ~1-ulp evaluation (general pow as fallback).
 #include "common.h"
+#include "fastpow.h"
 
 struct __attribute__((aligned(32))) HbvDay {
     double temp;   // temp[t]
@@ -49,6 +51,14 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
     d.dtemp = temp[t] - T_m[m];
     d.pe_m = PE_m[m];
     days[t] = d;
+}
+
+// General pow for the (never expected) arguments outside fastpow's domain.
+// Out of line on purpose: inlined, OCML's pow raised the kernel from ~100 to
+// 148 VGPRs (3 instead of 4-5 waves per SIMD) for a path that never runs.
+__device__ __attribute__((noinline)) double pow_general(double x, double y)
+{
+    return pow(x, y);
 }
 
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE>
@@ -112,7 +122,15 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
             !(wetness >= 0x1p-10 && wetness <= 0x1p10 && beta_small);
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
         if (__any(need_pow)) {
-            const double pw = pow(wetness, Beta);
+            // fastpow.h: ~1 ulp, a third of the general pow's instructions;
+            // arguments outside its domain take the general pow (wave-wide)
+            double z;
+            double pw = fastpow_core(wetness, Beta, &z);
+            const bool fast_ok = fastpow_ok(wetness, z);
+            if (__any(need_pow && !fast_ok)) {
+                const double general = pow_general(wetness, Beta);
+                pw = fast_ok ? pw : general;
+            }
             prec_eff = need_pow ? liquid_water * pw : liquid_water;
         }
 
