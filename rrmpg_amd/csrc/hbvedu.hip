@@ -78,7 +78,10 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
                  PWP = p[5], K_0 = p[6], K_1 = p[7], K_2 = p[8], K_p = p[9],
                  L = p[10];
 
-    const bool beta_small = fabs(Beta) <= 64.0;
+    // box in which (soil/FC)**Beta is certainly finite (see the time loop)
+    const double soil_lo = FC * 0x1p-9, soil_hi = FC * 0x1p9;
+    const bool box_ok = (FC > 0x1p-500) && (FC < 0x1p500) &&
+                        (fabs(Beta) <= 64.0);
 
     double snow = snow_init, soil = soil_init, s1 = s1_init, s2 = s2_init;
     double acc = 0.0;
@@ -112,16 +115,18 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         // effective precipitation (:99): liquid_water * (soil/FC)**Beta.
         // On dry or frozen days liquid_water is exactly 0 for every lane of
         // the wave (the forcing is shared), and 0 * pow(..) is 0 whenever
-        // pow(..) is finite -- guaranteed when the base lies in [2^-10, 2^10]
-        // and |Beta| <= 64 -- so the wave skips pow altogether.  Outside that
-        // box (NaN/inf/zero/negative base, huge Beta) pow is evaluated and
-        // 0 * inf / 0 * NaN propagate exactly as in the reference.
-        const double wetness = soil / FC;
+        // pow(..) is finite -- guaranteed when soil/FC lies in [2^-10, 2^10]
+        // (tested without dividing: FC * 2^-9 <= soil <= FC * 2^9, FC > 0)
+        // and |Beta| <= 64 -- so the wave skips the division and the power
+        // altogether.  Outside that box (NaN/inf/zero/negative operands, huge
+        // Beta) both are evaluated and 0 * inf / 0 * NaN propagate exactly as
+        // in the reference.
         const bool need_pow =
             (liquid_water != 0.0) ||
-            !(wetness >= 0x1p-10 && wetness <= 0x1p10 && beta_small);
+            !(soil >= soil_lo && soil <= soil_hi && box_ok);
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
         if (__any(need_pow)) {
+            const double wetness = soil / FC;
             // fastpow.h: ~1 ulp, a third of the general pow's instructions;
             // arguments outside its domain take the general pow (wave-wide)
             double z;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
 
         if (active) {
-            if (WRITE_Q) qsim[off] = q;
+            if (WRITE_Q) __builtin_nontemporal_store(q, &qsim[off]);
             if (WRITE_S) {
                 snow_out[off] = snow;
                 soil_out[off] = soil;
