@@ -348,3 +348,36 @@ extern "C" int rr_cemaneigegr4j_simulate(
                 qobs ? d_sse : nullptr, ws.p, wsb, nullptr);
         });
 }
+
+// ---- device self-test hook (not part of include/rrhip.h) -------------------
+// out[i] = div_by_invariant(a[i], b[i]) and ref[i] = a[i] / b[i], host arrays.
+__global__ void dbg_div_kernel(const double *a, const double *b, double *out,
+                               double *ref, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double av = (i < n) ? a[i] : 1.0, bv = (i < n) ? b[i] : 1.0;
+    const InvDivisor d = make_inv_divisor(bv);
+    const double q = div_by_invariant(av, inv_div_numerator_ok(av), d);
+    if (i < n) {
+        out[i] = q;
+        ref[i] = av / bv;
+    }
+}
+
+extern "C" int rrdbg_divide_by_invariant(const double *a, const double *b,
+                                         double *out, double *ref, int64_t n)
+{
+    int rc = require_device();
+    if (rc != RR_OK) return rc;
+    DevBuf da, db, dout, dref;
+    if ((rc = da.upload(a, (size_t)n * 8)) != RR_OK) return rc;
+    if ((rc = db.upload(b, (size_t)n * 8)) != RR_OK) return rc;
+    if ((rc = dout.alloc((size_t)n * 8)) != RR_OK) return rc;
+    if ((rc = dref.alloc((size_t)n * 8)) != RR_OK) return rc;
+    hipLaunchKernelGGL(dbg_div_kernel, dim3((unsigned)rr_ceil_div(n, 256)),
+                       dim3(256), 0, nullptr, da.as<double>(), db.as<double>(),
+                       dout.as<double>(), dref.as<double>(), n);
+    RR_HIP(hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    RR_HIP(hipMemcpy(ref, dref.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return RR_OK;
+}

@@ -24,6 +24,33 @@ __device__ __forceinline__ double nb_min(double a, double b) {
     return (b < a) ? b : a;
 }
 
+// ---- division by a per-lane loop invariant ---------------------------------
+// a / b where b is fixed for the lane's whole time loop (FC, PWP, x1, x3 ...).
+// hipcc expands every fp64 `/` into ~12 VALU instructions (v_div_scale x2,
+// v_rcp_f64, 4 Newton FMAs, mul, fma, v_div_fmas, v_div_fixup), most of which
+// only refine 1/b again.  With rb = RN(1/b) computed ONCE by a true division,
+//     q0 = RN(a * rb);  r = RN(a - b * q0) (exact, FMA);  q = RN(q0 + r * rb)
+// is the correctly rounded quotient RN(a / b) (Markstein's theorem: rb is
+// within 1/2 ulp of 1/b and q0 within 1 ulp of a/b) as long as nothing
+// overflows or underflows -- 3 instructions.  The guard keeps |b| in
+// [2^-100, 2^100] and |a| in [2^-900, 2^900]; any other operand (zero, inf,
+// NaN, subnormal, huge) takes the ordinary `/` for the wave, so the result is
+// bit-identical to `a / b` for EVERY input (tests/test_fastmath_cpu.py runs
+// 10^8 random and adversarial pairs on the host; the GPU self-test entry
+// rrdbg_divide_by_invariant does the same on the device).
+#include "invdiv.h"
+
+__device__ __forceinline__ double div_by_invariant(double a, bool a_ok,
+                                                   const InvDivisor &d) {
+    double q = inv_div_core(a, d);
+    const bool ok = a_ok && d.ok;
+    if (__any(!ok)) {
+        const double exact = a / d.b;
+        q = ok ? q : exact;
+    }
+    return q;
+}
+
 // ---- error plumbing (host) ------------------------------------------------
 void rr_set_error(const char *fmt, ...);
 

@@ -78,6 +78,8 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
                  PWP = p[5], K_0 = p[6], K_1 = p[7], K_2 = p[8], K_p = p[9],
                  L = p[10];
 
+    const InvDivisor inv_FC = make_inv_divisor(FC);
+    const InvDivisor inv_PWP = make_inv_divisor(PWP);
     // box in which (soil/FC)**Beta is certainly finite (see the time loop)
     const double soil_lo = FC * 0x1p-9, soil_hi = FC * 0x1p9;
     const bool box_ok = (FC > 0x1p-500) && (FC < 0x1p500) &&
@@ -121,12 +123,13 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         // altogether.  Outside that box (NaN/inf/zero/negative operands, huge
         // Beta) both are evaluated and 0 * inf / 0 * NaN propagate exactly as
         // in the reference.
+        const bool soil_ok = inv_div_numerator_ok(soil);
         const bool need_pow =
             (liquid_water != 0.0) ||
             !(soil >= soil_lo && soil <= soil_hi && box_ok);
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
         if (__any(need_pow)) {
-            const double wetness = soil / FC;
+            const double wetness = div_by_invariant(soil, soil_ok, inv_FC);
             // fastpow.h: ~1 ulp, a third of the general pow's instructions;
             // arguments outside its domain take the general pow (wave-wide)
             double z;
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
 
         // potential / actual evapotranspiration (:102-108)
         const double pe = (1 + C * f.dtemp) * f.pe_m;
-        const double ea = (soil > PWP) ? pe : pe * (soil / PWP);
+        const double ea = (soil > PWP)
+            ? pe : pe * div_by_invariant(soil, soil_ok, inv_PWP);
 
         // soil moisture (:111)
         const double soil_n = soil + liquid_water - prec_eff - ea;

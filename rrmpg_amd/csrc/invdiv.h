@@ -1,0 +1,37 @@
+// invdiv.h -- correctly rounded a / b for a loop-invariant b in 3 FMA-class
+// instructions (see common.h for the why).  Portable: the host build is used
+// by tests/test_fastmath_cpu.py to check bit-identity with `/`.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define ID_FN __host__ __device__ __forceinline__
+#else
+#define ID_FN static inline
+#endif
+
+struct InvDivisor {
+    double b;     // the divisor
+    double rb;    // RN(1 / b)
+    bool ok;      // |b| in [2^-100, 2^100]
+};
+
+ID_FN InvDivisor make_inv_divisor(double b) {
+    InvDivisor d;
+    d.b = b;
+    d.rb = 1.0 / b;
+    d.ok = (fabs(b) >= 0x1p-100) && (fabs(b) <= 0x1p100);
+    return d;
+}
+
+// |a| in [2^-900, 2^900]: shared by all quotients with the same numerator
+ID_FN bool inv_div_numerator_ok(double a) {
+    return (fabs(a) >= 0x1p-900) && (fabs(a) <= 0x1p900);
+}
+
+// valid (== RN(a / b)) when inv_div_numerator_ok(a) && d.ok
+ID_FN double inv_div_core(double a, const InvDivisor &d) {
+    const double q0 = a * d.rb;
+    const double r = __builtin_fma(-d.b, q0, a);
+    return __builtin_fma(r, d.rb, q0);
+}

@@ -1,0 +1,48 @@
+// CPU harness for rrmpg_amd/csrc/invdiv.h (built and run by
+// tests/test_fastmath_cpu.py): inv_div_core must be bit-identical to a / b
+// wherever its guards hold.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../rrmpg_amd/csrc/invdiv.h"
+
+static uint64_t s = 0x9E3779B97F4A7C15ULL;
+static inline uint64_t rnd() {
+    s ^= s >> 12; s ^= s << 25; s ^= s >> 27;
+    return s * 2685821237005ULL;
+}
+static inline double mk(uint64_t mant, int e, int neg) {
+    uint64_t b = ((uint64_t)neg << 63) | ((uint64_t)(1023 + e) << 52) |
+                 (mant & ((1ULL << 52) - 1));
+    double d; memcpy(&d, &b, 8); return d;
+}
+
+int main(int argc, char **argv) {
+    long n = argc > 1 ? atol(argv[1]) : 100000000L;
+    long bad = 0, checked = 0;
+    for (long i = 0; i < n; ++i) {
+        uint64_t ma = rnd(), mb = rnd();
+        const int mode = (int)(i & 7);
+        if (mode == 1) mb &= 0xFF;            // divisor significand just above 1
+        if (mode == 2) mb = ~(mb & 0xFF);     // ... just below 2
+        if (mode == 3) ma &= 0xFF;
+        if (mode == 4) ma = ~(ma & 0xFF);
+        if (mode == 5) mb = ~0ULL;            // all ones
+        if (mode == 6) { ma = mb; }           // quotient near a power of two
+        const int ea = (int)(rnd() % 1801) - 900, eb = (int)(rnd() % 201) - 100;
+        const double a = mk(ma, ea, (int)(rnd() & 1)), b = mk(mb, eb, (int)(rnd() & 1));
+        const InvDivisor d = make_inv_divisor(b);
+        if (!(d.ok && inv_div_numerator_ok(a))) continue;
+        checked++;
+        const double q = inv_div_core(a, d), want = a / b;
+        if (memcmp(&q, &want, 8) != 0) {
+            if (bad < 5) printf("MISMATCH a=%a b=%a got=%a want=%a\n", a, b, q, want);
+            bad++;
+        }
+    }
+    printf("checked %ld\nmismatches %ld\n", checked, bad);
+    return bad != 0;
+}

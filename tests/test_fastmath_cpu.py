@@ -1,0 +1,41 @@
+"""Host-side checks of the two numerical building blocks the HBV-Edu kernel
+uses instead of OCML's general pow / hipcc's division expansion.  Both headers
+are portable; small g++ harnesses (tests/native/) exercise the very source the
+kernels compile.
+
+  * fastpow.h : worst error vs 80-bit powl stays ~1 ulp (libm's pow: 0.5 ulp)
+  * invdiv.h  : bit-identical to `a / b` on 2e7 random + adversarial pairs
+"""
+
+import os
+import re
+import subprocess
+
+from .conftest import REPO
+
+NATIVE = os.path.join(REPO, "tests", "native")
+
+
+def _build_and_run(src, tmp_path, *args):
+    exe = os.path.join(str(tmp_path), os.path.splitext(src)[0])
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-o", exe,
+                           os.path.join(NATIVE, src), "-lm"])
+    return subprocess.run([exe, *args], capture_output=True, text=True,
+                          check=True).stdout
+
+
+def test_fastpow_accuracy(tmp_path):
+    out = _build_and_run("fastpow_harness.cpp", tmp_path, "400000")
+    vals = dict(re.findall(r"^(\w+) ([0-9.]+)", out, flags=re.M))
+    assert float(vals["worst_ulp_hbv"]) < 1.25, out
+    assert float(vals["worst_ulp_wide"]) < 1.25, out
+    assert float(vals["worst_ulp_near1"]) < 1.25, out
+    assert int(vals["exact_ok"]) == 1, out
+    assert int(vals["guard_rejected"]) == 0, out
+
+
+def test_invariant_division_is_bit_exact(tmp_path):
+    out = _build_and_run("invdiv_harness.cpp", tmp_path, "20000000")
+    vals = dict(re.findall(r"^(\w+) ([0-9]+)", out, flags=re.M))
+    assert int(vals["mismatches"]) == 0, out
+    assert int(vals["checked"]) > 15_000_000, out

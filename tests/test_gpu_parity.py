@@ -464,3 +464,40 @@ def test_fit_recovers_known_parameters(models):
     res = models.ABCModel().fit(qobs, prec, initial_state=1.0)
     assert res.fun < 1e-6
     assert np.allclose(res.x, [0.35, 0.15, 0.4], atol=1e-2)
+
+
+def test_device_division_by_invariant_is_bit_exact():
+    """common.h div_by_invariant (3 FMAs + guarded fallback) == `/` on the
+    device for random, adversarial and special operands."""
+    import ctypes
+    from rrmpg_amd import _lib
+    lib = _lib.load()
+    fn = lib.rrdbg_divide_by_invariant
+    fn.restype = ctypes.c_int
+    fn.argtypes = [_lib._f64p] * 4 + [ctypes.c_int64]
+    rng = np.random.default_rng(12)
+    n = 2_000_000
+    a = np.ldexp(rng.uniform(1, 2, n), rng.integers(-950, 950, n)) \
+        * rng.choice([-1.0, 1.0], n)
+    b = np.ldexp(rng.uniform(1, 2, n), rng.integers(-120, 120, n)) \
+        * rng.choice([-1.0, 1.0], n)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, 1e-310,
+                        1.7e308, 1.0, 3.0, 2.0 ** -1022, 105.89, 177.1])
+    sa, sb = np.meshgrid(special, special)
+    a = np.concatenate([a, sa.ravel()])
+    b = np.concatenate([b, sb.ravel()])
+    # significands at the ends of [1, 2)
+    b[:1000] = np.nextafter(2.0, 0) * 2.0 ** rng.integers(-50, 50, 1000)
+    b[1000:2000] = np.nextafter(1.0, 2) * 2.0 ** rng.integers(-50, 50, 1000)
+    out, ref = np.empty_like(a), np.empty_like(a)
+    p = lambda x: x.ctypes.data_as(_lib._f64p)
+    rc = fn(p(a), p(b), p(out), p(ref), a.size)
+    assert rc == 0
+    with np.errstate(all="ignore"):
+        want = a / b
+    same = (out.view(np.uint64) == ref.view(np.uint64)) | \
+           (np.isnan(out) & np.isnan(ref))
+    assert same.all()
+    same = (ref.view(np.uint64) == want.view(np.uint64)) | \
+           (np.isnan(ref) & np.isnan(want))
+    assert same.all()      # device `/` is IEEE-correct, like the host's
