@@ -112,6 +112,26 @@ int rr_hbvedu_simulate(const double *temp, const double *prec,
                        double *qsim, double *snow, double *soil, double *s1,
                        double *s2, const double *qobs, double *sse);
 
+/* Multi-catchment HBV-Edu (BASELINE.json configs[4]): C independent
+ * catchments, each with its own forcing and its own N parameter sets, in ONE
+ * launch -- replaces the user's outer loop `for basin: model.simulate(...)`
+ * around hbvedu.py:82-214, whose per-basin sweeps (10k sets = 157 waves) are
+ * far too small to fill 1024 SIMDs one at a time.  Device pointers only; all
+ * arrays catchment-major: temp/prec/month [C][T], PE_m/T_m [C][12],
+ * inits [C][4] = {snow, soil, s1, s2}, params [C][N][11], outputs
+ * [C][T][ld], qobs [C][T], sse [C][N]. */
+size_t rr_hbvedu_catchments_workspace_bytes(int64_t T, int64_t C, int64_t N);
+int rr_hbvedu_simulate_catchments_dev(const double *temp, const double *prec,
+                                      const int8_t *month, const double *PE_m,
+                                      const double *T_m, int64_t T, int64_t C,
+                                      const double *inits,
+                                      const double *params, int64_t N,
+                                      double *qsim, double *snow, double *soil,
+                                      double *s1, double *s2, int64_t ld,
+                                      const double *qobs, double *sse,
+                                      void *workspace, size_t workspace_bytes,
+                                      void *stream);
+
 /* ---- GR4J ------------------------------------------------------------
  * replaces run_gr4j(prec, etp, s_init, r_init, params)
  * (reference: rrmpg/models/gr4j_model.py:15-192); params = {x1,x2,x3,x4};

@@ -43,6 +43,11 @@ _SIGNATURES = {
     "rr_hbvedu_simulate": (ctypes.c_int,
                            [_f64p, _f64p, _i8p, _f64p, _f64p, _i64]
                            + [_dbl] * 4 + [_f64p, _i64] + [_f64p] * 7),
+    "rr_hbvedu_catchments_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "rr_hbvedu_simulate_catchments_dev": (ctypes.c_int,
+                                          [_vp] * 5 + [_i64, _i64, _vp, _vp,
+                                                       _i64] + [_vp] * 5
+                                          + [_i64, _vp, _vp, _vp, _sz, _vp]),
     "rr_gr4j_workspace_bytes": (_sz, [_i64, _i64]),
     "rr_gr4j_simulate_dev": (ctypes.c_int,
                              [_vp, _vp, _i64, _dbl, _dbl, _vp, _i64]

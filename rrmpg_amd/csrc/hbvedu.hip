@@ -33,6 +33,7 @@ struct __attribute__((aligned(32))) HbvDay {
     double pe_m;   // PE_m[month[t]]
 };
 
+// blockIdx.y = catchment (forcing arrays are [C][T], monthly tables [C][12])
 __global__ void hbv_pack_forcing(const double *__restrict__ temp,
                                  const double *__restrict__ prec,
                                  const int8_t *__restrict__ month,
@@ -42,15 +43,17 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    int m = month[t];
+    const int64_t c = blockIdx.y;
+    const int64_t g = c * T + t;
+    int m = month[g];
     m = m < 0 ? 0 : (m > 11 ? 11 : m);   // memory safety only; the wrapper
                                          // has already validated 1..12
     HbvDay d;
-    d.temp = temp[t];
-    d.prec = prec[t];
-    d.dtemp = temp[t] - T_m[m];
-    d.pe_m = PE_m[m];
-    days[t] = d;
+    d.temp = temp[g];
+    d.prec = prec[g];
+    d.dtemp = temp[g] - T_m[c * 12 + m];
+    d.pe_m = PE_m[c * 12 + m];
+    days[g] = d;
 }
 
 // General pow for the (never expected) arguments outside fastpow's domain.
@@ -61,17 +64,38 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
     return pow(x, y);
 }
 
+// blockIdx.y = catchment.  A single-catchment launch has gridDim.y == 1; a
+// multi-catchment launch (rr_hbvedu_simulate_catchments_dev) lays every array
+// out catchment-major: days [C][T], params [C][N][11], outputs [C][T][ld],
+// qobs [C][T], sse [C][N], inits [C][4].
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE>
 __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     const HbvDay *__restrict__ days, int64_t T, double snow_init,
     double soil_init, double s1_init, double s2_init,
-    const double *__restrict__ params, int64_t N, double *__restrict__ qsim,
-    double *__restrict__ snow_out, double *__restrict__ soil_out,
-    double *__restrict__ s1_out, double *__restrict__ s2_out, int64_t ld,
-    const double *__restrict__ qobs, double *__restrict__ sse)
+    const double *__restrict__ inits, const double *__restrict__ params,
+    int64_t N, double *__restrict__ qsim, double *__restrict__ snow_out,
+    double *__restrict__ soil_out, double *__restrict__ s1_out,
+    double *__restrict__ s2_out, int64_t ld, const double *__restrict__ qobs,
+    double *__restrict__ sse)
 {
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
+    {
+        const int64_t c = blockIdx.y;          // wave-uniform
+        days += c * T;
+        params += c * N * 11;
+        const int64_t out_off = c * T * ld;
+        if (WRITE_Q) qsim += out_off;
+        if (WRITE_S) {
+            snow_out += out_off; soil_out += out_off;
+            s1_out += out_off; s2_out += out_off;
+        }
+        if (WITH_SSE) { qobs += c * T; sse += c * N; }
+        if (inits) {
+            snow_init = inits[c * 4 + 0]; soil_init = inits[c * 4 + 1];
+            s1_init = inits[c * 4 + 2]; s2_init = inits[c * 4 + 3];
+        }
+    }
     // tail lanes recompute the last set and simply do not store
     const double *p = params + (active ? i : N - 1) * 11;
     const double T_t = p[0], DD = p[1], FC = p[2], Beta = p[3], C = p[4],
@@ -186,16 +210,50 @@ extern "C" size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N)
     return rr_align256((size_t)(T > 0 ? T : 1) * sizeof(HbvDay));
 }
 
-template <bool Q, bool S, bool E>
-static void launch_hbv(dim3 grid, hipStream_t st, const HbvDay *days,
-                       int64_t T, double a, double b, double c, double d,
-                       const double *params, int64_t N, double *qsim,
-                       double *snow, double *soil, double *s1, double *s2,
-                       int64_t ld, const double *qobs, double *sse)
+// Shared by the single- and multi-catchment entry points.
+static int hbv_launch(const double *temp, const double *prec,
+                      const int8_t *month, const double *PE_m,
+                      const double *T_m, int64_t T, int64_t C,
+                      double snow_init, double soil_init, double s1_init,
+                      double s2_init, const double *inits,
+                      const double *params, int64_t N, double *qsim,
+                      double *snow, double *soil, double *s1, double *s2,
+                      int64_t ld, const double *qobs, double *sse,
+                      void *workspace, hipStream_t st)
 {
-    hipLaunchKernelGGL((hbvedu_kernel<Q, S, E>), grid, dim3(RR_BLOCK), 0, st,
-                       days, T, a, b, c, d, params, N, qsim, snow, soil, s1,
-                       s2, ld, qobs, sse);
+    HbvDay *days = (HbvDay *)workspace;
+    hipLaunchKernelGGL(hbv_pack_forcing,
+                       dim3((unsigned)rr_ceil_div(T, 256), (unsigned)C),
+                       dim3(256), 0, st, temp, prec, month, PE_m, T_m, T,
+                       days);
+    const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK), (unsigned)C);
+    const bool any_s = snow != nullptr;
+    rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
+                 [&](auto Q, auto S, auto E) {
+        hbvedu_kernel<Q.value, S.value, E.value>
+            <<<grid, dim3(RR_BLOCK), 0, st>>>(
+                days, T, snow_init, soil_init, s1_init, s2_init, inits, params,
+                N, qsim, snow, soil, s1, s2, ld, qobs, sse);
+    });
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+static int hbv_check(const char *who, const void *temp, const void *prec,
+                     const void *month, const void *PE_m, const void *T_m,
+                     const double *snow, const double *soil, const double *s1,
+                     const double *s2)
+{
+    if (!temp || !prec || !month || !PE_m || !T_m) {
+        rr_set_error("%s: NULL forcing pointer", who);
+        return RR_E_NULL;
+    }
+    const bool any_s = snow || soil || s1 || s2;
+    if (any_s && !(snow && soil && s1 && s2)) {
+        rr_set_error("%s: pass all four storage outputs or none", who);
+        return RR_E_NULL;
+    }
+    return RR_OK;
 }
 
 extern "C" int rr_hbvedu_simulate_dev(
@@ -206,43 +264,60 @@ extern "C" int rr_hbvedu_simulate_dev(
     double *s2, int64_t ld, const double *qobs, double *sse, void *workspace,
     size_t workspace_bytes, void *stream)
 {
-    int rc = rr_check_common("rr_hbvedu_simulate_dev", T, N, ld, params, qobs,
-                             sse);
+    const char *who = "rr_hbvedu_simulate_dev";
+    int rc = rr_check_common(who, T, N, ld, params, qobs, sse);
     if (rc != RR_OK) return rc;
     if (T == 0 || N == 0) return RR_OK;
-    if (!temp || !prec || !month || !PE_m || !T_m) {
-        rr_set_error("rr_hbvedu_simulate_dev: NULL forcing pointer");
-        return RR_E_NULL;
-    }
-    const bool any_s = snow || soil || s1 || s2;
-    if (any_s && !(snow && soil && s1 && s2)) {
-        rr_set_error("rr_hbvedu_simulate_dev: pass all four storage outputs "
-                     "or none");
-        return RR_E_NULL;
-    }
+    rc = hbv_check(who, temp, prec, month, PE_m, T_m, snow, soil, s1, s2);
+    if (rc != RR_OK) return rc;
     if (!workspace || workspace_bytes < rr_hbvedu_workspace_bytes(T, N)) {
-        rr_set_error("rr_hbvedu_simulate_dev: workspace too small");
+        rr_set_error("%s: workspace too small", who);
         return RR_E_WORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream;
-    HbvDay *days = (HbvDay *)workspace;
-    hipLaunchKernelGGL(hbv_pack_forcing, dim3((unsigned)rr_ceil_div(T, 256)),
-                       dim3(256), 0, st, temp, prec, month, PE_m, T_m, T,
-                       days);
-    const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK));
-    const bool e = qobs && sse;
-#define HBV_GO(Q, S, E)                                                     \
-    launch_hbv<Q, S, E>(grid, st, days, T, snow_init, soil_init, s1_init,   \
-                        s2_init, params, N, qsim, snow, soil, s1, s2, ld,   \
-                        qobs, sse)
-    if (qsim) {
-        if (any_s) { if (e) HBV_GO(true, true, true); else HBV_GO(true, true, false); }
-        else       { if (e) HBV_GO(true, false, true); else HBV_GO(true, false, false); }
-    } else {
-        if (any_s) { if (e) HBV_GO(false, true, true); else HBV_GO(false, true, false); }
-        else       { if (e) HBV_GO(false, false, true); else HBV_GO(false, false, false); }
+    return hbv_launch(temp, prec, month, PE_m, T_m, T, 1, snow_init,
+                      soil_init, s1_init, s2_init, nullptr, params, N, qsim,
+                      snow, soil, s1, s2, ld, qobs, sse, workspace,
+                      (hipStream_t)stream);
+}
+
+extern "C" size_t rr_hbvedu_catchments_workspace_bytes(int64_t T, int64_t C,
+                                                       int64_t N)
+{
+    (void)N;
+    if (T < 1) T = 1;
+    if (C < 1) C = 1;
+    return rr_align256((size_t)T * (size_t)C * sizeof(HbvDay));
+}
+
+extern "C" int rr_hbvedu_simulate_catchments_dev(
+    const double *temp, const double *prec, const int8_t *month,
+    const double *PE_m, const double *T_m, int64_t T, int64_t C,
+    const double *inits, const double *params, int64_t N, double *qsim,
+    double *snow, double *soil, double *s1, double *s2, int64_t ld,
+    const double *qobs, double *sse, void *workspace, size_t workspace_bytes,
+    void *stream)
+{
+    const char *who = "rr_hbvedu_simulate_catchments_dev";
+    int rc = rr_check_common(who, T, N, ld, params, qobs, sse);
+    if (rc != RR_OK) return rc;
+    if (C < 0 || C > 65535) {
+        rr_set_error("%s: C=%lld catchments; supported 0..65535", who,
+                     (long long)C);
+        return RR_E_SIZE;
     }
-#undef HBV_GO
-    RR_HIP(hipGetLastError());
-    return RR_OK;
+    if (T == 0 || N == 0 || C == 0) return RR_OK;
+    rc = hbv_check(who, temp, prec, month, PE_m, T_m, snow, soil, s1, s2);
+    if (rc != RR_OK) return rc;
+    if (!inits) {
+        rr_set_error("%s: inits is NULL", who);
+        return RR_E_NULL;
+    }
+    if (!workspace ||
+        workspace_bytes < rr_hbvedu_catchments_workspace_bytes(T, C, N)) {
+        rr_set_error("%s: workspace too small", who);
+        return RR_E_WORKSPACE;
+    }
+    return hbv_launch(temp, prec, month, PE_m, T_m, T, C, 0., 0., 0., 0.,
+                      inits, params, N, qsim, snow, soil, s1, s2, ld, qobs,
+                      sse, workspace, (hipStream_t)stream);
 }

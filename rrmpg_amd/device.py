@@ -253,3 +253,61 @@ class CemaneigeGR4JEnsemble(_Ensemble):
             self._stream())
         _lib.check(rc, "rr_cemaneigegr4j_simulate_dev")
         return sse if qobs is not None else None
+
+
+class HBVEduCatchments(_Ensemble):
+    """HBV-Edu for C independent catchments x N parameter sets each, one
+    launch (rr_hbvedu_simulate_catchments_dev; BASELINE.json configs[4]).
+
+    Forcing arrays are [C, T] (month 1..12), monthly tables [C, 12], inits
+    [C, 4] = (snow, soil, s1, s2); params [C, N, 11]; outputs [C, T, N];
+    qobs [C, T] -> sse [C, N].
+    """
+
+    NUM_PARAMS = 11
+
+    def __init__(self, temp, prec, month, PE_m, T_m, inits, device="cuda:0"):
+        super().__init__(device)
+        self.temp = _dev_tensor(np.atleast_2d(temp), self.device)
+        self.prec = _dev_tensor(np.atleast_2d(prec), self.device)
+        month0 = np.atleast_2d(np.asarray(month, dtype=np.int64)) - 1
+        if month0.min() < 0 or month0.max() > 11:
+            raise ValueError("The month array must be between an integer1 "
+                             "(Jan) and 12 (Dec).")
+        self.month0 = _dev_tensor(month0.astype(np.int8), self.device,
+                                  torch.int8)
+        self.PE_m = _dev_tensor(np.atleast_2d(PE_m), self.device)
+        self.T_m = _dev_tensor(np.atleast_2d(T_m), self.device)
+        self.inits = _dev_tensor(np.atleast_2d(inits), self.device)
+        self.num_catchments, self.num_timesteps = (int(x) for x in
+                                                   self.prec.shape)
+        c = self.num_catchments
+        if (self.temp.shape != self.prec.shape
+                or self.month0.shape != self.prec.shape
+                or self.PE_m.shape != (c, 12) or self.T_m.shape != (c, 12)
+                or self.inits.shape != (c, 4)):
+            raise ValueError("inconsistent multi-catchment forcing shapes")
+
+    def new_output(self, num_sets):
+        return torch.empty((self.num_catchments, self.num_timesteps, num_sets),
+                           dtype=torch.float64, device=self.device)
+
+    def run(self, params, qsim=None, storages=None, qobs=None, sse=None):
+        """params: device tensor [C, N, 11]."""
+        c, t = self.num_catchments, self.num_timesteps
+        if params.dim() != 3 or params.shape[0] != c or params.shape[2] != 11:
+            raise ValueError("params must be [C, N, 11]")
+        n = params.shape[1]
+        if qobs is not None and sse is None:
+            sse = torch.empty((c, n), dtype=torch.float64, device=self.device)
+        wsb = self.lib.rr_hbvedu_catchments_workspace_bytes(t, c, n)
+        ws = self._workspace(wsb)
+        st = storages or (None,) * 4
+        rc = self.lib.rr_hbvedu_simulate_catchments_dev(
+            _ptr(self.temp), _ptr(self.prec), _ptr(self.month0),
+            _ptr(self.PE_m), _ptr(self.T_m), t, c, _ptr(self.inits),
+            _ptr(params), n, _ptr(qsim), *[_ptr(x) for x in st], n,
+            _ptr(qobs), _ptr(sse) if qobs is not None else None, _ptr(ws), wsb,
+            self._stream())
+        _lib.check(rc, "rr_hbvedu_simulate_catchments_dev")
+        return sse if qobs is not None else None

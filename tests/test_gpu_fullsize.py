@@ -184,3 +184,54 @@ def test_config3_cemaneigegr4j_shard_nse(env, oracle):
     for j, c in enumerate(cols):
         want = calc_nse(qobs_h, ref[:, j])
         assert abs(nse[c] - want) <= 1e-10 * max(1.0, abs(want))
+
+
+def test_config4_multi_catchment_hbv(env, oracle):
+    """BASELINE configs[4], one GPU's share: 125 catchments x 10,000 sets x
+    10,957 days in ONE launch (score-only at full size); a 6-catchment subset
+    with qsim must equal six single-catchment launches bit for bit, and
+    random columns must match the oracle."""
+    torch, syn = env["torch"], env["syn"]
+    HBV = env["models"].HBVEdu
+    dev = env["device"]
+    C, n, t = 125, 10_000, syn.T_30YR
+    fs = [syn.make_forcing(t, seed=syn.FORCING_SEED + c) for c in range(C)]
+    temp = np.stack([f["temp"] for f in fs])
+    prec = np.stack([f["prec"] for f in fs])
+    month = np.stack([f["month"] for f in fs])
+    rng = np.random.default_rng(5)
+    PE_m = np.stack([syn.PE_M * rng.uniform(0.8, 1.2) for _ in range(C)])
+    T_m = np.stack([syn.T_M + rng.uniform(-2, 2) for _ in range(C)])
+    inits = np.stack([[0., 100. + c % 7, 3., 10.] for c in range(C)])
+    np.random.seed(1)
+    flat = _flat(HBV().get_random_params(C * n), HBV).reshape(C, n, 11)
+    qobs_h = np.stack([syn.make_qobs(oracle.simulate_hbvedu(
+        temp[c], prec[c], month[c] - 1, PE_m[c], T_m[c], inits[c],
+        flat[c, :1])) for c in range(C)])
+    ens = dev.HBVEduCatchments(temp, prec, month, PE_m, T_m, inits)
+    params = torch.from_numpy(flat).cuda()
+    qobs = torch.from_numpy(qobs_h).cuda()
+    sse = ens.run(params, None, qobs=qobs)
+    torch.cuda.synchronize()
+    assert sse.shape == (C, n) and bool(torch.isfinite(sse).all())
+    # subset with qsim == single-catchment launches, bit for bit
+    sub = [0, 1, 17, 63, 99, 124]
+    ens6 = dev.HBVEduCatchments(temp[sub], prec[sub], month[sub], PE_m[sub],
+                                T_m[sub], inits[sub])
+    q6 = ens6.new_output(n)
+    sse6 = ens6.run(params[sub].contiguous(), q6, qobs=qobs[sub].contiguous())
+    torch.cuda.synchronize()
+    for j, c in enumerate(sub):
+        one = dev.HBVEduEnsemble(temp[c], prec[c], month[c], PE_m[c], T_m[c],
+                                 *inits[c])
+        q1 = one.new_output(n)
+        s1 = one.run(params[c].contiguous(), q1, qobs=qobs[c].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(q1, q6[j])
+        assert torch.equal(s1, sse6[j])
+        assert torch.equal(s1, sse[c])
+        cols = np.sort(rng.choice(n, 8, replace=False))
+        ref = oracle.simulate_hbvedu(temp[c], prec[c], month[c] - 1, PE_m[c],
+                                     T_m[c], inits[c], flat[c, cols])
+        got = q1[:, torch.from_numpy(cols).cuda()].cpu().numpy()
+        assert rel_err(got, ref) < RTOL
