@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void cema_gtresh(
 // (cemaneige_model.py:83-125).  Returns the layer-mean liquid outflow.
 template <int L>
 __device__ __forceinline__ double cema_day(
-    const double *__restrict__ day, const double *__restrict__ gtresh,
+    const double *__restrict__ day, const InvDivisor (&inv_gt)[L],
     bool first, double snow_pack_init, double thermal_state_init, double CTG,
     double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L])
 {
@@ -98,8 +98,12 @@ __device__ __forceinline__ double cema_day(
             pot_melt = Kf * temp;
             if (pot_melt > g) pot_melt = g;
         }
-        const double gt = gtresh[l];
-        const double ratio = (g < gt) ? g / gt : 1.0;      // :109-112
+        // G / G_tresh: the threshold is fixed for the whole run, so the
+        // quotient is the 3-instruction correctly rounded form of common.h
+        const double gt = inv_gt[l].b;
+        const double ratio =                               // :109-112
+            (g < gt) ? div_by_invariant(g, inv_div_numerator_ok(g), inv_gt[l])
+                     : 1.0;
         const double melt = (0.9 * ratio + 0.1) * pot_melt; // :115
         g = g - melt;                                      // :118
         G[l] = g;
@@ -124,13 +128,17 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const double CTG = p[0], Kf = p[1];
     const double omc = 1 - CTG;
     double G[L], eTG[L];
+    InvDivisor inv_gt[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
+    for (int l = 0; l < L; ++l) {
+        G[l] = 0.0; eTG[l] = 0.0;
+        inv_gt[l] = make_inv_divisor(gtresh[l]);
+    }
     double acc = 0.0;
     const bool wq = outflow != nullptr, ws = G_out != nullptr,
                we = sse != nullptr;
     for (int64_t t = 0; t < T; ++t) {
-        const double q = cema_day<L>(days + t * (3 * L), gtresh, t == 0,
+        const double q = cema_day<L>(days + t * (3 * L), inv_gt, t == 0,
                                      snow_pack_init, thermal_state_init, CTG,
                                      omc, Kf, G, eTG);
         if (active) {
@@ -167,11 +175,15 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneigegr4j_kernel(
     const double *p = params + (active ? i : N - 1) * 6;
     const double CTG = p[0], Kf = p[1];
     Gr4jPar P;
-    P.x1 = p[2]; P.x2 = p[3]; P.x3 = p[4]; P.x4 = p[5];
+    P.set(p[2], p[3], p[4], p[5]);
     const double omc = 1 - CTG;
     double G[L], eTG[L];
+    InvDivisor inv_gt[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
+    for (int l = 0; l < L; ++l) {
+        G[l] = 0.0; eTG[l] = 0.0;
+        inv_gt[l] = make_inv_divisor(gtresh[l]);
+    }
     UH uh;
     if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
     else uh.init(P.x4);
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneigegr4j_kernel(
     constexpr int D = 3 * L + 1;
     for (int64_t t = 0; t < T; ++t) {
         const double *day = days + t * D;
-        const double liquid = cema_day<L>(day, gtresh, t == 0, snow_pack_init,
+        const double liquid = cema_day<L>(day, inv_gt, t == 0, snow_pack_init,
                                           thermal_state_init, CTG, omc, Kf, G,
                                           eTG);
         const double q = gr4j_step(P, s, r, uh, liquid, day[3 * L]);

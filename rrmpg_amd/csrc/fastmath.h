@@ -1,5 +1,8 @@
-// fastpow.h -- x**y for the ensemble kernels, fp64, ~1 ulp, ~75 VALU
-// instructions instead of the ~224 of OCML's general pow.
+// fastmath.h -- the transcendental pieces of the ensemble kernels in fp64:
+//   fastpow_core      x**y, ~1 ulp, ~71 VALU instructions (OCML pow: ~224)
+//   fast_tanh         tanh, <= ~2.5 ulp, ~40 instructions (OCML tanh: ~165)
+//   inv_fourth_root   b**(-1/4), b >= 1, ~1.5 ulp, ~16 instructions
+// x**y first:
 //
 // Why: after the scalar forcing loads and coalesced stores, the HBV-Edu step
 // is fp64-VALU-issue bound and (soil/FC)**Beta (reference:
@@ -23,7 +26,7 @@
 // falls back to the general pow for the wave, so IEEE special cases stay
 // exactly those of pow().
 //
-// The same source compiles for the host (tests/test_fastpow_cpu.py builds a
+// The same source compiles for the host (tests/test_fastmath_cpu.py builds a
 // small harness with g++ and checks it against 80-bit powl): only the five
 // primitives below differ.
 #pragma once
@@ -51,6 +54,8 @@ static __device__ __forceinline__ double fp_fma_sconst_(double a, double b,
 #define FP_FREXP_MANT(x) __builtin_amdgcn_frexp_mant(x)
 #define FP_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
 #define FP_LDEXP(v, n) __builtin_amdgcn_ldexp((v), (n))
+#define FP_RSQ_APPROX(v) __builtin_amdgcn_rsq(v)      /* v_rsq_f64, ~2^-26 */
+#define FP_SQRT_APPROX(v) __builtin_amdgcn_sqrt(v)    /* v_sqrt_f64, ~2^-26 */
 #elif defined(__HIPCC__)
 // host pass of a .hip translation unit: the function is never called there
 #define FP_FN __device__ __forceinline__
@@ -61,6 +66,8 @@ static __device__ __forceinline__ double fp_fma_sconst_(double a, double b,
 #define FP_FREXP_MANT(x) (x)
 #define FP_FREXP_EXP(x) 0
 #define FP_LDEXP(v, n) (v)
+#define FP_RSQ_APPROX(v) (v)
+#define FP_SQRT_APPROX(v) (v)
 #else
 #define FP_FN static inline
 #define FP_RCP(g) (1.0 / (g))
@@ -72,6 +79,9 @@ static inline int fp_frexp_exp_(double x) { int e; (void)frexp(x, &e); return e;
 #define FP_FREXP_MANT(x) fp_frexp_mant_(x)
 #define FP_FREXP_EXP(x) fp_frexp_exp_(x)
 #define FP_LDEXP(v, n) ldexp((v), (n))
+/* host stand-ins for the hardware's ~26-bit estimates: single precision */
+#define FP_RSQ_APPROX(v) ((double)(1.0f / sqrtf((float)(v))))
+#define FP_SQRT_APPROX(v) ((double)sqrtf((float)(v)))
 #endif
 
 // Core: valid for finite x > 0.  Returns x**y if |y*log2 x| < 1000; *z_out
@@ -152,4 +162,62 @@ FP_FN bool fastpow_ok(double x, double z)
     // x > 0 and finite (NaN fails both compares); |z| < 1000 keeps 2^z normal
     // and rejects NaN / inf coming from a non-finite y
     return (x > 0.0) && (x < __builtin_inf()) && (__builtin_fabs(z) < 1000.0);
+}
+
+// ---------------------------------------------------------------------------
+// tanh(a), any a.  tanh(a) = E / (E + 2) with E = expm1(2|a|), sign restored.
+//   2|a| = n ln2 + r, |r| <= ln2/2 (ln2 split hi/lo so n*ln2_hi is exact);
+//   expm1(r) = r + r^2 (1/2 + r/6 + ... + r^11/13!) (truncation 1e-17 rel.);
+//   E = 2^n expm1(r) + (2^n - 1) in one FMA (2^n - 1 is exact for n <= 53).
+// |a| is clamped to 20 first (tanh(20) rounds to 1.0; keeps 2^n finite and
+// makes +-inf give +-1); NaN propagates; tanh(+-0) = +-0.  Error <= ~2.5 ulp
+// (libm: 1 ulp), measured by tests/native/fastmath_harness.cpp.
+// Used for np.tanh(p_n / x1) of GR4J (reference: gr4j_model.py:95-96, 107-108).
+FP_FN double fast_tanh(double a)
+{
+    const double ax = __builtin_fabs(a);
+    const double x = (ax > 20.0) ? 20.0 : ax;        // NaN stays NaN
+    const double y = 2.0 * x;
+    const double n = FP_RINT(y * 1.4426950408889634);
+    const double r = FP_FMA(-n, 1.90821492927058770002e-10,
+                            FP_FMA(-n, 6.93147180369123816490e-01, y));
+    double q = 1.6059043836821613e-10;               // 1/13!
+    q = FP_FMA_C(q, r, 2.08767569878681e-09);        // 1/12!
+    q = FP_FMA_C(q, r, 2.505210838544172e-08);       // 1/11!
+    q = FP_FMA_C(q, r, 2.755731922398589e-07);       // 1/10!
+    q = FP_FMA_C(q, r, 2.7557319223985893e-06);      // 1/9!
+    q = FP_FMA_C(q, r, 2.48015873015873e-05);        // 1/8!
+    q = FP_FMA_C(q, r, 0.0001984126984126984);       // 1/7!
+    q = FP_FMA_C(q, r, 0.001388888888888889);        // 1/6!
+    q = FP_FMA_C(q, r, 0.008333333333333333);        // 1/5!
+    q = FP_FMA_C(q, r, 0.041666666666666664);        // 1/4!
+    q = FP_FMA_C(q, r, 0.16666666666666666);         // 1/3!
+    q = FP_FMA_C(q, r, 0.5);
+    const double p = FP_FMA(r * r, q, r);            // expm1(r)
+    const double two_n = FP_LDEXP(1.0, (int)n);
+    const double E = FP_FMA(two_n, p, two_n - 1.0);  // expm1(2|a|)
+    const double t = E / (E + 2.0);
+    return __builtin_copysign(t, a);
+}
+
+// ---------------------------------------------------------------------------
+// b**(-1/4) for b >= 1 (or NaN).  Hardware estimate y0 = sqrt(rsq(b))
+// (~2^-25), then two Newton steps for y^-4 = b:
+//     y <- y + (y/4) (1 - b y^4)
+// (quadratic: 2^-25 -> 2^-50 -> below rounding), ~16 instructions instead of
+// sqrt, sqrt, divide (56).  Error <= ~1.5 ulp.  b is clamped to 1e300: for
+// b >= 1e300 (inf included) the result is < 1e-75, which every caller only
+// uses as 1 - result == 1.0 exactly; NaN propagates.
+// Used for (1 + v**4)**(-0.25) of GR4J (reference: gr4j_model.py:117, 145).
+FP_FN double inv_fourth_root(double b)
+{
+    const double bb = (b > 1e300) ? 1e300 : b;       // NaN stays NaN
+    double y = FP_SQRT_APPROX(FP_RSQ_APPROX(bb));
+    double y2 = y * y;
+    double e = FP_FMA(-bb, y2 * y2, 1.0);
+    y = FP_FMA(y * 0.25, e, y);
+    y2 = y * y;
+    e = FP_FMA(-bb, y2 * y2, 1.0);
+    y = FP_FMA(y * 0.25, e, y);
+    return y;
 }

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(RR_BLOCK) void gr4j_kernel(
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 4;
     Gr4jPar P;
-    P.x1 = p[0]; P.x2 = p[1]; P.x3 = p[2]; P.x4 = p[3];
+    P.set(p[0], p[1], p[2], p[3]);
 
     UH uh;
     if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);

@@ -22,10 +22,24 @@
 #pragma once
 
 #include "common.h"
+#include "fastmath.h"
 
 struct Gr4jPar {
     double x1, x2, x3, x4;
+    InvDivisor inv_x1, inv_x3;   // x1, x3 divide five quantities every day
+    __device__ __forceinline__ void set(double a, double b, double c, double d)
+    {
+        x1 = a; x2 = b; x3 = c; x4 = d;
+        inv_x1 = make_inv_divisor(a);
+        inv_x3 = make_inv_divisor(c);
+    }
 };
+
+// a / x for the per-lane invariant x (bit-identical to `/`, see common.h)
+__device__ __forceinline__ double gr4j_div(double a, const InvDivisor &d)
+{
+    return div_by_invariant(a, inv_div_numerator_ok(a), d);
+}
 
 // _s_curve1 (gr4j_model.py:159-173); t is the integer ordinate index
 __device__ __forceinline__ double gr4j_s_curve1(int t, double x4)
@@ -196,19 +210,17 @@ struct UhLds {
     }
 };
 
-// The three float powers of the daily step have fixed exponents, so they are
-// evaluated with correctly rounded sqrt / divide / multiply instead of the
-// general pow (224 VALU instructions in OCML): each is within ~2 ulp of the
-// exact power (libm's pow is within 1 ulp), far inside the 1e-10 parity
-// tolerance, and IEEE special cases come out as pow's do:
-//   b**(-0.25), b = 1 + v^4 >= 1 (or inf/NaN): 1/sqrt(sqrt(b));
-//   inf -> 0, NaN -> NaN.
-//   x**3.5: x*x*x*sqrt(x); 0 -> 0, inf -> inf, x < 0 -> NaN (as pow for a
-//   negative base with a non-integer exponent), NaN -> NaN.
-__device__ __forceinline__ double inv_fourth_root(double b)
-{
-    return 1.0 / sqrt(sqrt(b));
-}
+// The transcendental calls of the daily step (reference: 1 tanh + 3 pow) are
+// evaluated with fastmath.h instead of OCML's general tanh / pow (165 / 224
+// VALU instructions each):
+//   np.tanh(.)            -> fast_tanh, <= ~2.5 ulp;
+//   (1 + v**4)**(-0.25)   -> inv_fourth_root, ~1 ulp (Newton on y^-4 = b);
+//   (r/x3)**3.5           -> x*x*x*sqrt(x) with a correctly rounded sqrt,
+//                            <= ~2.5 ulp; 0 -> 0, inf -> inf, x < 0 -> NaN
+//                            (as pow for a negative base and a non-integer
+//                            exponent), NaN -> NaN.
+// libm's own pow/tanh are faithful to ~1 ulp; these few-ulp differences are
+// far inside the 1e-10 parity tolerance (observed ~1e-13 on 30-year runs).
 __device__ __forceinline__ double pow_3_5(double x)
 {
     return x * x * x * sqrt(x);
@@ -226,8 +238,8 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
     // quotient; only the branch that applies is evaluated.
     const bool wet = prec >= etp;
     const double net = wet ? prec - etp : etp - prec;
-    const double sx = s / P.x1;
-    const double th = tanh(net / P.x1);
+    const double sx = gr4j_div(s, P.inv_x1);
+    const double th = fast_tanh(gr4j_div(net, P.inv_x1));
     double num, den;
     if (wet) {
         num = P.x1 * (1 - sx * sx) * th;            // eq. 3 (:95-96)
@@ -243,7 +255,7 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
 
     double sn = s - e_s + p_s;                                  // :114
     // percolation (:117); **4 is two squarings
-    const double v = 4.0 / 9.0 * sn / P.x1;
+    const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1);
     const double v2 = v * v;
     const double perc = sn * (1 - inv_fourth_root(1 + v2 * v2));
     sn = sn - perc;                                             // :120
@@ -254,9 +266,9 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
     double head1, head2;
     uh.route(p_r_uh1, p_r_uh2, head1, head2);                   // :130-136
 
-    const double gw_exchange = P.x2 * pow_3_5(r / P.x3);        // :139
+    const double gw_exchange = P.x2 * pow_3_5(gr4j_div(r, P.inv_x3)); // :139
     double rn = nb_max(0.0, r + head1 + gw_exchange);           // :142
-    const double w = rn / P.x3;
+    const double w = gr4j_div(rn, P.inv_x3);
     const double w2 = w * w;
     const double q_r = rn * (1 - inv_fourth_root(1 + w2 * w2)); // :145
     rn = rn - q_r;                                              // :148

@@ -22,9 +22,9 @@
 //
 // Arithmetic follows the reference statement by statement in fp64 without
 // FMA contraction (-ffp-contract=off); only the power (soil/FC)**Beta is not
-// libm's: it is fastpow.h's ~1-ulp evaluation (general pow as fallback).
+// libm's: it is fastmath.h's ~1-ulp evaluation (general pow as fallback).
 #include "common.h"
-#include "fastpow.h"
+#include "fastmath.h"
 
 struct __attribute__((aligned(32))) HbvDay {
     double temp;   // temp[t]
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
         if (__any(need_pow)) {
             const double wetness = div_by_invariant(soil, soil_ok, inv_FC);
-            // fastpow.h: ~1 ulp, a third of the general pow's instructions;
+            // fastmath.h: ~1 ulp, a third of the general pow's instructions;
             // arguments outside its domain take the general pow (wave-wide)
             double z;
             double pw = fastpow_core(wetness, Beta, &z);

@@ -1,4 +1,4 @@
-// CPU accuracy harness for rrmpg_amd/csrc/fastpow.h (built and run by
+// CPU accuracy harness for rrmpg_amd/csrc/fastmath.h (built and run by
 // tests/test_fastpow_cpu.py): compares fastpow_core with 80-bit powl on random
 // arguments and prints the worst error in ulp of the double result.
 #include <cmath>
@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "../../rrmpg_amd/csrc/fastpow.h"
+#include "../../rrmpg_amd/csrc/fastmath.h"
 
 static uint64_t s = 88172645463325252ULL;
 static double u01() {          // xorshift64*, uniform in [0,1)
@@ -60,5 +60,38 @@ int main(int argc, char **argv) {
         if (err > wl) wl = err;
     }
     printf("libm_pow_worst_ulp_hbv %.4f\n", wl);
+
+    // tanh: arguments as GR4J produces them (net / x1 in [0, ~1]) and wide
+    double wt = 0, wtx = 0, wtw = 0, wtwx = 0;
+    for (long i = 0; i < n; ++i) {
+        double a = 1.2 * u01() * u01();
+        double err = ulp_err(fast_tanh(a), tanhl((long double)a));
+        if (err > wt) { wt = err; wtx = a; }
+        a = exp2(-40 + 46 * u01()) * (u01() < 0.5 ? -1 : 1);
+        err = ulp_err(fast_tanh(a), tanhl((long double)a));
+        if (err > wtw) { wtw = err; wtwx = a; }
+    }
+    printf("worst_ulp_tanh_gr4j %.4f at a=%.17g\n", wt, wtx);
+    printf("worst_ulp_tanh_wide %.4f at a=%.17g\n", wtw, wtwx);
+    int tanh_special = fast_tanh(0.0) == 0.0 && signbit(fast_tanh(-0.0)) &&
+                       fast_tanh(INFINITY) == 1.0 && fast_tanh(-INFINITY) == -1.0 &&
+                       fast_tanh(25.0) == 1.0 && fast_tanh(-1e300) == -1.0 &&
+                       std::isnan(fast_tanh(NAN)) &&
+                       fast_tanh(1e-300) == 1e-300 && fast_tanh(-4e-320) == -4e-320;
+    printf("tanh_special_ok %d\n", tanh_special);
+
+    // b**(-1/4), b = 1 + v^4 >= 1
+    double wr = 0, wrx = 0;
+    for (long i = 0; i < n; ++i) {
+        double v = (i & 1) ? 3.0 * u01() : exp2(-30 + 60 * u01());
+        double b = 1 + (v * v) * (v * v);
+        double err = ulp_err(inv_fourth_root(b), powl((long double)b, -0.25L));
+        if (err > wr) { wr = err; wrx = b; }
+    }
+    printf("worst_ulp_inv_fourth_root %.4f at b=%.17g\n", wr, wrx);
+    int r4_special = inv_fourth_root(1.0) == 1.0 && inv_fourth_root(16.0) == 0.5 &&
+                     inv_fourth_root(INFINITY) < 1e-70 && inv_fourth_root(1e308) < 1e-70 &&
+                     std::isnan(inv_fourth_root(NAN));
+    printf("r4_special_ok %d\n", r4_special);
     return 0;
 }

@@ -3,7 +3,7 @@ uses instead of OCML's general pow / hipcc's division expansion.  Both headers
 are portable; small g++ harnesses (tests/native/) exercise the very source the
 kernels compile.
 
-  * fastpow.h : worst error vs 80-bit powl stays ~1 ulp (libm's pow: 0.5 ulp)
+  * fastmath.h : worst error vs 80-bit powl stays ~1 ulp (libm's pow: 0.5 ulp)
   * invdiv.h  : bit-identical to `a / b` on 2e7 random + adversarial pairs
 """
 
@@ -25,13 +25,18 @@ def _build_and_run(src, tmp_path, *args):
 
 
 def test_fastpow_accuracy(tmp_path):
-    out = _build_and_run("fastpow_harness.cpp", tmp_path, "400000")
+    out = _build_and_run("fastmath_harness.cpp", tmp_path, "400000")
     vals = dict(re.findall(r"^(\w+) ([0-9.]+)", out, flags=re.M))
     assert float(vals["worst_ulp_hbv"]) < 1.25, out
     assert float(vals["worst_ulp_wide"]) < 1.25, out
     assert float(vals["worst_ulp_near1"]) < 1.25, out
     assert int(vals["exact_ok"]) == 1, out
     assert int(vals["guard_rejected"]) == 0, out
+    assert float(vals["worst_ulp_tanh_gr4j"]) < 3.0, out
+    assert float(vals["worst_ulp_tanh_wide"]) < 3.0, out
+    assert int(vals["tanh_special_ok"]) == 1, out
+    assert float(vals["worst_ulp_inv_fourth_root"]) < 2.0, out
+    assert int(vals["r4_special_ok"]) == 1, out
 
 
 def test_invariant_division_is_bit_exact(tmp_path):
