@@ -47,7 +47,8 @@ def parse_args():
     ap.add_argument("--sets", type=int, default=1_000_000,
                     help="parameter sets per GPU")
     ap.add_argument("--days", type=int, default=10957)
-    ap.add_argument("--mode", default="qsim", choices=["qsim", "metric"],
+    ap.add_argument("--mode", default="qsim",
+                    choices=["qsim", "metric", "storages"],
                     help="qsim: materialise qsim[T,N] + fused per-set SSE "
                          "(default); metric: fused per-set SSE only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,9 +96,20 @@ def build_workload(args, device, rank):
     ens.run(params[:1].contiguous(), q0)
     torch.cuda.synchronize(device)
     qobs = torch.from_numpy(syn.make_qobs(q0.cpu().numpy())).to(device)
-    qsim = ens.new_output(n) if args.mode == "qsim" else None
+    qsim = ens.new_output(n) if args.mode != "metric" else None
+    storages = None
+    if args.mode == "storages":          # every state series as well
+        if args.model == "hbvedu":
+            storages = tuple(ens.new_output(n) for _ in range(4))
+        elif args.model == "gr4j":
+            storages = tuple(ens.new_output(n) for _ in range(2))
+        elif args.model == "abc":
+            storages = ens.new_output(n)
+        else:
+            storages = (ens.new_output(n, 5), ens.new_output(n, 5),
+                        ens.new_output(n), ens.new_output(n))
     sse = torch.empty(n, dtype=torch.float64, device=device)
-    return ens, params, params_host, qsim, qobs, sse, name, f
+    return ens, params, params_host, qsim, storages, qobs, sse, name, f
 
 
 def cpu_baseline(args, f, params_host):
@@ -166,13 +178,19 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
-    ens, params, params_host, qsim, qobs, sse, name, f = build_workload(
-        args, device, rank)
+    (ens, params, params_host, qsim, storages, qobs, sse, name,
+     f) = build_workload(args, device, rank)
     n, t = args.sets, args.days
     total_sets = n * world
 
+    def launch():
+        if storages is None:
+            ens.run(params, qsim, qobs=qobs, sse=sse)
+        else:
+            ens.run(params, qsim, storages, qobs=qobs, sse=sse)
+
     def step():
-        ens.run(params, qsim, qobs=qobs, sse=sse)
+        launch()
         # per-set MSE of this rank's block, then the one collective of the
         # whole job: all-gather of the scores (8 B per set)
         mse = sse / t
@@ -195,7 +213,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        ens.run(params, qsim, qobs=qobs, sse=sse)
+        launch()
         ev[k][1].record()
         mse = sse / t
         scores = allgather_scores(mse, total_sets)
@@ -212,7 +230,9 @@ def main():
 
     if rank == 0:
         value = total_sets * t * args.steps / elapsed
-        bytes_per_step = 8 if args.mode == "qsim" else 0
+        all_out = {"hbvedu": 40, "abc": 16, "gr4j": 24, "cemaneigegr4j": 104}
+        bytes_per_step = {"qsim": 8, "metric": 0,
+                          "storages": all_out[args.model]}[args.mode]
         achieved = bytes_per_step * n * t / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
@@ -240,9 +260,13 @@ def main():
                 "workload": "%s Monte-Carlo sweep, %d parameter sets per GPU x "
                             "%d daily steps, %s, RCCL all-gather of per-set "
                             "MSE" % (name, n, t,
-                                     "qsim[T,N] written to HBM + fused "
-                                     "per-set MSE" if args.mode == "qsim"
-                                     else "fused per-set MSE only"),
+                                     {"qsim": "qsim[T,N] written to HBM + "
+                                              "fused per-set MSE",
+                                      "metric": "fused per-set MSE only",
+                                      "storages": "qsim and every state "
+                                                  "series written to HBM + "
+                                                  "fused per-set MSE"
+                                      }[args.mode]),
                 "model": args.model,
                 "sets_per_gpu": n,
                 "timesteps": t,

@@ -61,7 +61,8 @@ extern "C" {
 #define RR_E_NODEVICE -5  /* no usable gfx950 device                        */
 #define RR_E_WORKSPACE -6 /* workspace missing or too small                 */
 
-/* Cemaneige: elevation layers held in registers per parameter set. */
+/* Cemaneige: up to this many elevation layers keep their snow states in
+ * registers; more layers run through an HBM scratch (slower, same results). */
 #define RR_CEMANEIGE_MAX_LAYERS 8
 /* GR4J: largest x4 the LDS unit-hydrograph tier holds (ceil(x4) ordinates
  * for UH1, ceil(2*x4+1) for UH2). */
@@ -158,8 +159,7 @@ int rr_gr4j_simulate(const double *prec, const double *etp, int64_t T,
  *                        thermal_state_init, params)
  * (reference: rrmpg/models/cemaneige_model.py:15-126); the three forcing
  * arrays are [T][L] row-major; params = {CTG, Kf}; G, eTG are [T][L][ld].
- * 1 <= L <= RR_CEMANEIGE_MAX_LAYERS else RR_E_PARAM.  qobs/sse compare
- * against `outflow`. */
+ * L >= 1.  qobs/sse compare against `outflow`. */
 size_t rr_cemaneige_workspace_bytes(int64_t T, int64_t L, int64_t N);
 int rr_cemaneige_simulate_dev(const double *prec, const double *mean_temp,
                               const double *frac_solid_prec, int64_t T,

@@ -217,35 +217,149 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneigegr4j_kernel(
     if (we && active) sse[i] = acc;
 }
 
-// workspace: [0,256) x4 scan | [256,512) G_tresh[8] | days
-static size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp)
+// ---- more than RR_CEMANEIGE_MAX_LAYERS elevation layers ----------------------
+// Same day step with a run-time layer count; the per-layer snow states live
+// in an HBM scratch [2][L][N] (lane-contiguous, so every access is a coalesced
+// 512-byte row per wave) instead of registers.  Rare (Cemaneige is defined
+// with 5 layers), so it favours simplicity: plain `/`, no unrolling.
+__device__ __forceinline__ double cema_day_dyn(
+    const double *__restrict__ day, const double *__restrict__ gtresh, int L,
+    bool first, double snow_pack_init, double thermal_state_init, double CTG,
+    double one_minus_CTG, double Kf, double *__restrict__ Gs,
+    double *__restrict__ Es, int64_t stride, double *__restrict__ G_out,
+    double *__restrict__ eTG_out, int64_t out_stride, bool write)
+{
+    double c = 0.0;
+    for (int l = 0; l < L; ++l) {
+        const double snow = day[l], rain = day[L + l], temp = day[2 * L + l];
+        double g, e;
+        if (first) {
+            g = snow_pack_init;
+            e = thermal_state_init;
+        } else {
+            g = Gs[l * stride] + snow;
+            e = CTG * Es[l * stride] + one_minus_CTG * temp;
+        }
+        if (e > 0) e = 0.0;
+        double pot_melt = 0.0;
+        if (e == 0 && temp > 0) {
+            pot_melt = Kf * temp;
+            if (pot_melt > g) pot_melt = g;
+        }
+        const double gt = gtresh[l];
+        const double ratio = (g < gt) ? g / gt : 1.0;
+        const double melt = (0.9 * ratio + 0.1) * pot_melt;
+        g = g - melt;
+        Gs[l * stride] = g;
+        Es[l * stride] = e;
+        if (write) {
+            G_out[l * out_stride] = g;
+            eTG_out[l * out_stride] = e;
+        }
+        c += rain + melt;
+    }
+    return c / (double)L;
+}
+
+// UH = void: snow routine only; otherwise the fused Cemaneige -> GR4J sweep.
+template <class UH>
+__global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
+    const double *__restrict__ days, const double *__restrict__ gtresh,
+    int64_t T, int L, int D, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *__restrict__ params, int npar,
+    int64_t N, int n1cap, int n2cap, double *__restrict__ state,
+    double *__restrict__ qsim, double *__restrict__ G_out,
+    double *__restrict__ eTG_out, double *__restrict__ s_store,
+    double *__restrict__ r_store, int64_t ld,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr bool coupled = !std::is_same<UH, void>::value;
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = i < N;
+    const int64_t ii = active ? i : N - 1;
+    const double *p = params + ii * npar;
+    const double CTG = p[0], Kf = p[1];
+    const double omc = 1 - CTG;
+    // tail lanes of the last wave share (and rewrite identically) set N-1's
+    // scratch column, like the register kernels recompute it
+    double *Gs = state + ii, *Es = state + (int64_t)L * N + ii;
+    Gr4jPar P;
+    typename std::conditional<coupled, UH, int>::type uh;
+    double s = 0.0, r = 0.0;
+    if constexpr (coupled) {
+        P.set(p[2], p[3], p[4], p[5]);
+        if constexpr (std::is_same<UH, UhLds>::value)
+            uh.init(lds, n1cap, n2cap, P.x4);
+        else
+            uh.init(P.x4);
+        s = s_init * P.x1;
+        r = r_init * P.x3;
+    }
+    double acc = 0.0;
+    const bool wq = qsim != nullptr, ws = G_out != nullptr, we = sse != nullptr;
+    for (int64_t t = 0; t < T; ++t) {
+        const double *day = days + t * D;
+        double q = cema_day_dyn(day, gtresh, L, t == 0, snow_pack_init,
+                                thermal_state_init, CTG, omc, Kf, Gs, Es, N,
+                                ws ? G_out + (t * L) * ld + i : nullptr,
+                                ws ? eTG_out + (t * L) * ld + i : nullptr, ld,
+                                ws && active);
+        if constexpr (coupled) q = gr4j_step(P, s, r, uh, q, day[3 * L]);
+        if (active) {
+            if (wq) qsim[t * ld + i] = q;
+            if (coupled && ws) {
+                s_store[t * ld + i] = s;
+                r_store[t * ld + i] = r;
+            }
+        }
+        if (we) {
+            const double d = qobs[t] - q;
+            acc += d * d;
+        }
+    }
+    if (we && active) sse[i] = acc;
+}
+
+// workspace: [0,256) x4 scan | G_tresh[L] | days | (L > 8: state[2][L][N])
+static size_t cema_days_bytes(int64_t T, int64_t L, bool with_etp)
 {
     if (T < 1) T = 1;
     if (L < 1) L = 1;
-    return 512 + rr_align256((size_t)T * (size_t)(3 * L + (with_etp ? 1 : 0)) * 8);
+    return rr_align256((size_t)T * (size_t)(3 * L + (with_etp ? 1 : 0)) * 8);
+}
+
+// + the [2][L][N] snow-state scratch when the layers do not fit in registers
+static size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp, int64_t N)
+{
+    size_t b = 512 + rr_align256((size_t)(L > 0 ? L : 1) * 8) +
+               cema_days_bytes(T, L, with_etp);
+    if (L > RR_CEMANEIGE_MAX_LAYERS && N > 0)
+        b += rr_align256((size_t)2 * (size_t)L * (size_t)N * 8);
+    return b;
 }
 
 extern "C" size_t rr_cemaneige_workspace_bytes(int64_t T, int64_t L, int64_t N)
 {
-    (void)N;
-    return cema_ws_bytes(T, L, false);
+    return cema_ws_bytes(T, L, false, N);
 }
 
 extern "C" size_t rr_cemaneigegr4j_workspace_bytes(int64_t T, int64_t L,
                                                    int64_t N)
 {
-    (void)N;
-    return cema_ws_bytes(T, L, true);
+    return cema_ws_bytes(T, L, true, N);
 }
 
 static int cema_prepass(const double *prec, const double *mean_temp,
                         const double *frac, const double *etp, int64_t T,
                         int L, void *workspace, hipStream_t st,
-                        double **days_out, double **gt_out)
+                        double **days_out, double **gt_out,
+                        double **state_out)
 {
     const int D = 3 * L + (etp ? 1 : 0);
-    double *gt = (double *)((char *)workspace + 256);
-    double *days = (double *)((char *)workspace + 512);
+    double *gt = (double *)((char *)workspace + 512);
+    double *days = (double *)((char *)workspace + 512 +
+                              rr_align256((size_t)L * 8));
     hipLaunchKernelGGL(cema_pack, dim3((unsigned)rr_ceil_div(T * L, 256)),
                        dim3(256), 0, st, prec, mean_temp, frac, etp, T, L, D,
                        days);
@@ -253,15 +367,16 @@ static int cema_prepass(const double *prec, const double *mean_temp,
                        T, D, gt);
     *days_out = days;
     *gt_out = gt;
+    *state_out = (double *)((char *)days + cema_days_bytes(T, L, etp != nullptr));
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
 
 static int cema_check_layers(const char *who, int64_t L)
 {
-    if (L < 1 || L > RR_CEMANEIGE_MAX_LAYERS) {
-        rr_set_error("%s: %lld elevation layers; supported: 1..%d", who,
-                     (long long)L, RR_CEMANEIGE_MAX_LAYERS);
+    if (L < 1 || L > 4096) {
+        rr_set_error("%s: %lld elevation layers; supported: 1..4096", who,
+                     (long long)L);
         return RR_E_PARAM;
     }
     return RR_OK;
@@ -304,17 +419,25 @@ extern "C" int rr_cemaneige_simulate_dev(
         rr_set_error("rr_cemaneige_simulate_dev: pass both G and eTG or none");
         return RR_E_NULL;
     }
-    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, false)) {
+    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, false, N)) {
         rr_set_error("rr_cemaneige_simulate_dev: workspace too small");
         return RR_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    double *days, *gt;
+    double *days, *gt, *state;
     rc = cema_prepass(prec, mean_temp, frac_solid_prec, nullptr, T, (int)L,
-                      workspace, st, &days, &gt);
+                      workspace, st, &days, &gt, &state);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
+    if (L > RR_CEMANEIGE_MAX_LAYERS) {
+        cemaneige_dyn_kernel<void><<<grid, block, 0, st>>>(
+            days, gt, T, (int)L, 3 * (int)L, snow_pack_init,
+            thermal_state_init, 0., 0., params, 2, N, 0, 0, state, outflow, G,
+            eTG, nullptr, nullptr, ld, qo, sse);
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     dispatch_layers((int)L, [&](auto LL) {
         cemaneige_kernel<LL.value><<<grid, block, 0, st>>>(
             days, gt, T, snow_pack_init, thermal_state_init, params, N,
@@ -350,7 +473,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                      "outputs or none");
         return RR_E_NULL;
     }
-    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true)) {
+    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true, N)) {
         rr_set_error("rr_cemaneigegr4j_simulate_dev: workspace too small");
         return RR_E_WORKSPACE;
     }
@@ -358,14 +481,28 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
     int n1cap = 0, n2cap = 0;
     rc = rr_gr4j_plan(params, N, 6, 5, (int *)workspace, st, &n1cap, &n2cap);
     if (rc != RR_OK) return rc;
-    double *days, *gt;
+    double *days, *gt, *state;
     rc = cema_prepass(prec, mean_temp, frac_solid_prec, etp, T, (int)L,
-                      workspace, st, &days, &gt);
+                      workspace, st, &days, &gt, &state);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
     const size_t lds_bytes =
         (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
+    if (L > RR_CEMANEIGE_MAX_LAYERS) {
+        if (n1cap == 0)
+            cemaneige_dyn_kernel<UhRegs<3>><<<grid, block, 0, st>>>(
+                days, gt, T, (int)L, 3 * (int)L + 1, snow_pack_init,
+                thermal_state_init, s_init, r_init, params, 6, N, 0, 0, state,
+                qsim, G, eTG, s_store, r_store, ld, qo, sse);
+        else
+            cemaneige_dyn_kernel<UhLds><<<grid, block, lds_bytes, st>>>(
+                days, gt, T, (int)L, 3 * (int)L + 1, snow_pack_init,
+                thermal_state_init, s_init, r_init, params, 6, N, n1cap, n2cap,
+                state, qsim, G, eTG, s_store, r_store, ld, qo, sse);
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     dispatch_layers((int)L, [&](auto LL) {
         if (n1cap == 0)
             cemaneigegr4j_kernel<LL.value, UhRegs<3>><<<grid, block, 0, st>>>(

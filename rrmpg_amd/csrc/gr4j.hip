@@ -9,6 +9,8 @@
 // convolution state in registers (x4 <= 3 launch-wide) or staged in LDS
 // (gr4j_core.h).  The shared {prec, etp} day record is wave-uniform and is
 // fetched with one scalar s_load_dwordx4 per day.
+#include <stdlib.h>
+
 #include "gr4j_core.h"
 
 struct __attribute__((aligned(16))) GrDay {
@@ -126,7 +128,10 @@ int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
                      (double)RR_GR4J_MAX_X4);
         return RR_E_PARAM;
     }
-    if (h[0] <= 3) {
+    // RRHIP_GR4J_FORCE_LDS=1 (measurement hook): use the LDS tier even when
+    // every x4 <= 3 would allow the register tier
+    const char *force = getenv("RRHIP_GR4J_FORCE_LDS");
+    if (h[0] <= 3 && !(force && force[0] == '1')) {
         *n1cap = 0;
         *n2cap = 0;
     } else {

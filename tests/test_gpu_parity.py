@@ -310,10 +310,29 @@ def test_cemaneige_bit_exact_vs_oracle(models, oracle):
                                         return_storages=True)
         for a, b in zip(out, ref):
             assert np.array_equal(a, b), nl
-    with pytest.raises(RuntimeError, match="RR_E_PARAM"):
-        models.Cemaneige().simulate(
-            p["prec"][:50], p["temp"][:50], p["tmin"][:50], p["tmax"][:50],
-            500, altitudes=list(np.linspace(500, 3000, 9)))
+    # more than 8 layers: states move from registers to an HBM scratch, the
+    # results stay bit-identical
+    from rrmpg_amd.models import cemaneige_utils as cu
+    for nl in (9, 13):
+        alts = list(np.linspace(480, 3300, nl))
+        fl = rng.random((130, 2)) * np.array([1., 10.])
+        out = models.Cemaneige().simulate(
+            p["prec"][:700], p["temp"][:700], p["tmin"][:700], p["tmax"][:700],
+            500, 1.0, -0.5, altitudes=alts, return_storages=True,
+            params=_records(models.Cemaneige, fl))
+        lp = cu.extrapolate_precipitation(p["prec"][:700], alts, 500)
+        lmin, lmean, lmax = cu.extrapolate_temperature(
+            p["tmin"][:700], p["temp"][:700], p["tmax"][:700], alts, 500)
+        fr = cu.calculate_solid_fraction(lp, np.array(alts), lmean, lmin, lmax)
+        ref = oracle.simulate_cemaneige(lp, lmean, fr, (1.0, -0.5), fl,
+                                        return_storages=True)
+        for a, b in zip(out, ref):
+            assert np.array_equal(a, b), nl
+        o2 = models.Cemaneige().simulate(
+            p["prec"][:700], p["temp"][:700], p["tmin"][:700], p["tmax"][:700],
+            500, 1.0, -0.5, altitudes=alts,
+            params=_records(models.Cemaneige, fl))
+        assert np.array_equal(o2, ref[0])
 
 
 # --------------------------------------------------------- CemaneigeGR4J
@@ -362,6 +381,24 @@ def test_cemaneigegr4j_golden_and_oracle(models, oracle):
         g["etp"][:t], syn.STATION_HEIGHT, i[0], i[1], i[2], i[3],
         altitudes=syn.ALTITUDES, params=_records(models.CemaneigeGR4J, flat))
     assert rel_err(out, ref) < RTOL
+    # 10 elevation layers (HBM-scratch kernel), both unit-hydrograph tiers
+    from rrmpg_amd.models import cemaneige_utils as cu
+    alts = list(np.linspace(520, 2900, 10))
+    t = 600
+    lp = cu.extrapolate_precipitation(p["prec"][:t], alts, 500)
+    lmin, lmean, lmax = cu.extrapolate_temperature(
+        p["tmin"][:t], p["temp"][:t], p["tmax"][:t], alts, 500)
+    fr = cu.calculate_solid_fraction(lp, np.array(alts), lmean, lmin, lmax)
+    for fl in (g["params"], flat):
+        ref = oracle.simulate_cemaneigegr4j(lp, lmean, g["etp"][:t], fr, i, fl,
+                                            return_storages=True)
+        out = models.CemaneigeGR4J().simulate(
+            p["prec"][:t], p["temp"][:t], p["tmin"][:t], p["tmax"][:t],
+            g["etp"][:t], 500, i[0], i[1], i[2], i[3], altitudes=alts,
+            return_storages=True, params=_records(models.CemaneigeGR4J, fl))
+        assert np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2])
+        for a, b in zip(out, ref):
+            assert rel_err(a, b, floor=1e-9) < RTOL
 
 
 # ------------------------------------------ fused metric, sweeps, boundary
