@@ -8,7 +8,6 @@ call into librrhip (rr_abc_simulate) instead of a Python loop over run_abcmodel.
 import numbers
 
 import numpy as np
-from scipy import optimize
 
 from .. import _lib
 from ..utils.array_checks import check_for_negatives, validate_array_input
@@ -90,12 +89,15 @@ class ABCModel(BaseModel):
             return qsim, storage
         return qsim
 
-    def fit(self, qobs, prec, initial_state=0):
+    def fit(self, qobs, prec, initial_state=0, batched=False):
         """Fit the model to a timeseries of discharge.
 
         Uses scipy's differential evolution, as the reference does
         (abcmodel.py:188-232); every candidate is one GPU call that returns
         only its squared-error sum.
+
+        batched=True (extension): one GPU sweep per generation, see
+        BaseModel._differential_evolution.
 
         Returns:
             res: A scipy OptimizeResult class object.
@@ -103,8 +105,7 @@ class ABCModel(BaseModel):
         qobs = validate_array_input(qobs, np.float64, 'qobs')
         prec, initial_state = _validate(prec, initial_state)
         args = (prec, initial_state, qobs, self._dtype)
-        bnds = tuple([self._default_bounds[p] for p in self._param_list])
-        return optimize.differential_evolution(_loss, bounds=bnds, args=args)
+        return self._differential_evolution(_loss, args, batched)
 
     # used by rrmpg_amd.tools.monte_carlo: qsim and/or fused per-set SSE
     def _sweep(self, params, qobs, want_qsim, prec, initial_state=0):
@@ -148,7 +149,7 @@ def _run(prec, initial_state, params, want_qsim, want_storage, qobs):
 def _loss(X, *args):
     """Return the loss value (MSE) for the current parameter set."""
     prec, initial_state, qobs, dtype = args
-    params = np.zeros(1, dtype=dtype)
-    params['a'], params['b'], params['c'] = X[0], X[1], X[2]
+    params = ABCModel._params_from_population(X)
     _, _, sse = _run(prec, initial_state, params, False, False, qobs)
-    return sse[0] / prec.shape[0]
+    mse = sse / prec.shape[0]
+    return mse if np.ndim(X) == 2 else mse[0]

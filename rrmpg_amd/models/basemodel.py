@@ -144,12 +144,36 @@ class BaseModel(object):
         return params
 
     @classmethod
-    def _params_from_vector(cls, X):
-        """One parameter record from the optimiser's candidate vector."""
-        params = np.zeros(1, dtype=cls._dtype)
-        for value, name in zip(X, cls._param_list):
-            params[name] = value
+    def _params_from_population(cls, X):
+        """Parameter records from the optimiser's candidates.
+
+        X: one candidate vector [k] -> 1 record, or a population [k, S] (scipy
+        differential_evolution with vectorized=True) -> S records.
+        """
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = X[:, None]
+        params = np.zeros(X.shape[1], dtype=cls._dtype)
+        for row, name in zip(X, cls._param_list):
+            params[name] = row
         return params
+
+    def _differential_evolution(self, loss, args, batched):
+        """scipy's differential evolution over the default bounds.
+
+        batched=False reproduces the reference's call (one candidate per loss
+        evaluation, updating='immediate'; e.g. reference hbvedu.py:305).
+        batched=True (extension) hands scipy a vectorised loss so that every
+        generation's whole population is ONE GPU sweep (updating='deferred':
+        a different, equally valid, optimiser trajectory).
+        """
+        from scipy import optimize
+        bnds = tuple([self._default_bounds[p] for p in self._param_list])
+        if batched:
+            return optimize.differential_evolution(
+                loss, bounds=bnds, args=args, vectorized=True,
+                updating='deferred')
+        return optimize.differential_evolution(loss, bounds=bnds, args=args)
 
 
 def new_outputs(shape, wanted):

@@ -10,7 +10,6 @@ run_cemaneige.  The parameter-independent forcing preprocessing
 import numbers
 
 import numpy as np
-from scipy import optimize
 
 from .. import _lib
 from ..utils.array_checks import check_for_negatives, validate_array_input
@@ -84,7 +83,7 @@ class Cemaneige(BaseModel):
 
     def fit(self, obs, prec, mean_temp, min_temp, max_temp,
             met_station_height, snow_pack_init=0, thermal_state_init=0,
-            altitudes=[]):
+            altitudes=[], batched=False):
         """Fit the Cemaneige model to an observed timeseries.
 
         scipy differential evolution over the default bounds, as in the
@@ -98,8 +97,7 @@ class Cemaneige(BaseModel):
             prec, mean_temp, min_temp, max_temp, met_station_height,
             snow_pack_init, thermal_state_init, altitudes)
         args = (obs,) + layers + inits + (self._dtype,)
-        bnds = tuple([self._default_bounds[p] for p in self._param_list])
-        return optimize.differential_evolution(_loss, bounds=bnds, args=args)
+        return self._differential_evolution(_loss, args, batched)
 
     def _sweep(self, params, qobs, want_qsim, prec, mean_temp, min_temp,
                max_temp, met_station_height, snow_pack_init=0,
@@ -208,7 +206,7 @@ def _loss(X, *args):
     layers = args[1:4]
     inits = args[4:6]
     dtype = args[6]
-    params = np.zeros(1, dtype=dtype)
-    params['CTG'], params['Kf'] = X[0], X[1]
+    params = Cemaneige._params_from_population(X)
     _, sse = _run(layers, inits, params, False, False, obs)
-    return sse[0] / layers[0].shape[0]
+    mse = sse / layers[0].shape[0]
+    return mse if np.ndim(X) == 2 else mse[0]

@@ -9,7 +9,6 @@ kernel, the snow routine's outflow feeds GR4J in registers.
 import numbers
 
 import numpy as np
-from scipy import optimize
 
 from .. import _lib
 from ..utils.array_checks import validate_array_input
@@ -83,7 +82,7 @@ class CemaneigeGR4J(BaseModel):
 
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp,
             met_station_height, snow_pack_init=0, thermal_state_init=0,
-            s_init=0, r_init=0, altitudes=[]):
+            s_init=0, r_init=0, altitudes=[], batched=False):
         """Fit the Cemaneige + GR4J coupled model to an observed timeseries.
 
         scipy differential evolution over the default bounds, as in the
@@ -97,8 +96,7 @@ class CemaneigeGR4J(BaseModel):
                                  met_station_height, snow_pack_init,
                                  thermal_state_init, s_init, r_init, altitudes)
         args = (obs,) + layers + inits + (self._dtype,)
-        bnds = tuple([self._default_bounds[p] for p in self._param_list])
-        return optimize.differential_evolution(_loss, bounds=bnds, args=args)
+        return self._differential_evolution(_loss, args, batched)
 
     def _sweep(self, params, qobs, want_qsim, prec, mean_temp, min_temp,
                max_temp, etp, met_station_height, snow_pack_init=0,
@@ -154,8 +152,7 @@ def _loss(X, *args):
     layers = args[1:5]
     inits = args[5:9]
     dtype = args[9]
-    params = np.zeros(1, dtype=dtype)
-    for value, name in zip(X, CemaneigeGR4J._param_list):
-        params[name] = value
+    params = CemaneigeGR4J._params_from_population(X)
     _, sse = _run(layers, inits, params, False, False, obs)
-    return sse[0] / layers[0].shape[0]
+    mse = sse / layers[0].shape[0]
+    return mse if np.ndim(X) == 2 else mse[0]

@@ -13,7 +13,6 @@ column is simulated.
 import numbers
 
 import numpy as np
-from scipy import optimize
 
 from .. import _lib
 from ..utils.array_checks import check_for_negatives, validate_array_input
@@ -83,7 +82,7 @@ class GR4J(BaseModel):
             return tuple(out)
         return out[0]
 
-    def fit(self, qobs, prec, etp, s_init=0., r_init=0.):
+    def fit(self, qobs, prec, etp, s_init=0., r_init=0., batched=False):
         """Fit the GR4J model to a timeseries of discharge.
 
         scipy differential evolution over the default bounds, as in the
@@ -96,8 +95,7 @@ class GR4J(BaseModel):
         qobs = validate_array_input(qobs, np.float64, 'observed discharge')
         s_init, r_init = _validate_inits(s_init, r_init)
         args = (qobs, prec, etp, s_init, r_init, self._dtype)
-        bnds = tuple([self._default_bounds[p] for p in self._param_list])
-        return optimize.differential_evolution(_loss, bounds=bnds, args=args)
+        return self._differential_evolution(_loss, args, batched)
 
     def _sweep(self, params, qobs, want_qsim, prec, etp, s_init=0.,
                r_init=0.):
@@ -155,8 +153,7 @@ def _run(prec, etp, s_init, r_init, params, want_qsim, want_storage, qobs):
 def _loss(X, *args):
     """Return the loss value (MSE) for the current parameter set."""
     qobs, prec, etp, s_init, r_init, dtype = args
-    params = np.zeros(1, dtype=dtype)
-    params['x1'], params['x2'] = X[0], X[1]
-    params['x3'], params['x4'] = X[2], X[3]
+    params = GR4J._params_from_population(X)
     _, sse = _run(prec, etp, s_init, r_init, params, False, False, qobs)
-    return sse[0] / prec.shape[0]
+    mse = sse / prec.shape[0]
+    return mse if np.ndim(X) == 2 else mse[0]

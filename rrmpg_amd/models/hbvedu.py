@@ -6,7 +6,6 @@ librrhip (rr_hbvedu_simulate) instead of a Python loop over run_hbvedu.
 """
 
 import numpy as np
-from scipy import optimize
 
 from .. import _lib
 from ..utils.array_checks import check_for_negatives, validate_array_input
@@ -81,7 +80,7 @@ class HBVEdu(BaseModel):
         return out[0]
 
     def fit(self, qobs, temp, prec, month, PE_m, T_m, snow_init=0.,
-            soil_init=0., s1_init=0., s2_init=0.):
+            soil_init=0., s1_init=0., s2_init=0., batched=False):
         """Fit the HBVEdu model to a timeseries of discharge.
 
         scipy differential evolution over the default bounds, as in the
@@ -95,8 +94,7 @@ class HBVEdu(BaseModel):
         inits = tuple(float(v) for v in (snow_init, soil_init, s1_init,
                                          s2_init))
         args = (qobs,) + forcing + inits + (self._dtype,)
-        bnds = tuple([self._default_bounds[p] for p in self._param_list])
-        return optimize.differential_evolution(_loss, bounds=bnds, args=args)
+        return self._differential_evolution(_loss, args, batched)
 
     def _sweep(self, params, qobs, want_qsim, temp, prec, month, PE_m, T_m,
                snow_init=0, soil_init=0, s1_init=0, s2_init=0):
@@ -159,8 +157,7 @@ def _loss(X, *args):
     forcing = args[1:6]
     inits = args[6:10]
     dtype = args[10]
-    params = np.zeros(1, dtype=dtype)
-    for value, name in zip(X, HBVEdu._param_list):
-        params[name] = value
+    params = HBVEdu._params_from_population(X)
     _, sse = _run(forcing, inits, params, False, False, qobs)
-    return sse[0] / forcing[1].shape[0]
+    mse = sse / forcing[1].shape[0]
+    return mse if np.ndim(X) == 2 else mse[0]

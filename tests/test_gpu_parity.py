@@ -538,3 +538,29 @@ def test_device_division_by_invariant_is_bit_exact():
     same = (ref.view(np.uint64) == want.view(np.uint64)) | \
            (np.isnan(ref) & np.isnan(want))
     assert same.all()      # device `/` is IEEE-correct, like the host's
+
+
+def test_batched_fit_one_sweep_per_generation(models):
+    """fit(batched=True): scipy hands whole populations to a vectorised loss,
+    so each generation is one GPU sweep.  Checked on GR4J (4 parameters)."""
+    rng = np.random.default_rng(3)
+    n = 400
+    prec = rng.gamma(0.8, 6.0, n) * (rng.random(n) < 0.5)
+    etp = np.clip(2 + np.sin(np.arange(n) / 58.0), 0, None)
+    truth = models.GR4J(params={'x1': 420., 'x2': 0.8, 'x3': 95., 'x4': 1.9})
+    qobs = truth.simulate(prec, etp, s_init=0.5, r_init=0.5).ravel()
+    np.random.seed(1)
+    res = models.GR4J().fit(qobs, prec, etp, s_init=0.5, r_init=0.5,
+                            batched=True)
+    assert res.fun < 1e-3
+    best = models.GR4J(params=dict(zip(models.GR4J._param_list, res.x)))
+    q = best.simulate(prec, etp, s_init=0.5, r_init=0.5).ravel()
+    assert np.mean((q - qobs) ** 2) < 1e-3
+    # the vectorised loss and the scalar loss agree
+    from rrmpg_amd.models import gr4j as gr4j_mod
+    args = (qobs, prec, etp, 0.5, 0.5, models.GR4J._dtype)
+    X = np.array([[400., 450.], [0.5, 1.0], [90., 100.], [1.5, 2.5]])
+    pop = gr4j_mod._loss(X, *args)
+    assert pop.shape == (2,)
+    assert pop[0] == gr4j_mod._loss(X[:, 0], *args)
+    assert pop[1] == gr4j_mod._loss(X[:, 1], *args)
