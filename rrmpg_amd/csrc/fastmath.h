@@ -70,7 +70,8 @@ static __device__ __forceinline__ double fp_fma_sconst_(double a, double b,
 #define FP_SQRT_APPROX(v) (v)
 #else
 #define FP_FN static inline
-#define FP_RCP(g) (1.0 / (g))
+/* host stand-in for v_rcp_f64's ~26-bit estimate: a single-precision 1/g */
+#define FP_RCP(g) ((double)(1.0f / (float)(g)))
 #define FP_FMA(a, b, c) fma((a), (b), (c))
 #define FP_FMA_C(a, b, c) fma((a), (b), (c))
 #define FP_RINT(v) rint(v)
@@ -99,8 +100,10 @@ FP_FN double fastpow_core(double x, double y, double *z_out)
     const double f = m - 1.0;                   // exact
     const double g = m + 1.0;                   // may round ...
     const double g_lo = m - (g - 1.0);          // ... by exactly this much
+    // 1/g to ~2^-50: hardware estimate (~2^-26) + one Newton step.  That is
+    // all the double-double quotient needs: the FMA residual below removes
+    // s_hi's error exactly and s_lo only has to be good to ~2^-50 itself.
     double rg = FP_RCP(g);
-    rg = FP_FMA(FP_FMA(-g, rg, 1.0), rg, rg);   // Newton: ~1 ulp reciprocal
     rg = FP_FMA(FP_FMA(-g, rg, 1.0), rg, rg);
     const double s_hi = f * rg;
     double res = FP_FMA(-s_hi, g, f);           // f - s_hi*(g + g_lo)
