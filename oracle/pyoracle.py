@@ -156,3 +156,45 @@ def simulate_cemaneigegr4j(prec, mean_temp, etp, frac_solid, inits, params,
     if rc != 0:
         raise IndexError("GR4J unit hydrograph has no ordinates (x4 <= 0)")
     return (q, g, e, s, r) if return_storages else q
+
+
+def simulate_snow_gr4j(hyst, ice, prec, mean_temp, etp, frac_solid, inits,
+                       params, frac_ice=None, return_storages=False,
+                       nthreads=1):
+    """The hysteresis / ice-melt couplings (next tier).
+
+    inits = (snow_pack_init, thermal_state_init, sca_init, s_init, r_init).
+    Returns qsim, or with return_storages a dict of every series.
+    """
+    L = lib()
+    if not hasattr(L, "_snow_set"):
+        L.oracle_simulate_snow_gr4j.argtypes = (
+            [ctypes.c_int, ctypes.c_int] + [_f64p] * 5 + [_i64, _i64]
+            + [_dbl] * 5 + [_f64p, _i64] + [_f64p] * 9 + [ctypes.c_int])
+        L.oracle_simulate_snow_gr4j.restype = ctypes.c_int
+        L._snow_set = True
+    prec, mean_temp, frac_solid = _c(prec), _c(mean_temp), _c(frac_solid)
+    etp = _c(etp)
+    t, nl = prec.shape
+    k = 6 + (2 if hyst else 0) + (1 if ice else 0)
+    p, n = _params2d(params, k)
+    fi = _c(frac_ice) if frac_ice is not None else np.zeros(nl)
+    q = np.zeros((t, n))
+    out = {}
+    if return_storages:
+        for name in ("G", "eTG", "sca", "rain"):
+            out[name] = np.zeros((t, nl, n))
+        for name in ("s_store", "r_store", "icemelt", "snowmelt"):
+            out[name] = np.zeros((t, n))
+    g = lambda name: _p(out.get(name))
+    rc = L.oracle_simulate_snow_gr4j(
+        int(hyst), int(ice), _p(prec), _p(mean_temp), _p(etp), _p(fi),
+        _p(frac_solid), t, nl, *[float(x) for x in inits], _p(p), n, _p(q),
+        g("G"), g("eTG"), g("s_store"), g("r_store"), g("sca"), g("icemelt"),
+        g("snowmelt"), g("rain"), nthreads)
+    if rc != 0:
+        raise IndexError("GR4J unit hydrograph has no ordinates (x4 <= 0)")
+    if return_storages:
+        out["qsim"] = q
+        return out
+    return q

@@ -448,3 +448,206 @@ int oracle_max_threads(void)
     return 1;
 #endif
 }
+
+/* ======================================================================
+ * Next tier: hysteresis snow routine, ice melt
+ * and their couplings with GR4J.
+ * ====================================================================== */
+
+/* reference: rrmpg/models/cemaneigehyst_model.py:5-166
+ * params = {CTG, Kf, Thacc, Rsp} (read by name from the coupled record);
+ * G, eTG, sca, rain: [T][L]; outflow: [T].  Quirk kept: at t = 0 the
+ * accumulation branch reads sca[t-1] = sca[-1], the still-zero LAST row, so
+ * sca_init never survives the first step (cemaneigehyst_model.py:96-98,126). */
+void oracle_run_cemaneigehyst(const double *prec, const double *mean_temp,
+                              const double *frac_solid_prec, int64_t T,
+                              int64_t L, double snow_pack_init,
+                              double thermal_state_init, double sca_init,
+                              double CTG, double Kf, double Thacc, double Rsp,
+                              double *outflow, double *G, double *eTG,
+                              double *sca, double *rain)
+{
+    if (T <= 0 || L <= 0) return;
+    double *liquid_water = (double *)calloc((size_t)(T * L), sizeof(double));
+    double *snow = (double *)malloc((size_t)T * sizeof(double));
+    memset(sca, 0, (size_t)(T * L) * sizeof(double));
+    for (int64_t l = 0; l < L; ++l) {           /* :86 */
+        double c = 0.0;
+        for (int64_t t = 0; t < T; ++t) {       /* :89-90 */
+            snow[t] = prec[t * L + l] * frac_solid_prec[t * L + l];
+            rain[t * L + l] = prec[t * L + l] - snow[t];
+            c += snow[t];
+        }
+        const double Psolannual = 365.25 * (c / (double)T);    /* :93 */
+        double swe_max = 0.0, Thmax = 0.0;
+        for (int64_t t = 0; t < T; ++t) {
+            double g, e, s;
+            if (t == 0) {                       /* :98-102 */
+                g = snow_pack_init;
+                sca[t * L + l] = sca_init;
+            } else {
+                g = G[(t - 1) * L + l] + snow[t];
+            }
+            if (t == 0) e = thermal_state_init; /* :105-110 */
+            else e = CTG * eTG[(t - 1) * L + l]
+                     + (1 - CTG) * mean_temp[t * L + l];
+            if (e > 0) e = 0.0;
+            double pot_melt;                    /* :113-120 */
+            if (e == 0 && mean_temp[t * L + l] > 0) {
+                pot_melt = Kf * mean_temp[t * L + l];
+                if (pot_melt > g) pot_melt = g;
+            } else {
+                pot_melt = 0.0;
+            }
+            const double snow_balance = snow[t] - pot_melt;     /* :123 */
+            if (snow_balance >= 0) {            /* :126-129 */
+                /* sca[t-1]: row -1 (= T-1, still zero) when t == 0 */
+                const double prev = sca[((t == 0) ? (T - 1) : (t - 1)) * L + l];
+                s = prev + snow_balance / Thacc;
+                swe_max = nb_max(swe_max, g);
+            } else {                            /* :130-142 */
+                const double Thmelt = Psolannual * Rsp;
+                if (swe_max > Thmelt) Thmax = Thmelt;
+                else Thmax = swe_max;
+                if (Thmax > 0) s = g / Thmax;
+                else s = 0.0;
+            }
+            s = nb_min(nb_max(s, 0.0), 1.0);    /* :145 */
+            double melt = (0.9 * s + 0.1) * pot_melt;           /* :148 */
+            melt = nb_min(melt, g);             /* :151 */
+            g = g - melt;                       /* :154 */
+            if (g == 0) swe_max = 0.0;          /* :157-158 */
+            G[t * L + l] = g;
+            eTG[t * L + l] = e;
+            sca[t * L + l] = s;
+            liquid_water[t * L + l] = rain[t * L + l] + melt;   /* :162 */
+        }
+    }
+    for (int64_t t = 0; t < T; ++t) {           /* :165-166 */
+        double c = 0.0;
+        for (int64_t l = 0; l < L; ++l) c += liquid_water[t * L + l];
+        outflow[t] = c / (double)L;
+    }
+    free(liquid_water); free(snow);
+}
+
+/* reference: rrmpg/models/icemelt_model.py:15-65 followed by the layer
+ * weighting of the couplings, np.sum(icemelt * frac_ice[None, :], axis=1)
+ * (cemaneigegr4jice_model.py:81-84): total[t] = sum_l ice[t,l]*frac_ice[l],
+ * summed left to right. */
+void oracle_icemelt_total(const double *temp, const double *snow,
+                          const double *frac_ice, int64_t T, int64_t L,
+                          double ddf, double *total)
+{
+    for (int64_t t = 0; t < T; ++t) {
+        double c = 0.0;
+        for (int64_t l = 0; l < L; ++l) {
+            double melt = ddf * (temp[t * L + l] - 0);  /* tbase = 0, :57 */
+            if (melt < 0) melt = 0.0;
+            const double lw = (snow[t * L + l] > 1) ? 0.0 : melt;  /* :60-63 */
+            c += lw * frac_ice[l];
+        }
+        total[t] = c;
+    }
+}
+
+/* One parameter set of the three couplings.
+ * hyst: params = {CTG,Kf,Thacc,Rsp,x1..x4[,DDF]}, else {CTG,Kf,x1..x4[,DDF]}.
+ * reference: cemaneigehystgr4j_model.py:17-79, cemaneigegr4jice_model.py:
+ * 20-93, cemaneigehystgr4jice_model.py:22-104.  Outputs not produced by a
+ * variant may be NULL (sca: hyst only; icemelt: ice only; snowmelt: the snow
+ * routine's outflow before the ice melt is added). */
+int oracle_run_snow_gr4j(int hyst, int ice, const double *prec,
+                         const double *mean_temp, const double *etp,
+                         const double *frac_ice,
+                         const double *frac_solid_prec, int64_t T, int64_t L,
+                         double snow_pack_init, double thermal_state_init,
+                         double sca_init, double s_init, double r_init,
+                         const double *params, double *qsim, double *G,
+                         double *eTG, double *s_store, double *r_store,
+                         double *sca, double *icemelt, double *snowmelt,
+                         double *rain)
+{
+    if (T <= 0 || L <= 0) return 0;
+    const size_t tl = (size_t)(T * L);
+    double *snow_out = (double *)malloc((size_t)T * sizeof(double));
+    double *sca_b = sca ? sca : (double *)malloc(tl * sizeof(double));
+    double *rain_b = rain ? rain : (double *)malloc(tl * sizeof(double));
+    const double *gp;
+    double ddf = 0.0;
+    if (hyst) {
+        oracle_run_cemaneigehyst(prec, mean_temp, frac_solid_prec, T, L,
+                                 snow_pack_init, thermal_state_init, sca_init,
+                                 params[0], params[1], params[2], params[3],
+                                 snow_out, G, eTG, sca_b, rain_b);
+        gp = params + 4;
+        if (ice) ddf = params[8];
+    } else {
+        oracle_run_cemaneige(prec, mean_temp, frac_solid_prec, T, L,
+                             snow_pack_init, thermal_state_init, params,
+                             snow_out, G, eTG);
+        gp = params + 2;
+        if (ice) ddf = params[6];
+    }
+    double *liquid = (double *)malloc((size_t)T * sizeof(double));
+    if (ice) {
+        double *tot = icemelt ? icemelt : (double *)malloc((size_t)T * 8);
+        oracle_icemelt_total(mean_temp, G, frac_ice, T, L, ddf, tot);
+        for (int64_t t = 0; t < T; ++t) liquid[t] = snow_out[t] + tot[t];
+        if (!icemelt) free(tot);
+    } else {
+        memcpy(liquid, snow_out, (size_t)T * sizeof(double));
+    }
+    if (snowmelt) memcpy(snowmelt, snow_out, (size_t)T * sizeof(double));
+    const int rc = oracle_run_gr4j(liquid, etp, T, s_init, r_init, gp, qsim,
+                                   s_store, r_store);
+    free(liquid); free(snow_out);
+    if (!sca) free(sca_b);
+    if (!rain) free(rain_b);
+    return rc;
+}
+
+/* Reference-shaped sweep of a coupling over N parameter sets (npar doubles
+ * each).  2-D outputs [T][N], 3-D outputs [T][L][N]; all but qsim nullable. */
+int oracle_simulate_snow_gr4j(int hyst, int ice, const double *prec,
+                              const double *mean_temp, const double *etp,
+                              const double *frac_ice,
+                              const double *frac_solid_prec, int64_t T,
+                              int64_t L, double snow_pack_init,
+                              double thermal_state_init, double sca_init,
+                              double s_init, double r_init,
+                              const double *params, int64_t N, double *qsim,
+                              double *G, double *eTG, double *s_store,
+                              double *r_store, double *sca, double *icemelt,
+                              double *snowmelt, double *rain, int nthreads)
+{
+    const int npar = 6 + (hyst ? 2 : 0) + (ice ? 1 : 0);
+    int rc = 0;
+    SWEEP_THREADS(nthreads)
+#pragma omp parallel for num_threads(_nt) schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        const size_t n = (size_t)(T > 0 ? T : 1), nl = n * (size_t)(L > 0 ? L : 1);
+        double *a = (double *)calloc(5 * n, sizeof(double));
+        double *b = (double *)calloc(4 * nl, sizeof(double));
+        if (oracle_run_snow_gr4j(hyst, ice, prec, mean_temp, etp, frac_ice,
+                                 frac_solid_prec, T, L, snow_pack_init,
+                                 thermal_state_init, sca_init, s_init, r_init,
+                                 params + npar * i, a, b, b + nl, a + n,
+                                 a + 2 * n, b + 2 * nl, a + 3 * n, a + 4 * n,
+                                 b + 3 * nl) != 0) {
+#pragma omp atomic write
+            rc = -1;
+        }
+        scatter(qsim, N, i, a, T);
+        scatter(s_store, N, i, a + n, T);
+        scatter(r_store, N, i, a + 2 * n, T);
+        scatter(icemelt, N, i, a + 3 * n, T);
+        scatter(snowmelt, N, i, a + 4 * n, T);
+        scatter(G, N, i, b, T * L);
+        scatter(eTG, N, i, b + nl, T * L);
+        scatter(sca, N, i, b + 2 * nl, T * L);
+        scatter(rain, N, i, b + 3 * nl, T * L);
+        free(a); free(b);
+    }
+    return rc;
+}

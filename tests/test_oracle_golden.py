@@ -182,3 +182,63 @@ def test_threads_do_not_change_results(oracle):
     a = oracle.simulate_hbvedu(*args, nthreads=1)
     b = oracle.simulate_hbvedu(*args, nthreads=4)
     assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------ next tier
+# hysteresis snow routine, ice melt and their GR4J couplings (reference:
+# cemaneigehyst_model.py, icemelt_model.py, cemaneigehystgr4j_model.py,
+# cemaneigegr4jice_model.py, cemaneigehystgr4jice_model.py); KATs:
+# reference test/test_models.py:293-310 and :336-356.
+def _check_next(out, g, keys, idx=None):
+    for k in keys:
+        a, b = out[k], g[k] if idx is not None else g["ref_" + k]
+        if idx is not None and a.ndim == 3:
+            assert rel_err(a[idx], b, floor=1e-6) < TOL, k
+            assert rel_err(a[-1], g[k + "_last"], floor=1e-6) < TOL, k
+        else:
+            assert rel_err(a.reshape(b.shape), b, floor=1e-6) < TOL, k
+
+
+def test_cemaneigehystgr4j_kat_excel(oracle):
+    g = golden("kat_cemaneigehystgr4j")
+    lp, lmean, frac = _layers(g)
+    out = oracle.simulate_snow_gr4j(True, False, lp, lmean, g["etp"], frac,
+                                    g["inits"], g["params"],
+                                    return_storages=True)
+    assert np.allclose(out["qsim"].ravel(), g["qsim_excel"])
+    _check_next(out, g, ["qsim", "G", "eTG", "s_store", "r_store", "sca",
+                         "rain"])
+
+
+def test_cemaneigehystgr4jice_kat_excel(oracle):
+    g = golden("kat_cemaneigehystgr4jice")
+    lp, lmean, frac = _layers(g)
+    out = oracle.simulate_snow_gr4j(True, True, lp, lmean, g["etp"], frac,
+                                    g["inits"], g["params"],
+                                    frac_ice=g["frac_ice"],
+                                    return_storages=True)
+    assert np.allclose(out["qsim"].ravel(), g["qsim_excel"])
+    _check_next(out, g, ["qsim", "G", "eTG", "s_store", "r_store", "sca",
+                         "icemelt", "snowmelt", "rain"])
+
+
+def test_next_tier_synthetic(oracle):
+    h = golden("syn_cemaneigehystgr4j")
+    idx = h["stride_idx"]
+    forcing = (h["layer_prec"], h["layer_mean"], h["etp"], h["frac_solid"])
+    out = oracle.simulate_snow_gr4j(True, False, *forcing, h["inits"],
+                                    h["params"], return_storages=True)
+    _check_next(out, h, ["qsim", "G", "eTG", "s_store", "r_store", "sca",
+                         "rain"], idx)
+    g = golden("syn_cemaneigegr4jice")
+    out = oracle.simulate_snow_gr4j(False, True, *forcing, g["inits"],
+                                    g["params"], frac_ice=g["frac_ice"],
+                                    return_storages=True)
+    _check_next(out, g, ["qsim", "G", "eTG", "s_store", "r_store", "icemelt"],
+                idx)
+    g = golden("syn_cemaneigehystgr4jice")
+    out = oracle.simulate_snow_gr4j(True, True, *forcing, g["inits"],
+                                    g["params"], frac_ice=g["frac_ice"],
+                                    return_storages=True)
+    _check_next(out, g, ["qsim", "G", "eTG", "s_store", "r_store", "sca",
+                         "icemelt", "snowmelt", "rain"], idx)
