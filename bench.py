@@ -43,7 +43,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="hbvedu",
-                    choices=["hbvedu", "abc", "gr4j", "cemaneigegr4j"])
+                    choices=["hbvedu", "abc", "gr4j", "cemaneigegr4j",
+                             "cemaneigehystgr4j", "cemaneigegr4jice",
+                             "cemaneigehystgr4jice"])
     ap.add_argument("--sets", type=int, default=1_000_000,
                     help="parameter sets per GPU")
     ap.add_argument("--days", type=int, default=10957)
@@ -79,6 +81,21 @@ def build_workload(args, device, rank):
         ens = rrdev.GR4JEnsemble(f["prec"], f["etp"], device=device,
                                  **syn.GR4J_INITS)
         name = "GR4J"
+    elif args.model in ("cemaneigehystgr4j", "cemaneigegr4jice",
+                        "cemaneigehystgr4jice"):
+        from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+        hyst, ice = "hyst" in args.model, "ice" in args.model
+        cls = {"cemaneigehystgr4j": models.CemaneigeHystGR4J,
+               "cemaneigegr4jice": models.CemaneigeGR4JIce,
+               "cemaneigehystgr4jice": models.CemaneigeHystGR4JIce}[args.model]
+        layers, inits = prepare_snow_inputs(
+            f["prec"], f["temp"] - 3, f["tmin"] - 3, f["tmax"] - 3,
+            syn.STATION_HEIGHT, 0, 0, list(syn.ALTITUDES), etp=f["etp"])
+        ens = rrdev.SnowGR4JEnsemble(
+            hyst, ice, layers[0], layers[1], layers[2], layers[3],
+            frac_ice=[0.02, 0.04, 0.25, 0.51, 0.71] if ice else None,
+            s_init=0.6, r_init=0.7, device=device)
+        name = cls.__name__ + "(L=5)"
     else:
         cls = models.CemaneigeGR4J
         from rrmpg_amd.models.cemaneige import prepare_snow_inputs
@@ -230,7 +247,9 @@ def main():
 
     if rank == 0:
         value = total_sets * t * args.steps / elapsed
-        all_out = {"hbvedu": 40, "abc": 16, "gr4j": 24, "cemaneigegr4j": 104}
+        all_out = {"hbvedu": 40, "abc": 16, "gr4j": 24, "cemaneigegr4j": 104,
+                   "cemaneigehystgr4j": 0, "cemaneigegr4jice": 0,
+                   "cemaneigehystgr4jice": 0}
         bytes_per_step = {"qsim": 8, "metric": 0,
                           "storages": all_out[args.model]}[args.mode]
         achieved = bytes_per_step * n * t / (kernel_ms * 1e-3) / 1e9

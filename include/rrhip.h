@@ -206,6 +206,80 @@ int rr_cemaneigegr4j_simulate(const double *prec, const double *mean_temp,
                               double *s_store, double *r_store,
                               const double *qobs, double *sse);
 
+/* ==== next tier: SWE-SCA hysteresis snow routine, ice melt, couplings ====
+ * The reference's CemaneigeHystGR4J, CemaneigeGR4JIce, CemaneigeHystGR4JIce
+ * (SURVEY.md section 8f N1).  Same conventions as above; 1 <= L <= 8;
+ * `frac_ice` is [L]; sca is [T][L][ld]; icemelt, snowmelt are [T][ld]
+ * (snowmelt = the snow routine's layer-mean outflow before the ice melt is
+ * added).  All variants share one workspace size. */
+size_t rr_snowgr4j_workspace_bytes(int64_t T, int64_t L, int64_t N);
+
+/* replaces run_cemaneigehystgr4j(prec, mean_temp, etp, frac_solid_prec,
+ *     snow_pack_init, thermal_state_init, sca_init, s_init, r_init, params)
+ * (reference: rrmpg/models/cemaneigehystgr4j_model.py:17-79 over
+ * cemaneigehyst_model.py:5-166); params = {CTG,Kf,Thacc,Rsp,x1,x2,x3,x4}.
+ * The reference's `rain` output is parameter independent (prec - prec*frac)
+ * and is rebuilt on the host. */
+int rr_cemaneigehystgr4j_simulate_dev(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_solid_prec, int64_t T, int64_t L,
+    double snow_pack_init, double thermal_state_init, double sca_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *sca, int64_t ld, const double *qobs, double *sse, void *workspace,
+    size_t workspace_bytes, void *stream);
+int rr_cemaneigehystgr4j_simulate(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_solid_prec, int64_t T, int64_t L,
+    double snow_pack_init, double thermal_state_init, double sca_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *sca, const double *qobs, double *sse);
+
+/* replaces run_cemaneigegr4jice(prec, mean_temp, etp, frac_ice,
+ *     frac_solid_prec, snow_pack_init, thermal_state_init, s_init, r_init,
+ *     params)
+ * (reference: rrmpg/models/cemaneigegr4jice_model.py:20-93 over
+ * icemelt_model.py:15-65); params = {CTG,Kf,x1,x2,x3,x4,DDF}. */
+int rr_cemaneigegr4jice_simulate_dev(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *icemelt, int64_t ld, const double *qobs, double *sse,
+    void *workspace, size_t workspace_bytes, void *stream);
+int rr_cemaneigegr4jice_simulate(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *icemelt, const double *qobs, double *sse);
+
+/* replaces run_cemaneigehystgr4jice(prec, mean_temp, etp, frac_ice,
+ *     frac_solid_prec, snow_pack_init, thermal_state_init, sca_init, s_init,
+ *     r_init, params)
+ * (reference: rrmpg/models/cemaneigehystgr4jice_model.py:22-104);
+ * params = {CTG,Kf,Thacc,Rsp,x1,x2,x3,x4,DDF}. */
+int rr_cemaneigehystgr4jice_simulate_dev(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double sca_init, double s_init, double r_init, const double *params,
+    int64_t N, double *qsim, double *G, double *eTG, double *s_store,
+    double *r_store, double *sca, double *icemelt, double *snowmelt,
+    int64_t ld, const double *qobs, double *sse, void *workspace,
+    size_t workspace_bytes, void *stream);
+int rr_cemaneigehystgr4jice_simulate(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double sca_init, double s_init, double r_init, const double *params,
+    int64_t N, double *qsim, double *G, double *eTG, double *s_store,
+    double *r_store, double *sca, double *icemelt, double *snowmelt,
+    const double *qobs, double *sse);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,25 @@ _SIGNATURES = {
     "rr_cemaneigegr4j_simulate": (ctypes.c_int,
                                   [_f64p] * 4 + [_i64, _i64] + [_dbl] * 4
                                   + [_f64p, _i64] + [_f64p] * 7),
+    "rr_snowgr4j_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "rr_cemaneigehystgr4j_simulate_dev": (
+        ctypes.c_int, [_vp] * 4 + [_i64, _i64] + [_dbl] * 5 + [_vp, _i64]
+        + [_vp] * 6 + [_i64, _vp, _vp, _vp, _sz, _vp]),
+    "rr_cemaneigehystgr4j_simulate": (
+        ctypes.c_int, [_f64p] * 4 + [_i64, _i64] + [_dbl] * 5 + [_f64p, _i64]
+        + [_f64p] * 8),
+    "rr_cemaneigegr4jice_simulate_dev": (
+        ctypes.c_int, [_vp] * 5 + [_i64, _i64] + [_dbl] * 4 + [_vp, _i64]
+        + [_vp] * 6 + [_i64, _vp, _vp, _vp, _sz, _vp]),
+    "rr_cemaneigegr4jice_simulate": (
+        ctypes.c_int, [_f64p] * 5 + [_i64, _i64] + [_dbl] * 4 + [_f64p, _i64]
+        + [_f64p] * 8),
+    "rr_cemaneigehystgr4jice_simulate_dev": (
+        ctypes.c_int, [_vp] * 5 + [_i64, _i64] + [_dbl] * 5 + [_vp, _i64]
+        + [_vp] * 8 + [_i64, _vp, _vp, _vp, _sz, _vp]),
+    "rr_cemaneigehystgr4jice_simulate": (
+        ctypes.c_int, [_f64p] * 5 + [_i64, _i64] + [_dbl] * 5 + [_f64p, _i64]
+        + [_f64p] * 10),
 }
 
 _lib = None

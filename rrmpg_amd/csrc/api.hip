@@ -381,3 +381,119 @@ extern "C" int rrdbg_divide_by_invariant(const double *a, const double *b,
     RR_HIP(hipMemcpy(ref, dref.p, (size_t)n * 8, hipMemcpyDeviceToHost));
     return RR_OK;
 }
+
+// ---- next tier: hysteresis / ice-melt couplings (host pointers) ------------
+namespace {
+
+enum SnowVariant { HYST = 1, ICE = 2 };
+
+int snow_gr4j_host(const char *who, int variant, const double *prec,
+                   const double *mean_temp, const double *etp,
+                   const double *frac_ice, const double *frac_solid_prec,
+                   int64_t T, int64_t L, double snow_pack_init,
+                   double thermal_state_init, double sca_init, double s_init,
+                   double r_init, const double *params, int64_t N,
+                   double *qsim, double *G, double *eTG, double *s_store,
+                   double *r_store, double *sca, double *icemelt,
+                   double *snowmelt, const double *qobs, double *sse)
+{
+    const bool hyst = variant & HYST, ice = variant & ICE;
+    const int npar = 6 + (hyst ? 2 : 0) + (ice ? 1 : 0);
+    int rc = rr_check_common(who, T, N, N, params, qobs, sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if (L < 1) { rr_set_error("%s: L < 1", who); return RR_E_PARAM; }
+    if (!prec || !mean_temp || !etp || !frac_solid_prec || (ice && !frac_ice)) {
+        rr_set_error("%s: NULL forcing pointer", who);
+        return RR_E_NULL;
+    }
+    if ((rc = require_device()) != RR_OK) return rc;
+    DevBuf d_prec, d_temp, d_etp, d_frac, d_fice, d_par, d_qobs, ws;
+    const size_t tl = (size_t)T * (size_t)L * 8;
+    if ((rc = d_prec.upload(prec, tl)) != RR_OK) return rc;
+    if ((rc = d_temp.upload(mean_temp, tl)) != RR_OK) return rc;
+    if ((rc = d_etp.upload(etp, (size_t)T * 8)) != RR_OK) return rc;
+    if ((rc = d_frac.upload(frac_solid_prec, tl)) != RR_OK) return rc;
+    if (ice && (rc = d_fice.upload(frac_ice, (size_t)L * 8)) != RR_OK) return rc;
+    if ((rc = d_par.upload(params, (size_t)N * npar * 8)) != RR_OK) return rc;
+    if (qobs && (rc = d_qobs.upload(qobs, (size_t)T * 8)) != RR_OK) return rc;
+    const size_t wsb = rr_snowgr4j_workspace_bytes(T, L, N);
+    if ((rc = ws.alloc(wsb)) != RR_OK) return rc;
+    std::vector<OutSpec> outs = {{qsim, 1}, {G, L}, {eTG, L}, {s_store, 1},
+                                 {r_store, 1}, {sca, L}, {icemelt, 1},
+                                 {snowmelt, 1}};
+    return sweep_blocks(T, N, outs, sse,
+        [&](int64_t i0, int64_t nc, double **o, double *d_sse) {
+            const double *p = d_par.as<double>() + i0 * npar;
+            const double *qo = qobs ? d_qobs.as<double>() : nullptr;
+            double *so = qobs ? d_sse : nullptr;
+            if (hyst && ice)
+                return rr_cemaneigehystgr4jice_simulate_dev(
+                    d_prec.as<double>(), d_temp.as<double>(),
+                    d_etp.as<double>(), d_fice.as<double>(),
+                    d_frac.as<double>(), T, L, snow_pack_init,
+                    thermal_state_init, sca_init, s_init, r_init, p, nc, o[0],
+                    o[1], o[2], o[3], o[4], o[5], o[6], o[7], nc, qo, so, ws.p,
+                    wsb, nullptr);
+            if (hyst)
+                return rr_cemaneigehystgr4j_simulate_dev(
+                    d_prec.as<double>(), d_temp.as<double>(),
+                    d_etp.as<double>(), d_frac.as<double>(), T, L,
+                    snow_pack_init, thermal_state_init, sca_init, s_init,
+                    r_init, p, nc, o[0], o[1], o[2], o[3], o[4], o[5], nc, qo,
+                    so, ws.p, wsb, nullptr);
+            return rr_cemaneigegr4jice_simulate_dev(
+                d_prec.as<double>(), d_temp.as<double>(), d_etp.as<double>(),
+                d_fice.as<double>(), d_frac.as<double>(), T, L, snow_pack_init,
+                thermal_state_init, s_init, r_init, p, nc, o[0], o[1], o[2],
+                o[3], o[4], o[6], nc, qo, so, ws.p, wsb, nullptr);
+        });
+}
+
+}  // namespace
+
+extern "C" int rr_cemaneigehystgr4j_simulate(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_solid_prec, int64_t T, int64_t L,
+    double snow_pack_init, double thermal_state_init, double sca_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *sca, const double *qobs, double *sse)
+{
+    return snow_gr4j_host("rr_cemaneigehystgr4j_simulate", HYST, prec,
+                          mean_temp, etp, nullptr, frac_solid_prec, T, L,
+                          snow_pack_init, thermal_state_init, sca_init, s_init,
+                          r_init, params, N, qsim, G, eTG, s_store, r_store,
+                          sca, nullptr, nullptr, qobs, sse);
+}
+
+extern "C" int rr_cemaneigegr4jice_simulate(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *icemelt, const double *qobs, double *sse)
+{
+    return snow_gr4j_host("rr_cemaneigegr4jice_simulate", ICE, prec, mean_temp,
+                          etp, frac_ice, frac_solid_prec, T, L, snow_pack_init,
+                          thermal_state_init, 0.0, s_init, r_init, params, N,
+                          qsim, G, eTG, s_store, r_store, nullptr, icemelt,
+                          nullptr, qobs, sse);
+}
+
+extern "C" int rr_cemaneigehystgr4jice_simulate(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double sca_init, double s_init, double r_init, const double *params,
+    int64_t N, double *qsim, double *G, double *eTG, double *s_store,
+    double *r_store, double *sca, double *icemelt, double *snowmelt,
+    const double *qobs, double *sse)
+{
+    return snow_gr4j_host("rr_cemaneigehystgr4jice_simulate", HYST | ICE, prec,
+                          mean_temp, etp, frac_ice, frac_solid_prec, T, L,
+                          snow_pack_init, thermal_state_init, sca_init, s_init,
+                          r_init, params, N, qsim, G, eTG, s_store, r_store,
+                          sca, icemelt, snowmelt, qobs, sse);
+}

@@ -311,3 +311,59 @@ class HBVEduCatchments(_Ensemble):
             self._stream())
         _lib.check(rc, "rr_hbvedu_simulate_catchments_dev")
         return sse if qobs is not None else None
+
+
+class SnowGR4JEnsemble(_Ensemble):
+    """Next-tier couplings over N parameter sets, resident in HBM:
+    hyst=True, ice=False -> CemaneigeHystGR4J
+    hyst=False, ice=True -> CemaneigeGR4JIce
+    hyst=True, ice=True  -> CemaneigeHystGR4JIce
+    (rr_cemaneigehystgr4j_simulate_dev & co.)."""
+
+    def __init__(self, hyst, ice, layer_prec, layer_mean_temp, frac_solid_prec,
+                 etp, frac_ice=None, snow_pack_init=0., thermal_state_init=0.,
+                 sca_init=0., s_init=0., r_init=0., device="cuda:0"):
+        super().__init__(device)
+        if not (hyst or ice):
+            raise ValueError("use CemaneigeGR4JEnsemble for the plain model")
+        self.hyst, self.ice = bool(hyst), bool(ice)
+        self.NUM_PARAMS = 6 + (2 if hyst else 0) + (1 if ice else 0)
+        self.prec = _dev_tensor(layer_prec, self.device)
+        self.temp = _dev_tensor(layer_mean_temp, self.device)
+        self.frac = _dev_tensor(frac_solid_prec, self.device)
+        self.etp = _dev_tensor(etp, self.device)
+        self.frac_ice = (_dev_tensor(frac_ice, self.device) if ice else None)
+        self.inits = tuple(float(v) for v in (snow_pack_init,
+                                              thermal_state_init, sca_init,
+                                              s_init, r_init))
+        self.num_timesteps, self.num_layers = (int(x) for x in
+                                               self.prec.shape)
+
+    def run(self, params, qsim=None, qobs=None, sse=None):
+        """Discharge and/or fused per-set squared error (storages are served
+        by the model classes' host path)."""
+        n, sse = self._common(params, qobs, sse)
+        t, nl = self.num_timesteps, self.num_layers
+        wsb = self.lib.rr_snowgr4j_workspace_bytes(t, nl, n)
+        ws = self._workspace(wsb)
+        ld = qsim.stride(0) if qsim is not None else n
+        sse_p = _ptr(sse) if qobs is not None else None
+        i = self.inits
+        tail = (ld, _ptr(qobs), sse_p, _ptr(ws), wsb, self._stream())
+        if self.hyst and self.ice:
+            rc = self.lib.rr_cemaneigehystgr4jice_simulate_dev(
+                _ptr(self.prec), _ptr(self.temp), _ptr(self.etp),
+                _ptr(self.frac_ice), _ptr(self.frac), t, nl, *i, _ptr(params),
+                n, _ptr(qsim), *([None] * 7), *tail)
+        elif self.hyst:
+            rc = self.lib.rr_cemaneigehystgr4j_simulate_dev(
+                _ptr(self.prec), _ptr(self.temp), _ptr(self.etp),
+                _ptr(self.frac), t, nl, *i, _ptr(params), n, _ptr(qsim),
+                *([None] * 5), *tail)
+        else:
+            rc = self.lib.rr_cemaneigegr4jice_simulate_dev(
+                _ptr(self.prec), _ptr(self.temp), _ptr(self.etp),
+                _ptr(self.frac_ice), _ptr(self.frac), t, nl, i[0], i[1], i[3],
+                i[4], _ptr(params), n, _ptr(qsim), *([None] * 5), *tail)
+        _lib.check(rc, "rr_snowgr4j_simulate_dev")
+        return sse if qobs is not None else None

@@ -1,0 +1,165 @@
+"""Shared implementation of the three next-tier couplings: the SWE-SCA
+hysteresis snow routine and/or the degree-day ice melt in front of GR4J.
+
+The reference spells each model out in its own 450-700 line module
+(rrmpg/models/cemaneigehystgr4j.py, cemaneigegr4jice.py,
+cemaneigehystgr4jice.py); their simulate / fit / fit_Q_SCA bodies differ only
+in which optional pieces (hysteresis parameters, frac_ice, sca_init) exist.
+The public classes in those three modules here are thin and delegate to the
+functions below; every parameter set is simulated by ONE call into librrhip
+(rr_cemaneigehystgr4j_simulate & co.).
+"""
+
+import numbers
+
+import numpy as np
+
+from .. import _lib
+from ..utils.array_checks import validate_array_input
+from ..utils.metrics import calc_kge, calc_mse
+from .basemodel import new_outputs, out_ptr
+from .cemaneige import prepare_snow_inputs
+
+
+def prepare(hyst, ice, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
+            met_station_height, snow_pack_init, thermal_state_init, sca_init,
+            s_init, r_init, altitudes):
+    """Validation + forcing preprocessing; same checks, exceptions and order
+    as the reference wrappers (e.g. cemaneigehystgr4j.py:153-243).
+
+    Returns (layers, frac_ice or None, inits) with layers = (layer_prec,
+    layer_mean_temp, frac_solid_prec, etp) and inits = (snow_pack_init,
+    thermal_state_init, sca_init, s_init, r_init) as floats.
+    """
+    layers, snow_inits = prepare_snow_inputs(
+        prec, mean_temp, min_temp, max_temp, met_station_height,
+        snow_pack_init, thermal_state_init, altitudes, etp=etp)
+    if hyst and not isinstance(sca_init, numbers.Number):
+        raise TypeError("'sca_init' must be a Number.")
+    if not isinstance(s_init, numbers.Number):
+        raise TypeError("'s_init' must be a Number." if (hyst and ice)
+                        else "'s1_init' must be a Number.")
+    if not isinstance(r_init, numbers.Number):
+        raise TypeError("'r_init' must be a Number.")
+    if ice:
+        if isinstance(frac_ice, np.ndarray) and frac_ice.ndim != 1:
+            raise ValueError("frac_ice must be a 1D array.")
+        frac_ice = np.ascontiguousarray(np.asarray(frac_ice),
+                                        dtype=np.float64).ravel()
+        if frac_ice.shape[0] != layers[0].shape[1]:
+            raise ValueError("frac_ice must hold one value per elevation "
+                             "layer.")
+    else:
+        frac_ice = None
+    inits = snow_inits + (float(sca_init) if hyst else 0.0, float(s_init),
+                          float(r_init))
+    return layers, frac_ice, inits
+
+
+def rain_per_layer(layers, num_sets):
+    """The reference's `rain` output: prec - prec * frac_solid_prec per layer
+    (cemaneigehyst_model.py:89-90), identical for every parameter set."""
+    prec, _, frac, _ = layers
+    rain = prec - prec * frac
+    return np.repeat(rain[:, :, None], num_sets, axis=2)
+
+
+def run(hyst, ice, layers, frac_ice, inits, params, want_qsim, want_storages,
+        qobs):
+    """One batched GPU call.  Returns (dict of outputs, sse)."""
+    prec, mean_temp, frac, etp = layers
+    lib = _lib.load()
+    _lib.require_gpu()
+    k = 6 + (2 if hyst else 0) + (1 if ice else 0)
+    block, p_ptr, n = _lib.params_block(params, k)
+    t, nl = prec.shape
+    qsim, s_store, r_store, icemelt, snowmelt = new_outputs(
+        (t, n), (want_qsim, want_storages, want_storages,
+                 want_storages and ice, want_storages and hyst and ice))
+    G, eTG, sca = new_outputs((t, nl, n), (want_storages, want_storages,
+                                           want_storages and hyst))
+    qobs_arr, qobs_ptr = _lib.f64(qobs)
+    if qobs is not None and qobs_arr.shape[0] != t:
+        raise ValueError("Arrays must have the same size.")
+    sse = np.zeros(n) if qobs is not None else None
+    arrays = [prec, mean_temp, etp] + ([frac_ice] if ice else []) + [frac]
+    keep, ptrs = _lib.f64s(*arrays)
+    if hyst and ice:
+        rc = lib.rr_cemaneigehystgr4jice_simulate(
+            *ptrs, t, nl, *inits, p_ptr, n, out_ptr(qsim), out_ptr(G),
+            out_ptr(eTG), out_ptr(s_store), out_ptr(r_store), out_ptr(sca),
+            out_ptr(icemelt), out_ptr(snowmelt), qobs_ptr, out_ptr(sse))
+        what = "rr_cemaneigehystgr4jice_simulate"
+    elif hyst:
+        rc = lib.rr_cemaneigehystgr4j_simulate(
+            *ptrs, t, nl, *inits, p_ptr, n, out_ptr(qsim), out_ptr(G),
+            out_ptr(eTG), out_ptr(s_store), out_ptr(r_store), out_ptr(sca),
+            qobs_ptr, out_ptr(sse))
+        what = "rr_cemaneigehystgr4j_simulate"
+    else:
+        rc = lib.rr_cemaneigegr4jice_simulate(
+            *ptrs, t, nl, inits[0], inits[1], inits[3], inits[4], p_ptr, n,
+            out_ptr(qsim), out_ptr(G), out_ptr(eTG), out_ptr(s_store),
+            out_ptr(r_store), out_ptr(icemelt), qobs_ptr, out_ptr(sse))
+        what = "rr_cemaneigegr4jice_simulate"
+    del keep
+    _lib.check(rc, what)
+    out = dict(qsim=qsim, G=G, eTG=eTG, s_store=s_store, r_store=r_store,
+               sca=sca, icemelt=icemelt, snowmelt=snowmelt)
+    return out, sse
+
+
+def check_loss_metric(loss_metric):
+    if loss_metric not in ("mse", "kge"):
+        raise ValueError("Invalid loss_metric. Choose 'mse' or 'kge'.")
+
+
+def loss_q(cls, hyst, ice, kge_as_is, X, obs, layers, frac_ice, inits,
+           loss_metric):
+    """Loss of one candidate (or, X 2-D, of a whole population) on discharge.
+
+    mse: from the kernel's fused squared-error sum, no series leaves the GPU.
+    kge: needs the series; kge_as_is reproduces CemaneigeHystGR4J's loss,
+    which returns KGE itself rather than 1 - KGE (reference:
+    cemaneigehystgr4j.py:608-609); CemaneigeHystGR4JIce uses 1 - KGE
+    (cemaneigehystgr4jice.py:633-634).
+    """
+    check_loss_metric(loss_metric)
+    params = cls._params_from_population(X)
+    if loss_metric == "mse":
+        _, sse = run(hyst, ice, layers, frac_ice, inits, params, False, False,
+                     obs)
+        loss = sse / layers[0].shape[0]
+    else:
+        out, _ = run(hyst, ice, layers, frac_ice, inits, params, True, False,
+                     None)
+        kge = np.array([calc_kge(obs, out["qsim"][:, j])
+                        for j in range(params.size)])
+        loss = kge if kge_as_is else 1 - kge
+    return loss if np.ndim(X) == 2 else loss[0]
+
+
+def loss_q_sca(cls, ice, X, obs, layers, frac_ice, ndsi, inits, loss_metric):
+    """Multi-objective loss on discharge (75 %) and the snow-covered area of
+    the five elevation bands (5 % each, in percent against the NDSI series);
+    reference: cemaneigehystgr4j.py:615-691."""
+    check_loss_metric(loss_metric)
+    params = cls._params_from_population(X)
+    out, _ = run(True, ice, layers, frac_ice, inits, params, True, True, None)
+    losses = np.zeros(params.size)
+    for j in range(params.size):
+        outflow = out["qsim"][:, j]
+        scas = [out["sca"][:, b, j].flatten() * 100 for b in range(5)]
+        if loss_metric == "mse":
+            parts = [calc_mse(obs, outflow)] + [calc_mse(nd, sc) for nd, sc
+                                                in zip(ndsi, scas)]
+        else:
+            parts = [1 - calc_kge(obs, outflow)] + [1 - calc_kge(nd, sc)
+                                                    for nd, sc
+                                                    in zip(ndsi, scas)]
+        losses[j] = 0.75 * parts[0] + sum(0.05 * v for v in parts[1:])
+    return losses if np.ndim(X) == 2 else losses[0]
+
+
+def validated_obs(obs):
+    return validate_array_input(obs, np.float64, 'obs')

@@ -65,3 +65,63 @@ def nse_from_sse(sse, obs):
     """Per-set NSE from the kernels' fused squared-error sums."""
     obs = validate_array_input(obs, np.float64, 'obs')
     return 1 - np.asarray(sse, dtype=np.float64) / _nse_denominator(obs)
+
+
+# --- the remaining scores of the reference's metrics module (used by the
+# hysteresis models' loss_metric="kge"; reference: calc_kge :139-188,
+# calc_alpha_nse :191-232, calc_beta_nse :235-281, calc_r :284-299)
+def _std_obs(obs, msg):
+    std_obs = np.std(obs)
+    if std_obs == 0:
+        raise RuntimeError(msg)
+    return std_obs
+
+
+def calc_kge(obs, sim):
+    """Kling-Gupta-Efficiency (Gupta et al. 2009):
+    1 - sqrt((r-1)^2 + (alpha-1)^2 + (beta-1)^2).
+
+    Raises:
+        ValueError / TypeError: as calc_mse.
+        RuntimeError: if the mean or the standard deviation of the
+            observations equals 0.
+    """
+    from scipy.stats import pearsonr
+    obs, sim = _pair(obs, sim)
+    mean_obs = np.mean(obs)
+    if mean_obs == 0:
+        raise RuntimeError("KGE not definied if the mean of the observations "
+                           "equals 0.")
+    std_obs = _std_obs(obs, "KGE not definied if the standard deviation of "
+                            "the observations equals 0.")
+    r = pearsonr(obs, sim)[0]
+    alpha = np.std(sim) / std_obs
+    beta = np.mean(sim) / mean_obs
+    return 1 - np.sqrt((r - 1) ** 2 + (alpha - 1) ** 2 + (beta - 1) ** 2)
+
+
+def calc_alpha_nse(obs, sim):
+    """Alpha decomposition of the NSE: std(sim) / std(obs)."""
+    obs, sim = _pair(obs, sim)
+    return np.std(sim) / _std_obs(obs, "Not definied if the standard "
+                                       "deviation of the observations equals "
+                                       "0.")
+
+
+def calc_beta_nse(obs, sim):
+    """Beta decomposition of the NSE: (mean(sim) - mean(obs)) / std(obs)."""
+    obs, sim = _pair(obs, sim)
+    std_obs = _std_obs(obs, "Not definied if the standard deviation of the "
+                            "observations equals 0.")
+    mean_obs = np.mean(obs)
+    if mean_obs == 0:
+        raise RuntimeError("Not definied if the mean of the observations "
+                           "equals 0.")
+    return (np.mean(sim) - mean_obs) / std_obs
+
+
+def calc_r(obs, sim):
+    """Pearson r (scipy.stats.pearsonr result, as the reference returns it)."""
+    from scipy.stats import pearsonr
+    obs, sim = _pair(obs, sim)
+    return pearsonr(obs, sim)

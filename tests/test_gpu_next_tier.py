@@ -1,0 +1,225 @@
+"""GPU parity of the next-tier models (SWE-SCA hysteresis snow routine, ice
+melt, couplings with GR4J) against the reference's Excel known answers
+(reference: test/test_models.py:293-310, 336-356), the golden fixtures and
+the oracle.  Snow states (G, eTG, sca, ice melt, snow melt) involve no
+transcendental and are asserted bit-exact; discharge and the GR4J stores at
+1e-10 relative."""
+
+import numpy as np
+import pytest
+
+from .conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+ALTS = [550, 620, 700, 785, 920]
+
+
+@pytest.fixture(scope="module")
+def models():
+    from rrmpg_amd import _lib
+    _lib.load()
+    _lib.require_gpu()
+    import rrmpg_amd.models as m
+    return m
+
+
+def _records(cls, flat):
+    p = np.zeros(flat.shape[0], dtype=cls._dtype)
+    for k, name in enumerate(cls._param_list):
+        p[name] = flat[:, k]
+    return p
+
+
+def test_hyst_kat_excel(models):
+    g = golden("kat_cemaneigehystgr4j")
+    cls = models.CemaneigeHystGR4J
+    m = cls(params=dict(zip(cls._param_list, g["params"].tolist())))
+    qsim = m.simulate(g["prec"], g["mean_temp"], g["min_temp"], g["max_temp"],
+                      g["etp"], met_station_height=700, altitudes=ALTS,
+                      s_init=0.5, r_init=0.4)
+    assert np.allclose(qsim.flatten(), g["qsim_excel"])  # the reference's test
+    out = m.simulate(g["prec"], g["mean_temp"], g["min_temp"], g["max_temp"],
+                     g["etp"], met_station_height=700, altitudes=ALTS,
+                     s_init=0.5, r_init=0.4, return_storages=True)
+    names = ["qsim", "G", "eTG", "s_store", "r_store", "sca", "rain"]
+    for a, n in zip(out, names):
+        assert rel_err(a, g["ref_" + n], floor=1e-6) < RTOL, n
+    assert np.array_equal(out[6], g["ref_rain"])
+
+
+def test_hystice_kat_excel(models):
+    g = golden("kat_cemaneigehystgr4jice")
+    cls = models.CemaneigeHystGR4JIce
+    m = cls(params=dict(zip(cls._param_list, g["params"].tolist())))
+    qsim = m.simulate(g["prec"], g["mean_temp"], g["min_temp"], g["max_temp"],
+                      g["etp"], g["frac_ice"], met_station_height=700,
+                      altitudes=ALTS, s_init=0.5, r_init=0.4, sca_init=0.2)
+    assert np.allclose(qsim.flatten(), g["qsim_excel"])  # the reference's test
+    out = m.simulate(g["prec"], g["mean_temp"], g["min_temp"], g["max_temp"],
+                     g["etp"], g["frac_ice"], met_station_height=700,
+                     altitudes=ALTS, s_init=0.5, r_init=0.4, sca_init=0.2,
+                     return_storages=True)
+    names = ["qsim", "G", "eTG", "s_store", "r_store", "sca", "icemelt",
+             "snowmelt", "rain"]
+    for a, n in zip(out, names):
+        assert rel_err(a, g["ref_" + n], floor=1e-6) < RTOL, n
+
+
+def _device_run(models, hyst, ice, g, forcing, frac_ice):
+    """Through the host C-ABI with the [T, L] arrays of the fixture."""
+    from rrmpg_amd.models import _snowgr4j as core
+    cls = {(True, False): models.CemaneigeHystGR4J,
+           (False, True): models.CemaneigeGR4JIce,
+           (True, True): models.CemaneigeHystGR4JIce}[(hyst, ice)]
+    layers = (forcing["layer_prec"], forcing["layer_mean"],
+              forcing["frac_solid"], forcing["etp"])
+    out, _ = core.run(hyst, ice, layers, frac_ice, tuple(g["inits"]),
+                      _records(cls, g["params"]), True, True, None)
+    out["rain"] = core.rain_per_layer(layers, g["params"].shape[0])
+    return out, cls, layers
+
+
+def _check(out, g, ref, keys, exact):
+    idx = g["stride_idx"]
+    for k in keys:
+        a = out[k]
+        if a.ndim == 3:
+            assert rel_err(a[idx], g[k], floor=1e-6) < RTOL, k
+            assert rel_err(a[-1], g[k + "_last"], floor=1e-6) < RTOL, k
+        else:
+            assert rel_err(a, g[k], floor=1e-6) < RTOL, k
+        if k in exact:
+            assert np.array_equal(a, ref[k]), k     # vs the oracle, bit for bit
+        else:
+            assert rel_err(a, ref[k], floor=1e-9) < RTOL, k
+
+
+def test_next_tier_golden_and_oracle(models, oracle):
+    h = golden("syn_cemaneigehystgr4j")
+    forcing = (h["layer_prec"], h["layer_mean"], h["etp"], h["frac_solid"])
+    snow_exact = {"G", "eTG", "sca", "icemelt", "snowmelt", "rain"}
+
+    out, _, _ = _device_run(models, True, False, h, h, None)
+    ref = oracle.simulate_snow_gr4j(True, False, *forcing, h["inits"],
+                                    h["params"], return_storages=True)
+    _check(out, h, ref, ["qsim", "G", "eTG", "s_store", "r_store", "sca",
+                         "rain"], snow_exact)
+
+    g = golden("syn_cemaneigegr4jice")
+    out, _, _ = _device_run(models, False, True, g, h, g["frac_ice"])
+    ref = oracle.simulate_snow_gr4j(False, True, *forcing, g["inits"],
+                                    g["params"], frac_ice=g["frac_ice"],
+                                    return_storages=True)
+    _check(out, g, ref, ["qsim", "G", "eTG", "s_store", "r_store", "icemelt"],
+           snow_exact)
+
+    g = golden("syn_cemaneigehystgr4jice")
+    out, _, _ = _device_run(models, True, True, g, h, g["frac_ice"])
+    ref = oracle.simulate_snow_gr4j(True, True, *forcing, g["inits"],
+                                    g["params"], frac_ice=g["frac_ice"],
+                                    return_storages=True)
+    _check(out, g, ref, ["qsim", "G", "eTG", "s_store", "r_store", "sca",
+                         "icemelt", "snowmelt", "rain"], snow_exact)
+
+
+def test_next_tier_random_sweeps_and_scores(models, oracle):
+    from rrmpg_amd.models import _snowgr4j as core
+    from rrmpg_amd.utils.metrics import calc_mse
+    h = golden("syn_cemaneigehystgr4j")
+    t = 1500
+    layers = tuple(h[k][:t] for k in ("layer_prec", "layer_mean",
+                                      "frac_solid", "etp"))
+    forcing = (layers[0], layers[1], layers[3], layers[2])
+    fice = np.array([0.0, 0.1, 0.3, 0.6, 0.9])
+    for (hyst, ice), cls in [((True, False), models.CemaneigeHystGR4J),
+                             ((False, True), models.CemaneigeGR4JIce),
+                             ((True, True), models.CemaneigeHystGR4JIce)]:
+        np.random.seed(11)
+        p = cls().get_random_params(193)          # x4 up to 10 -> LDS UH tier
+        flat = np.stack([p[k] for k in cls._param_list], 1)
+        inits = (3.0, -0.2, 0.4, 0.5, 0.6)
+        ref = oracle.simulate_snow_gr4j(hyst, ice, *forcing, inits, flat,
+                                        frac_ice=fice if ice else None,
+                                        return_storages=True, nthreads=8)
+        out, _ = core.run(hyst, ice, layers, fice if ice else None, inits, p,
+                          True, True, None)
+        for k, a in out.items():
+            if a is None:
+                continue
+            if k in ("G", "eTG", "sca", "icemelt", "snowmelt"):
+                assert np.array_equal(a, ref[k]), (hyst, ice, k)
+            else:
+                assert rel_err(a, ref[k], floor=1e-9) < RTOL, (hyst, ice, k)
+        # fused score == MSE of the series; score-only == with series
+        qobs = ref["qsim"][:, 0] * 1.05
+        _, sse = core.run(hyst, ice, layers, fice if ice else None, inits, p,
+                          False, False, qobs)
+        for j in (0, 7, 192):
+            want = calc_mse(qobs, out["qsim"][:, j])
+            assert abs(sse[j] / t - want) <= 1e-10 * max(want, 1e-12)
+
+
+def test_next_tier_validation_and_limits(models):
+    m = models.CemaneigeHystGR4JIce()
+    s = [1., 2., 3.]
+    with pytest.raises(TypeError, match="'sca_init' must be a Number"):
+        m.simulate(s, s, s, s, s, [0.1], 500, sca_init="x")
+    with pytest.raises(TypeError, match="'s_init' must be a Number"):
+        m.simulate(s, s, s, s, s, [0.1], 500, s_init="x")
+    with pytest.raises(ValueError, match="frac_ice must be a 1D array"):
+        m.simulate(s, s, s, s, s, np.ones((2, 2)), 500)
+    with pytest.raises(TypeError, match="'s1_init' must be a Number"):
+        models.CemaneigeHystGR4J().simulate(s, s, s, s, s, 500, s_init="x")
+    with pytest.raises(ValueError, match="Invalid loss_metric"):
+        models.CemaneigeHystGR4J().fit(s, s, s, s, s, s, 500,
+                                       loss_metric="nse")
+    # more than 8 layers: loud error for these models
+    alts = list(np.linspace(500, 3000, 9))
+    with pytest.raises(RuntimeError, match="RR_E_PARAM"):
+        models.CemaneigeHystGR4J().simulate(s, s, s, s, s, 500,
+                                            altitudes=alts)
+
+
+def test_next_tier_fit_losses(models):
+    """_loss / _loss_Q_SCA follow the reference's definitions, including
+    CemaneigeHystGR4J's KGE loss that is KGE itself (quirk Q8)."""
+    from rrmpg_amd.models import cemaneigehystgr4j as hmod
+    from rrmpg_amd.models import cemaneigehystgr4jice as himod
+    from rrmpg_amd.models import _snowgr4j as core
+    from rrmpg_amd.utils.metrics import calc_kge, calc_mse
+    h = golden("syn_cemaneigehystgr4j")
+    t = 800
+    layers = tuple(h[k][:t] for k in ("layer_prec", "layer_mean",
+                                      "frac_solid", "etp"))
+    inits = tuple(h["inits"])
+    X = h["params"][2]
+    p = _records(models.CemaneigeHystGR4J, X[None, :])
+    out, _ = core.run(True, False, layers, None, inits, p, True, True, None)
+    q = out["qsim"][:, 0]
+    obs = q * 1.1 + 0.01
+    assert abs(hmod._loss(X, obs, layers, inits, "mse")
+               - calc_mse(obs, q)) < 1e-12
+    assert abs(hmod._loss(X, obs, layers, inits, "kge")
+               - calc_kge(obs, q)) < 1e-12                      # KGE itself
+    ndsi = tuple(np.clip(out["sca"][:, b, 0] * 100 + 3, 0, 100)
+                 for b in range(5))
+    want = 0.75 * calc_mse(obs, q) + sum(
+        0.05 * calc_mse(ndsi[b], out["sca"][:, b, 0] * 100) for b in range(5))
+    got = hmod._loss_Q_SCA(X, obs, layers, ndsi, inits, "mse")
+    assert abs(got - want) <= 1e-10 * want
+    # population form
+    pop = hmod._loss(np.stack([X, h["params"][3]], 1), obs, layers, inits,
+                     "mse")
+    assert pop.shape == (2,) and pop[0] == hmod._loss(X, obs, layers, inits,
+                                                      "mse")
+    # ice variant: 1 - KGE
+    g = golden("syn_cemaneigehystgr4jice")
+    Xi = g["params"][1]
+    pi = _records(models.CemaneigeHystGR4JIce, Xi[None, :])
+    oi, _ = core.run(True, True, layers, g["frac_ice"], inits, pi, True,
+                     False, None)
+    qi = oi["qsim"][:, 0]
+    li = himod._loss(Xi, obs, layers, g["frac_ice"], inits, "kge")
+    assert abs(li - (1 - calc_kge(obs, qi))) < 1e-12

@@ -19,13 +19,15 @@ from .conftest import REPO, golden
 
 from rrmpg_amd import _lib
 from rrmpg_amd.models import (ABCModel, HBVEdu, GR4J, Cemaneige,
-                              CemaneigeGR4J)
+                              CemaneigeGR4J, CemaneigeHystGR4J,
+                              CemaneigeGR4JIce, CemaneigeHystGR4JIce)
 from rrmpg_amd.models import cemaneige_utils as cu
 from rrmpg_amd.models.basemodel import BaseModel
 from rrmpg_amd.tools import monte_carlo
 from rrmpg_amd.utils.array_checks import (check_for_negatives,
                                           validate_array_input)
-from rrmpg_amd.utils.metrics import (calc_mse, calc_nse, calc_rmse,
+from rrmpg_amd.utils.metrics import (calc_alpha_nse, calc_beta_nse, calc_kge,
+                                     calc_mse, calc_nse, calc_r, calc_rmse,
                                      mse_from_sse, nse_from_sse)
 
 NO_GPU = _lib.device_count() == 0
@@ -159,6 +161,35 @@ def test_sampling_reproduces_the_reference_stream():
         assert np.array_equal(ctor, g[name + "_ctor"]), name
         flat = np.stack([pp[k] for k in mdl.get_parameter_names()], 1)
         assert np.array_equal(flat, g[name + "_rand7"]), name
+
+
+def test_next_tier_classes_sampling_and_metrics():
+    g = golden("sampling_next")
+    for name, cls, k in [("cemaneigehystgr4j", CemaneigeHystGR4J, 8),
+                         ("cemaneigegr4jice", CemaneigeGR4JIce, 7),
+                         ("cemaneigehystgr4jice", CemaneigeHystGR4JIce, 9)]:
+        assert issubclass(cls, BaseModel) and cls._dtype.itemsize == 8 * k
+        np.random.seed(1234)
+        mdl = cls()
+        pp = mdl.get_random_params(7)
+        ctor = np.array([mdl.get_params()[n] for n in cls._param_list])
+        assert np.array_equal(ctor, g[name + "_ctor"]), name
+        flat = np.stack([pp[n] for n in cls._param_list], 1)
+        assert np.array_equal(flat, g[name + "_rand7"]), name
+    # KGE and the NSE decompositions (scores of a perfect / shifted series)
+    obs = np.array([1., 2., 4., 3., 5.])
+    assert calc_kge(obs, obs) == pytest.approx(1.0)
+    assert calc_alpha_nse(obs, obs) == pytest.approx(1.0)
+    assert calc_beta_nse(obs, obs + 1) == pytest.approx(1 / np.std(obs))
+    assert calc_r(obs, 2 * obs)[0] == pytest.approx(1.0)
+    r = np.corrcoef(obs, obs ** 2)[0, 1]
+    want = 1 - np.sqrt((r - 1) ** 2 + (np.std(obs ** 2) / np.std(obs) - 1) ** 2
+                       + (np.mean(obs ** 2) / np.mean(obs) - 1) ** 2)
+    assert calc_kge(obs, obs ** 2) == pytest.approx(want)
+    with pytest.raises(RuntimeError, match="mean of the observations"):
+        calc_kge([-1., 1.], [1., 2.])
+    with pytest.raises(RuntimeError, match="standard deviation"):
+        calc_kge([2., 2.], [1., 2.])
 
 
 # ---------------------------------------------- input validation & errors
