@@ -104,10 +104,13 @@ extern "C" size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N)
     return 256 + rr_align256((size_t)T * sizeof(GrDay));
 }
 
-// Shared by gr4j.hip and cemaneige.hip: scans x4, returns the LDS capacities
-// (n1cap == 0 selects the register tier).  Synchronises the stream once.
+// Shared by gr4j.hip, cemaneige.hip and snownext.hip: scans x4 and picks the
+// unit-hydrograph storage tier (3, 5, 10 = register tiers for max ceil(x4)
+// up to that; 0 = LDS tier with the returned capacities).  Synchronises the
+// stream once.
 int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
-                 int *d_scan, hipStream_t st, int *n1cap, int *n2cap)
+                 int *d_scan, hipStream_t st, int *tier, int *n1cap,
+                 int *n2cap)
 {
     RR_HIP(hipMemsetAsync(d_scan, 0, 2 * sizeof(int), st));
     int blocks = (int)rr_ceil_div(N, 256);
@@ -129,15 +132,12 @@ int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
         return RR_E_PARAM;
     }
     // RRHIP_GR4J_FORCE_LDS=1 (measurement hook): use the LDS tier even when
-    // every x4 <= 3 would allow the register tier
+    // a register tier would do
     const char *force = getenv("RRHIP_GR4J_FORCE_LDS");
-    if (h[0] <= 3 && !(force && force[0] == '1')) {
-        *n1cap = 0;
-        *n2cap = 0;
-    } else {
-        *n1cap = h[0];
-        *n2cap = 2 * h[0] + 1;
-    }
+    const bool lds = (force && force[0] == '1') || h[0] > 10;
+    *tier = lds ? 0 : (h[0] <= 3 ? 3 : (h[0] <= 5 ? 5 : 10));
+    *n1cap = lds ? h[0] : 0;
+    *n2cap = lds ? 2 * h[0] + 1 : 0;
     return RR_OK;
 }
 
@@ -169,8 +169,8 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     hipStream_t st = (hipStream_t)stream;
     int *d_scan = (int *)workspace;
     GrDay *days = (GrDay *)((char *)workspace + 256);
-    int n1cap = 0, n2cap = 0;
-    rc = rr_gr4j_plan(params, N, 4, 3, d_scan, st, &n1cap, &n2cap);
+    int tier = 3, n1cap = 0, n2cap = 0;
+    rc = rr_gr4j_plan(params, N, 4, 3, d_scan, st, &tier, &n1cap, &n2cap);
     if (rc != RR_OK) return rc;
     hipLaunchKernelGGL(gr4j_pack_forcing, dim3((unsigned)rr_ceil_div(T, 256)),
                        dim3(256), 0, st, prec, etp, T, days);
@@ -179,17 +179,13 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     const size_t lds_bytes =
         (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
     rr_dispatch3(q, s, e, [&](auto Q, auto S, auto E) {
-        if (n1cap == 0)
-            gr4j_kernel<UhRegs<3>, Q.value, S.value, E.value>
-                <<<grid, block, 0, st>>>(days, T, s_init, r_init, params, N, 0,
-                                         0, qsim, s_store, r_store, ld, qobs,
-                                         sse);
-        else
-            gr4j_kernel<UhLds, Q.value, S.value, E.value>
-                <<<grid, block, lds_bytes, st>>>(days, T, s_init, r_init,
-                                                 params, N, n1cap, n2cap, qsim,
-                                                 s_store, r_store, ld, qobs,
-                                                 sse);
+        gr4j_dispatch_uh(tier, [&](auto uh) {
+            using UH = decltype(uh);
+            gr4j_kernel<UH, Q.value, S.value, E.value>
+                <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
+                   st>>>(days, T, s_init, r_init, params, N, n1cap, n2cap,
+                         qsim, s_store, r_store, ld, qobs, sse);
+        });
     });
     RR_HIP(hipGetLastError());
     return RR_OK;

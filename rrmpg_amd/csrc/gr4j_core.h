@@ -8,9 +8,10 @@
 // ceil(2*x4+1) ordinates, gr4j_model.py:68-69), handled by two storage tiers
 // with identical arithmetic:
 //
-//   UhRegs<3>  x4 <= 3 for every set of the launch (the reference's default
-//              bounds, rrmpg/models/gr4j.py:51-54): 3 + 7 ordinates and
-//              3 + 7 convolution slots in registers, loops fully unrolled.
+//   UhRegs<M>  x4 <= M for every set of the launch, M = 3 (the reference's
+//              default GR4J bounds, rrmpg/models/gr4j.py:51-54), 5 or 10 (the
+//              hysteresis models' bounds): M + (2M+1) ordinates and as many
+//              convolution slots in registers, loops fully unrolled.
 //   UhLds      any x4 <= RR_GR4J_MAX_X4: ordinates and slots are staged in
 //              LDS as [slot][lane] (8-byte elements, lane-contiguous ->
 //              ds_read_b64 / ds_write_b64 are bank-conflict free) and the
@@ -86,12 +87,13 @@ struct UhRegs {
         n2 = gr4j_num_uh2(x4);
         // ordinate j = S(j+1) - S(j) (gr4j_model.py:75-79); S(j) is carried
         // over from the previous ordinate instead of being re-evaluated.
-        // Ordinates j >= n are never used.
+        // Invariant kept for the whole run: ordinates and slots at j >= n
+        // are exactly 0 (route() relies on it).
         double prev = 0.0;
 #pragma unroll
         for (int j = 0; j < N1MAX; ++j) {
             const double cur = gr4j_s_curve1(j + 1, x4);
-            o1[j] = cur - prev;
+            o1[j] = (j < n1) ? cur - prev : 0.0;
             prev = cur;
             u1[j] = 0.0;
         }
@@ -99,29 +101,42 @@ struct UhRegs {
 #pragma unroll
         for (int j = 0; j < N2MAX; ++j) {
             const double cur = gr4j_s_curve2(j + 1, x4);
-            o2[j] = cur - prev;
+            o2[j] = (j < n2) ? cur - prev : 0.0;
             prev = cur;
             u2[j] = 0.0;
         }
     }
 
-    // shift-and-add both hydrographs; returns uh1[0], uh2[0]
+    // shift-and-add both hydrographs; returns uh1[0], uh2[0].
+    //
+    // Reference (gr4j_model.py:130-136), a lane with n ordinates:
+    //     uh[j] = uh[j+1] + ord[j]*p  (j < n-1),   uh[n-1] = ord[n-1]*p.
+    // With the zero invariant above, the single formula
+    //     uh[j] = uh[j+1] + ord[j]*p   for every j < MAX  (uh[MAX] := 0)
+    // gives the same values: slot n-1 becomes 0 + ord*p and, for finite p,
+    // the padding stays 0 + 0*p = 0 (only the sign of an exact zero can
+    // differ).  That is 2 instructions per slot instead of 5 (no per-lane
+    // selects).  A non-finite p (never in a sane run) leaves the real slots
+    // right as well -- they only read padding that was still zero -- but
+    // writes 0*NaN into the padding, so on such days the wave re-zeroes it.
     __device__ __forceinline__ void route(double p1, double p2, double &head1,
                                           double &head2)
     {
 #pragma unroll
-        for (int j = 0; j < N1MAX; ++j) {
-            const double v = o1[j] * p1;
-            const double nxt = (j + 1 < N1MAX) ? u1[(j + 1 < N1MAX) ? j + 1 : j]
-                                               : 0.0;
-            u1[j] = (j + 1 < n1) ? nxt + v : v;
-        }
+        for (int j = 0; j < N1MAX; ++j)
+            u1[j] = ((j + 1 < N1MAX) ? u1[(j + 1 < N1MAX) ? j + 1 : j] : 0.0) +
+                    o1[j] * p1;
 #pragma unroll
-        for (int j = 0; j < N2MAX; ++j) {
-            const double v = o2[j] * p2;
-            const double nxt = (j + 1 < N2MAX) ? u2[(j + 1 < N2MAX) ? j + 1 : j]
-                                               : 0.0;
-            u2[j] = (j + 1 < n2) ? nxt + v : v;
+        for (int j = 0; j < N2MAX; ++j)
+            u2[j] = ((j + 1 < N2MAX) ? u2[(j + 1 < N2MAX) ? j + 1 : j] : 0.0) +
+                    o2[j] * p2;
+        const bool finite = (__builtin_fabs(p1) < __builtin_inf()) &&
+                            (__builtin_fabs(p2) < __builtin_inf());
+        if (!__all(finite)) {
+#pragma unroll
+            for (int j = 0; j < N1MAX; ++j) u1[j] = (j < n1) ? u1[j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < N2MAX; ++j) u2[j] = (j < n2) ? u2[j] : 0.0;
         }
         head1 = u1[0];
         head2 = u2[0];
@@ -209,6 +224,19 @@ struct UhLds {
         }
     }
 };
+
+// Calls f(UH{}) with the storage tier picked by rr_gr4j_plan:
+// tier 3 / 5 / 10 -> UhRegs<3> / <5> / <10>, 0 -> UhLds.
+template <class F>
+static inline void gr4j_dispatch_uh(int tier, F &&f)
+{
+    switch (tier) {
+    case 3: f(UhRegs<3>{}); break;
+    case 5: f(UhRegs<5>{}); break;
+    case 10: f(UhRegs<10>{}); break;
+    default: f(UhLds{}); break;
+    }
+}
 
 // The transcendental calls of the daily step (reference: 1 tanh + 3 pow) are
 // evaluated with fastmath.h instead of OCML's general tanh / pow (165 / 224

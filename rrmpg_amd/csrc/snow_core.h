@@ -1,0 +1,96 @@
+// snow_core.h -- pieces shared by cemaneige.hip (Cemaneige, CemaneigeGR4J) and
+// snownext.hip (hysteresis / ice-melt couplings): the per-day Cemaneige step,
+// the layer-count dispatch, workspace sizing and the forcing pre-pass.
+#pragma once
+
+#include "gr4j_core.h"
+
+// defined in gr4j.hip: scans x4 and picks the unit-hydrograph tier
+int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
+                 int *d_scan, hipStream_t st, int *tier, int *n1cap,
+                 int *n2cap);
+
+// defined in cemaneige.hip: packs the per-day records {snow[L], rain[L],
+// temp[L] (, etp)} and the per-layer G_tresh[L] / Psolannual[L] into the
+// workspace (layout below); returns device pointers into it
+int rr_cema_prepass(const double *prec, const double *mean_temp,
+                    const double *frac, const double *etp, int64_t T, int L,
+                    void *workspace, hipStream_t st, double **days_out,
+                    double **gt_out, double **state_out);
+
+static inline size_t cema_days_bytes(int64_t T, int64_t L, bool with_etp)
+{
+    if (T < 1) T = 1;
+    if (L < 1) L = 1;
+    return rr_align256((size_t)T * (size_t)(3 * L + (with_etp ? 1 : 0)) * 8);
+}
+
+// + the [2][L][N] snow-state scratch when the layers do not fit in registers
+static inline size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp, int64_t N)
+{
+    size_t b = 512 + rr_align256((size_t)(L > 0 ? L : 1) * 16) +
+               cema_days_bytes(T, L, with_etp);
+    if (L > RR_CEMANEIGE_MAX_LAYERS && N > 0)
+        b += rr_align256((size_t)2 * (size_t)L * (size_t)N * 8);
+    return b;
+}
+
+
+// One day of the snow routine for all L layers of one parameter set
+// (cemaneige_model.py:83-125).  Returns the layer-mean liquid outflow.
+template <int L>
+__device__ __forceinline__ double cema_day(
+    const double *__restrict__ day, const InvDivisor (&inv_gt)[L],
+    bool first, double snow_pack_init, double thermal_state_init, double CTG,
+    double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L])
+{
+    double c = 0.0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const double snow = day[l], rain = day[L + l], temp = day[2 * L + l];
+        double g, e;
+        if (first) {                                       // :85-96
+            g = snow_pack_init;
+            e = thermal_state_init;
+        } else {
+            g = G[l] + snow;
+            e = CTG * eTG[l] + one_minus_CTG * temp;
+        }
+        if (e > 0) e = 0.0;
+        double pot_melt = 0.0;                             // :99-106
+        if (e == 0 && temp > 0) {
+            pot_melt = Kf * temp;
+            if (pot_melt > g) pot_melt = g;
+        }
+        // G / G_tresh: the threshold is fixed for the whole run, so the
+        // quotient is the 3-instruction correctly rounded form of common.h
+        const double gt = inv_gt[l].b;
+        const double ratio =                               // :109-112
+            (g < gt) ? div_by_invariant(g, inv_div_numerator_ok(g), inv_gt[l])
+                     : 1.0;
+        const double melt = (0.9 * ratio + 0.1) * pot_melt; // :115
+        g = g - melt;                                      // :118
+        G[l] = g;
+        eTG[l] = e;
+        c += rain + melt;                                  // :121, :125
+    }
+    return c / (double)L;
+}
+
+
+// calls f(std::integral_constant<int, L>) for the runtime L in 1..8
+template <class F>
+static inline void dispatch_layers(int L, F &&f)
+{
+    switch (L) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 5: f(std::integral_constant<int, 5>{}); break;
+    case 6: f(std::integral_constant<int, 6>{}); break;
+    case 7: f(std::integral_constant<int, 7>{}); break;
+    default: f(std::integral_constant<int, 8>{}); break;
+    }
+}
+

@@ -1,0 +1,296 @@
+// snownext.hip -- next-tier ensemble kernels for gfx950: the SWE-SCA
+// hysteresis snow routine, the degree-day ice melt, and their couplings with
+// GR4J (the reference's CemaneigeHystGR4J, CemaneigeGR4JIce,
+// CemaneigeHystGR4JIce).  One fused kernel template, one lane per parameter
+// set, all snow states in registers; see snow_core.h / gr4j_core.h.
+#include "snow_core.h"
+
+// ===========================================================================
+// Next tier: SWE-SCA hysteresis snow routine, ice
+// melt, and their couplings with GR4J -- the reference's CemaneigeHystGR4J,
+// CemaneigeGR4JIce and CemaneigeHystGR4JIce.
+// ===========================================================================
+
+// One day of the hysteresis snow routine for all L layers of one parameter
+// set (reference: rrmpg/models/cemaneigehyst_model.py:95-162).  Four states
+// per layer: snow pack G, thermal state eTG, snow-covered area sca and the
+// maximum SWE before melt.  Returns the layer-mean liquid outflow.
+// sca_prev0: what the reference reads as sca[t-1] at t = 0 -- row -1, i.e. 0
+// (or sca_init when T == 1); sca_init itself never survives (quirk Q8).
+template <int L>
+__device__ __forceinline__ double cema_hyst_day(
+    const double *__restrict__ day, const double *__restrict__ psol,
+    bool first, double snow_pack_init, double thermal_state_init,
+    double sca_prev0, double CTG, double one_minus_CTG, double Kf,
+    const InvDivisor &inv_Thacc, double Rsp, double (&G)[L], double (&eTG)[L],
+    double (&sca)[L], double (&swe_max)[L])
+{
+    double c = 0.0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const double snow = day[l], rain = day[L + l], temp = day[2 * L + l];
+        double g, e;
+        if (first) {                                       // :98-110
+            g = snow_pack_init;
+            e = thermal_state_init;
+        } else {
+            g = G[l] + snow;
+            e = CTG * eTG[l] + one_minus_CTG * temp;
+        }
+        if (e > 0) e = 0.0;
+        double pot_melt = 0.0;                             // :113-120
+        if (e == 0 && temp > 0) {
+            pot_melt = Kf * temp;
+            if (pot_melt > g) pot_melt = g;
+        }
+        const double snow_balance = snow - pot_melt;       // :123
+        double sc;
+        if (snow_balance >= 0) {                           // :126-129
+            const double prev = first ? sca_prev0 : sca[l];
+            sc = prev + div_by_invariant(
+                            snow_balance, inv_div_numerator_ok(snow_balance),
+                            inv_Thacc);
+            swe_max[l] = nb_max(swe_max[l], g);
+        } else {                                           // :130-142
+            const double Thmelt = psol[l] * Rsp;
+            const double Thmax = (swe_max[l] > Thmelt) ? Thmelt : swe_max[l];
+            sc = (Thmax > 0) ? g / Thmax : 0.0;
+        }
+        sc = nb_min(nb_max(sc, 0.0), 1.0);                 // :145
+        double melt = (0.9 * sc + 0.1) * pot_melt;         // :148
+        melt = nb_min(melt, g);                            // :151
+        g = g - melt;                                      // :154
+        if (g == 0) swe_max[l] = 0.0;                      // :157-158
+        G[l] = g;
+        eTG[l] = e;
+        sca[l] = sc;
+        c += rain + melt;                                  // :162, :166
+    }
+    return c / (double)L;
+}
+
+// Where the optional parameters sit in a record of `npar` doubles:
+// {CTG, Kf, [Thacc, Rsp,] x1, x2, x3, x4 [, DDF]}.
+struct SnowParLayout {
+    int npar, i_x1, i_ddf;
+};
+
+// min. 2 waves per SIMD: caps the allocation at 256 registers (the x4 <= 10
+// register tier of the hysteresis + ice variant would otherwise take a few
+// AGPRs more and drop to one wave per SIMD)
+template <int L, class UH, bool HYST, bool ICE>
+__global__ __launch_bounds__(RR_BLOCK, 2) void snow_gr4j_kernel(
+    const double *__restrict__ days, const double *__restrict__ gtresh,
+    const double *__restrict__ frac_ice, int64_t T, double snow_pack_init,
+    double thermal_state_init, double sca_init, double s_init, double r_init,
+    const double *__restrict__ params, SnowParLayout lay, int64_t N,
+    int n1cap, int n2cap, double *__restrict__ qsim,
+    double *__restrict__ G_out, double *__restrict__ eTG_out,
+    double *__restrict__ s_store, double *__restrict__ r_store,
+    double *__restrict__ sca_out, double *__restrict__ icemelt_out,
+    double *__restrict__ snowmelt_out, int64_t ld,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = i < N;
+    const double *p = params + (active ? i : N - 1) * lay.npar;
+    const double CTG = p[0], Kf = p[1];
+    const double Rsp = HYST ? p[3] : 0.0;
+    const InvDivisor inv_Thacc = make_inv_divisor(HYST ? p[2] : 1.0);
+    const double ddf = ICE ? p[lay.i_ddf] : 0.0;
+    Gr4jPar P;
+    P.set(p[lay.i_x1], p[lay.i_x1 + 1], p[lay.i_x1 + 2], p[lay.i_x1 + 3]);
+    const double omc = 1 - CTG;
+    double G[L], eTG[L], sca[L], swe_max[L];
+    InvDivisor inv_gt[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        G[l] = 0.0; eTG[l] = 0.0; sca[l] = 0.0; swe_max[l] = 0.0;
+        inv_gt[l] = make_inv_divisor(gtresh[l]);
+    }
+    const double *psol = gtresh + L;
+    const double sca_prev0 = (T == 1) ? sca_init : 0.0;
+    UH uh;
+    if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
+    else uh.init(P.x4);
+    double s = s_init * P.x1, r = r_init * P.x3;
+    double acc = 0.0;
+    const bool wq = qsim != nullptr, ws = G_out != nullptr, we = sse != nullptr;
+    constexpr int D = 3 * L + 1;
+    for (int64_t t = 0; t < T; ++t) {
+        const double *day = days + t * D;
+        double snowmelt;
+        if constexpr (HYST)
+            snowmelt = cema_hyst_day<L>(day, psol, t == 0, snow_pack_init,
+                                        thermal_state_init, sca_prev0, CTG,
+                                        omc, Kf, inv_Thacc, Rsp, G, eTG, sca,
+                                        swe_max);
+        else
+            snowmelt = cema_day<L>(day, inv_gt, t == 0, snow_pack_init,
+                                   thermal_state_init, CTG, omc, Kf, G, eTG);
+        double liquid = snowmelt;
+        double ice_total = 0.0;
+        if constexpr (ICE) {
+            // degree-day ice melt where the layer is (nearly) snow free
+            // (icemelt_model.py:55-63), weighted by the glaciated fraction
+            // and summed over the layers left to right
+            // (cemaneigegr4jice_model.py:81-87)
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                double melt = ddf * day[2 * L + l];
+                if (melt < 0) melt = 0.0;
+                const double lw = (G[l] > 1) ? 0.0 : melt;
+                ice_total += lw * frac_ice[l];
+            }
+            liquid = snowmelt + ice_total;
+        }
+        const double q = gr4j_step(P, s, r, uh, liquid, day[3 * L]);
+        if (active) {
+            if (wq) qsim[t * ld + i] = q;
+            if (ws) {
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    G_out[(t * L + l) * ld + i] = G[l];
+                    eTG_out[(t * L + l) * ld + i] = eTG[l];
+                    if (HYST) sca_out[(t * L + l) * ld + i] = sca[l];
+                }
+                s_store[t * ld + i] = s;
+                r_store[t * ld + i] = r;
+                if (ICE) icemelt_out[t * ld + i] = ice_total;
+                if (HYST && ICE) snowmelt_out[t * ld + i] = snowmelt;
+            }
+        }
+        if (we) {
+            const double d = qobs[t] - q;
+            acc += d * d;
+        }
+    }
+    if (we && active) sse[i] = acc;
+}
+
+template <bool HYST, bool ICE>
+static int snow_gr4j_dev(const char *who, const double *prec,
+                         const double *mean_temp, const double *etp,
+                         const double *frac_ice, const double *frac_solid_prec,
+                         int64_t T, int64_t L, double snow_pack_init,
+                         double thermal_state_init, double sca_init,
+                         double s_init, double r_init, const double *params,
+                         int64_t N, double *qsim, double *G, double *eTG,
+                         double *s_store, double *r_store, double *sca,
+                         double *icemelt, double *snowmelt, int64_t ld,
+                         const double *qobs, double *sse, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    int rc = rr_check_common(who, T, N, ld, params, qobs, sse);
+    if (rc != RR_OK) return rc;
+    if (T == 0 || N == 0) return RR_OK;
+    if (L < 1 || L > RR_CEMANEIGE_MAX_LAYERS) {
+        rr_set_error("%s: %lld elevation layers; this model supports 1..%d",
+                     who, (long long)L, RR_CEMANEIGE_MAX_LAYERS);
+        return RR_E_PARAM;
+    }
+    if (!prec || !mean_temp || !etp || !frac_solid_prec || (ICE && !frac_ice)) {
+        rr_set_error("%s: NULL forcing pointer", who);
+        return RR_E_NULL;
+    }
+    const int want = 4 + (HYST ? 1 : 0) + (ICE ? 1 : 0) + (HYST && ICE ? 1 : 0);
+    const int got = (G != nullptr) + (eTG != nullptr) + (s_store != nullptr) +
+                    (r_store != nullptr) + (HYST && sca != nullptr) +
+                    (ICE && icemelt != nullptr) +
+                    (HYST && ICE && snowmelt != nullptr);
+    if (got != 0 && got != want) {
+        rr_set_error("%s: pass all %d storage outputs or none", who, want);
+        return RR_E_NULL;
+    }
+    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true, 0)) {
+        rr_set_error("%s: workspace too small", who);
+        return RR_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    SnowParLayout lay;
+    lay.npar = 6 + (HYST ? 2 : 0) + (ICE ? 1 : 0);
+    lay.i_x1 = HYST ? 4 : 2;
+    lay.i_ddf = lay.npar - 1;
+    int tier = 3, n1cap = 0, n2cap = 0;
+    rc = rr_gr4j_plan(params, N, lay.npar, lay.i_x1 + 3, (int *)workspace, st,
+                      &tier, &n1cap, &n2cap);
+    if (rc != RR_OK) return rc;
+    double *days, *gt, *state;
+    rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp, T, (int)L,
+                      workspace, st, &days, &gt, &state);
+    if (rc != RR_OK) return rc;
+    const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
+    const double *qo = (qobs && sse) ? qobs : nullptr;
+    const size_t lds_bytes =
+        (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
+    dispatch_layers((int)L, [&](auto LL) {
+        gr4j_dispatch_uh(tier, [&](auto uh) {
+            using UH = decltype(uh);
+            snow_gr4j_kernel<LL.value, UH, HYST, ICE>
+                <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
+                   st>>>(days, gt, frac_ice, T, snow_pack_init,
+                         thermal_state_init, sca_init, s_init, r_init, params,
+                         lay, N, n1cap, n2cap, qsim, G, eTG, s_store, r_store,
+                         sca, icemelt, snowmelt, ld, qo, sse);
+        });
+    });
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+extern "C" size_t rr_snowgr4j_workspace_bytes(int64_t T, int64_t L, int64_t N)
+{
+    (void)N;
+    return cema_ws_bytes(T, L, true, 0);
+}
+
+extern "C" int rr_cemaneigehystgr4j_simulate_dev(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_solid_prec, int64_t T, int64_t L,
+    double snow_pack_init, double thermal_state_init, double sca_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *sca, int64_t ld, const double *qobs, double *sse, void *workspace,
+    size_t workspace_bytes, void *stream)
+{
+    return snow_gr4j_dev<true, false>(
+        "rr_cemaneigehystgr4j_simulate_dev", prec, mean_temp, etp, nullptr,
+        frac_solid_prec, T, L, snow_pack_init, thermal_state_init, sca_init,
+        s_init, r_init, params, N, qsim, G, eTG, s_store, r_store, sca,
+        nullptr, nullptr, ld, qobs, sse, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rr_cemaneigegr4jice_simulate_dev(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *icemelt, int64_t ld, const double *qobs, double *sse,
+    void *workspace, size_t workspace_bytes, void *stream)
+{
+    return snow_gr4j_dev<false, true>(
+        "rr_cemaneigegr4jice_simulate_dev", prec, mean_temp, etp, frac_ice,
+        frac_solid_prec, T, L, snow_pack_init, thermal_state_init, 0.0,
+        s_init, r_init, params, N, qsim, G, eTG, s_store, r_store, nullptr,
+        icemelt, nullptr, ld, qobs, sse, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rr_cemaneigehystgr4jice_simulate_dev(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double sca_init, double s_init, double r_init, const double *params,
+    int64_t N, double *qsim, double *G, double *eTG, double *s_store,
+    double *r_store, double *sca, double *icemelt, double *snowmelt,
+    int64_t ld, const double *qobs, double *sse, void *workspace,
+    size_t workspace_bytes, void *stream)
+{
+    return snow_gr4j_dev<true, true>(
+        "rr_cemaneigehystgr4jice_simulate_dev", prec, mean_temp, etp,
+        frac_ice, frac_solid_prec, T, L, snow_pack_init, thermal_state_init,
+        sca_init, s_init, r_init, params, N, qsim, G, eTG, s_store, r_store,
+        sca, icemelt, snowmelt, ld, qobs, sse, workspace, workspace_bytes,
+        stream);
+}
