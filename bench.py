@@ -54,6 +54,12 @@ def parse_args():
                     help="qsim: materialise qsim[T,N] + fused per-set SSE "
                          "(default); metric: fused per-set SSE only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank) is the product "
+                         "path; gloo + --share-gpu lets several ranks share "
+                         "ONE GPU to rehearse the multi-rank code path on a "
+                         "single-GPU box (scores gathered on the host)")
+    ap.add_argument("--share-gpu", action="store_true")
     return ap.parse_args()
 
 
@@ -190,10 +196,16 @@ def main():
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE"
               % (args.gpus, world), file=sys.stderr)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    on_host = world > 1 and args.backend == "gloo"
 
     (ens, params, params_host, qsim, storages, qobs, sse, name,
      f) = build_workload(args, device, rank)
@@ -211,7 +223,7 @@ def main():
         # per-set MSE of this rank's block, then the one collective of the
         # whole job: all-gather of the scores (8 B per set)
         mse = sse / t
-        return allgather_scores(mse, total_sets)
+        return allgather_scores(mse.cpu() if on_host else mse, total_sets)
 
     def fence():
         if world > 1:
@@ -233,12 +245,13 @@ def main():
         launch()
         ev[k][1].record()
         mse = sse / t
-        scores = allgather_scores(mse, total_sets)
+        scores = allgather_scores(mse.cpu() if on_host else mse, total_sets)
     fence()
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device="cpu" if on_host else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
