@@ -31,10 +31,9 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-# algorithmic bytes per model-timestep written to HBM (DESIGN.md, section
-# "Roofline"): qsim only.  Forcing (32 B/day shared by all sets) and the
+# Algorithmic bytes per model-timestep: 8 B, the qsim
+# element, in the default mode.  Forcing (32 B/day shared by all sets) and the
 # parameter block (88 B/set, read once) amortise to ~0.
-BYTES_PER_STEP = {"qsim": 8, "metric": 0, "storages": None}
 
 
 def parse_args():
