@@ -73,6 +73,11 @@ int rr_version(void);
 int rr_device_count(void);
 /* Text of the last error on the calling thread ("" if none). */
 const char *rr_last_error(void);
+/* Select / query the HIP device the calling thread's later calls run on (one
+ * process per GPU: call once with the local rank).  rr_get_device: -1 if no
+ * device. */
+int rr_set_device(int device);
+int rr_get_device(void);
 
 /* ---- ABC model -------------------------------------------------------
  * replaces run_abcmodel(prec, initial_state, params)
@@ -205,6 +210,16 @@ int rr_cemaneigegr4j_simulate(const double *prec, const double *mean_temp,
                               double *qsim, double *G, double *eTG,
                               double *s_store, double *r_store,
                               const double *qobs, double *sse);
+
+/* ---- per-set skill scores from a resident discharge array ---------------
+ * One pass over qsim[T][ld] (device) against obs[T] (device) gives, for each
+ * of the N columns, sums[i] = {sum q, sum q^2, sum q*obs, sum (obs-q)^2}
+ * (sums: device double[N][4]), from which MSE, RMSE, NSE, KGE, alpha, beta
+ * and Pearson r follow on the host -- replaces the per-column Python loop
+ * over calc_mse (reference: rrmpg/tools/monte_carlo.py:66-71) and the
+ * per-call array copies of rrmpg/utils/metrics.py:29-299. */
+int rr_column_sums_dev(const double *qsim, int64_t ld, const double *obs,
+                       int64_t T, int64_t N, double *sums, void *stream);
 
 /* ==== next tier: SWE-SCA hysteresis snow routine, ice melt, couplings ====
  * The reference's CemaneigeHystGR4J, CemaneigeGR4JIce, CemaneigeHystGR4JIce

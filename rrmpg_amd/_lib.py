@@ -30,6 +30,10 @@ _SIGNATURES = {
     "rr_version": (ctypes.c_int, []),
     "rr_device_count": (ctypes.c_int, []),
     "rr_last_error": (ctypes.c_char_p, []),
+    "rr_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "rr_get_device": (ctypes.c_int, []),
+    "rr_column_sums_dev": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp,
+                                          _vp]),
     "rr_abc_workspace_bytes": (_sz, [_i64, _i64]),
     "rr_abc_simulate_dev": (ctypes.c_int, [_vp, _i64, _dbl, _vp, _i64, _vp,
                                            _vp, _i64, _vp, _vp, _vp, _sz,
@@ -159,6 +163,12 @@ def check(rc, what):
 
 def device_count():
     return int(load().rr_device_count())
+
+
+def set_device(index):
+    """Run this process's later sweeps on HIP device `index` (one process per
+    GPU: pass the local rank)."""
+    check(load().rr_set_device(int(index)), "rr_set_device")
 
 
 def require_gpu():

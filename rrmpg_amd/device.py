@@ -367,3 +367,25 @@ class SnowGR4JEnsemble(_Ensemble):
                 i[4], _ptr(params), n, _ptr(qsim), *([None] * 5), *tail)
         _lib.check(rc, "rr_snowgr4j_simulate_dev")
         return sse if qobs is not None else None
+
+
+def column_sums(qsim, obs):
+    """Per-column {sum q, sum q^2, sum q*obs, sum (obs-q)^2} of a resident
+    discharge tensor qsim [T, N] against obs [T] (both on the GPU), in one
+    HBM-bandwidth-bound pass (rr_column_sums_dev).  Feed the result (moved to
+    the host) to rrmpg_amd.utils.metrics.scores_from_sums."""
+    lib = _lib.load()
+    if qsim.dim() != 2 or qsim.stride(1) != 1 or qsim.dtype != torch.float64:
+        raise ValueError("qsim must be a float64 [T, N] tensor with "
+                         "contiguous columns")
+    t, n = qsim.shape
+    obs = obs.to(qsim.device, torch.float64).contiguous()
+    if obs.numel() != t:
+        raise ValueError("Arrays must have the same size.")
+    sums = torch.empty((n, 4), dtype=torch.float64, device=qsim.device)
+    rc = lib.rr_column_sums_dev(qsim.data_ptr(), qsim.stride(0),
+                                obs.data_ptr(), t, n, sums.data_ptr(),
+                                torch.cuda.current_stream(
+                                    qsim.device).cuda_stream)
+    _lib.check(rc, "rr_column_sums_dev")
+    return sums

@@ -125,3 +125,40 @@ def calc_r(obs, sim):
     from scipy.stats import pearsonr
     obs, sim = _pair(obs, sim)
     return pearsonr(obs, sim)
+
+
+def scores_from_sums(sums, obs):
+    """Every score of this module for N simulated series at once, from the
+    per-column sums the GPU produces in one pass (rrmpg_amd.device.
+    column_sums: {sum q, sum q^2, sum q*obs, sum (obs-q)^2} per column).
+
+    Returns a dict of arrays [N]: mse, rmse, nse, kge, alpha, beta, r.
+    Same definitions (and the same RuntimeErrors for degenerate
+    observations) as calc_mse / calc_rmse / calc_nse / calc_kge /
+    calc_alpha_nse / calc_beta_nse / calc_r.
+    """
+    obs = validate_array_input(obs, np.float64, 'obs')
+    sums = np.asarray(sums, dtype=np.float64).reshape(-1, 4)
+    t = obs.size
+    s_q, s_qq, s_qo, s_dd = sums.T
+    mean_obs, std_obs = np.mean(obs), np.std(obs)
+    if mean_obs == 0:
+        raise RuntimeError("KGE not definied if the mean of the observations "
+                           "equals 0.")
+    if std_obs == 0:
+        raise RuntimeError("KGE not definied if the standard deviation of "
+                           "the observations equals 0.")
+    mean_q = s_q / t
+    var_q = np.maximum(s_qq / t - mean_q ** 2, 0.0)
+    std_q = np.sqrt(var_q)
+    cov = s_qo / t - mean_q * mean_obs
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = cov / (std_q * std_obs)
+    alpha = std_q / std_obs
+    beta = mean_q / mean_obs
+    mse = s_dd / t
+    return dict(mse=mse, rmse=np.sqrt(mse),
+                nse=1 - s_dd / _nse_denominator(obs),
+                kge=1 - np.sqrt((r - 1) ** 2 + (alpha - 1) ** 2
+                                + (beta - 1) ** 2),
+                alpha=alpha, beta=(mean_q - mean_obs) / std_obs, r=r)

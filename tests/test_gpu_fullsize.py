@@ -235,3 +235,41 @@ def test_config4_multi_catchment_hbv(env, oracle):
                                      T_m[c], inits[c], flat[c, cols])
         got = q1[:, torch.from_numpy(cols).cuda()].cpu().numpy()
         assert rel_err(got, ref) < RTOL
+
+
+def test_column_scores_match_metric_functions(env, oracle):
+    """rr_column_sums_dev + scores_from_sums == calc_mse / rmse / nse / kge /
+    alpha / beta / r evaluated column by column (reference:
+    rrmpg/utils/metrics.py:29-299), here for HBV-Edu 20k sets x 30 yr."""
+    torch, syn, f = env["torch"], env["syn"], env["f"]
+    from rrmpg_amd.utils import metrics as M
+    HBV = env["models"].HBVEdu
+    n = 20_000
+    np.random.seed(4)
+    flat = _flat(HBV().get_random_params(n), HBV)
+    ens = env["device"].HBVEduEnsemble(f["temp"], f["prec"], f["month"],
+                                       f["PE_m"], f["T_m"], **syn.HBV_INITS)
+    qsim = ens.new_output(n)
+    params = ens.upload_params(flat)
+    ens.run(params, qsim)
+    torch.cuda.synchronize()
+    qobs_h = syn.make_qobs(qsim[:, 0].cpu().numpy())
+    qobs = torch.from_numpy(qobs_h).cuda()
+    sums = env["device"].column_sums(qsim, qobs)
+    sse = ens.run(params, None, qobs=qobs)
+    torch.cuda.synchronize()
+    assert float(((sums[:, 3] - sse).abs() / sse).max()) < 1e-12
+    sc = M.scores_from_sums(sums.cpu().numpy(), qobs_h)
+    rng = np.random.default_rng(9)
+    for c in rng.choice(n, 12, replace=False):
+        q = qsim[:, c].cpu().numpy()
+        for name, fn in [("mse", M.calc_mse), ("rmse", M.calc_rmse),
+                         ("nse", M.calc_nse), ("kge", M.calc_kge),
+                         ("alpha", M.calc_alpha_nse),
+                         ("beta", M.calc_beta_nse)]:
+            want = fn(qobs_h, q)
+            assert abs(sc[name][c] - want) <= 1e-9 * max(1.0, abs(want)), name
+        assert abs(sc["r"][c] - M.calc_r(qobs_h, q)[0]) < 1e-9
+    # a column view of a wider array (ld > N)
+    part = env["device"].column_sums(qsim[:, 100:164], qobs)
+    assert torch.equal(part, sums[100:164])
