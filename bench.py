@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--sets", type=int, default=1_000_000,
                     help="parameter sets per GPU")
     ap.add_argument("--days", type=int, default=10957)
+    ap.add_argument("--catchments", type=int, default=0,
+                    help="HBV-Edu only: C independent catchments x --sets "
+                         "parameter sets each in one launch (BASELINE "
+                         "configs[4]; 125 x 10000 is one GPU's share)")
     ap.add_argument("--mode", default="qsim",
                     choices=["qsim", "metric", "storages"],
                     help="qsim: materialise qsim[T,N] + fused per-set SSE "
@@ -72,6 +76,8 @@ def build_workload(args, device, rank):
     f = syn.make_forcing(args.days)
     np.random.seed(1 + rank)            # each rank: its own block of sets
     n = args.sets
+    if args.model == "hbvedu" and args.catchments > 0:
+        return build_catchments(args, device, rank)
     if args.model == "hbvedu":
         cls = models.HBVEdu
         ens = rrdev.HBVEduEnsemble(f["temp"], f["prec"], f["month"], f["PE_m"],
@@ -132,6 +138,39 @@ def build_workload(args, device, rank):
                         ens.new_output(n), ens.new_output(n))
     sse = torch.empty(n, dtype=torch.float64, device=device)
     return ens, params, params_host, qsim, storages, qobs, sse, name, f
+
+
+def build_catchments(args, device, rank):
+    """C catchments x N sets each (score-only unless --mode qsim)."""
+    import torch
+    from rrmpg_amd import device as rrdev
+    from rrmpg_amd import models
+    from rrmpg_amd.utils import synthetic as syn
+    c, n = args.catchments, args.sets
+    fs = [syn.make_forcing(args.days, seed=syn.FORCING_SEED + rank * c + k)
+          for k in range(c)]
+    temp = np.stack([f["temp"] for f in fs])
+    prec = np.stack([f["prec"] for f in fs])
+    month = np.stack([f["month"] for f in fs])
+    pe = np.tile(syn.PE_M, (c, 1))
+    tm = np.tile(syn.T_M, (c, 1))
+    inits = np.tile([0., 100., 3., 10.], (c, 1))
+    ens = rrdev.HBVEduCatchments(temp, prec, month, pe, tm, inits,
+                                 device=device)
+    np.random.seed(1 + rank)
+    cls = models.HBVEdu
+    params_host = cls().get_random_params(c * n)
+    flat = np.stack([params_host[k] for k in cls._param_list], 1)
+    params = torch.from_numpy(flat.reshape(c, n, 11)).to(device)
+    q0 = ens.new_output(1)
+    ens.run(params[:, :1].contiguous(), q0)
+    torch.cuda.synchronize(device)
+    qobs = torch.from_numpy(np.stack(
+        [syn.make_qobs(q0[k].cpu().numpy()) for k in range(c)])).to(device)
+    qsim = ens.new_output(n) if args.mode != "metric" else None
+    sse = torch.empty((c, n), dtype=torch.float64, device=device)
+    name = "HBV-Edu x %d catchments" % c
+    return ens, params, params_host, qsim, None, qobs, sse, name, fs[0]
 
 
 def cpu_baseline(args, f, params_host):
@@ -208,7 +247,7 @@ def main():
 
     (ens, params, params_host, qsim, storages, qobs, sse, name,
      f) = build_workload(args, device, rank)
-    n, t = args.sets, args.days
+    n, t = args.sets * max(1, args.catchments), args.days
     total_sets = n * world
 
     def launch():
@@ -221,7 +260,7 @@ def main():
         launch()
         # per-set MSE of this rank's block, then the one collective of the
         # whole job: all-gather of the scores (8 B per set)
-        mse = sse / t
+        mse = sse.reshape(-1) / t
         return allgather_scores(mse.cpu() if on_host else mse, total_sets)
 
     def fence():
@@ -243,7 +282,7 @@ def main():
         ev[k][0].record()
         launch()
         ev[k][1].record()
-        mse = sse / t
+        mse = sse.reshape(-1) / t
         scores = allgather_scores(mse.cpu() if on_host else mse, total_sets)
     fence()
     elapsed = time.perf_counter() - t0
@@ -317,7 +356,8 @@ def main():
             },
             "scores_finite": finite,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if (not args.no_cpu_baseline and world == 1
+                and args.catchments == 0):
             out["cpu_baseline"] = cpu_baseline(args, f, params_host)
         print(json.dumps(out))
     if world > 1:
