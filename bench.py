@@ -42,7 +42,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="hbvedu",
-                    choices=["hbvedu", "abc", "gr4j", "cemaneigegr4j",
+                    choices=["hbvedu", "abc", "gr4j", "cemaneige",
+                             "cemaneigegr4j",
                              "cemaneigehystgr4j", "cemaneigegr4jice",
                              "cemaneigehystgr4jice"])
     ap.add_argument("--sets", type=int, default=1_000_000,
@@ -92,6 +93,15 @@ def build_workload(args, device, rank):
         ens = rrdev.GR4JEnsemble(f["prec"], f["etp"], device=device,
                                  **syn.GR4J_INITS)
         name = "GR4J"
+    elif args.model == "cemaneige":
+        cls = models.Cemaneige
+        from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+        layers, inits = prepare_snow_inputs(
+            f["prec"], f["temp"] - 3, f["tmin"] - 3, f["tmax"] - 3,
+            syn.STATION_HEIGHT, 0, 0, list(syn.ALTITUDES))
+        ens = rrdev.CemaneigeEnsemble(layers[0], layers[1], layers[2],
+                                      device=device)
+        name = "Cemaneige(L=5)"
     elif args.model in ("cemaneigehystgr4j", "cemaneigegr4jice",
                         "cemaneigehystgr4jice"):
         from rrmpg_amd.models.cemaneige import prepare_snow_inputs
@@ -133,6 +143,8 @@ def build_workload(args, device, rank):
             storages = tuple(ens.new_output(n) for _ in range(2))
         elif args.model == "abc":
             storages = ens.new_output(n)
+        elif args.model == "cemaneige":
+            storages = (ens.new_output(n, 5), ens.new_output(n, 5))
         else:
             storages = (ens.new_output(n, 5), ens.new_output(n, 5),
                         ens.new_output(n), ens.new_output(n))
@@ -299,6 +311,7 @@ def main():
     if rank == 0:
         value = total_sets * t * args.steps / elapsed
         all_out = {"hbvedu": 40, "abc": 16, "gr4j": 24, "cemaneigegr4j": 104,
+                   "cemaneige": 88,
                    "cemaneigehystgr4j": 0, "cemaneigegr4jice": 0,
                    "cemaneigehystgr4jice": 0}
         bytes_per_step = {"qsim": 8, "metric": 0,
