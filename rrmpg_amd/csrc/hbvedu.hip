@@ -128,6 +128,7 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         acc = d * d;
     }
 
+#pragma unroll 2
     for (int64_t t = 1; t < T; ++t) {
         const HbvDay f = days[t];          // wave-uniform -> s_load_dwordx8
         off += ld;
