@@ -273,3 +273,56 @@ def test_column_scores_match_metric_functions(env, oracle):
     # a column view of a wider array (ld > N)
     part = env["device"].column_sums(qsim[:, 100:164], qobs)
     assert torch.equal(part, sums[100:164])
+
+
+def test_column_blocks_with_3d_storages(env, oracle):
+    """ld > N with the [T][L][ld] storages: two launches fill the two column
+    blocks of one set of wide arrays; result == one launch == oracle (snow
+    states bit for bit)."""
+    torch, syn, f = env["torch"], env["syn"], env["f"]
+    from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+    CG = env["models"].CemaneigeGR4J
+    t = 1200
+    layers, _ = prepare_snow_inputs(
+        f["prec"][:t], f["temp"][:t] - 4, f["tmin"][:t] - 4, f["tmax"][:t] - 4,
+        syn.STATION_HEIGHT, 0., 0., list(syn.ALTITUDES), etp=f["etp"][:t])
+    n, h = 517, 200
+    np.random.seed(8)
+    flat = _flat(CG().get_random_params(n), CG)
+    ens = env["device"].CemaneigeGR4JEnsemble(*layers, 2.0, -0.1, 0.6, 0.7)
+    params = ens.upload_params(flat)
+
+    def outputs():
+        return (ens.new_output(n), ens.new_output(n, 5), ens.new_output(n, 5),
+                ens.new_output(n), ens.new_output(n))
+    q, G, E, S, R = outputs()
+    ens.run(params, q, (G, E, S, R))
+    q2, G2, E2, S2, R2 = outputs()
+    ens.run(params[:h].contiguous(), q2[:, :h],
+            (G2[:, :, :h], E2[:, :, :h], S2[:, :h], R2[:, :h]))
+    ens.run(params[h:].contiguous(), q2[:, h:],
+            (G2[:, :, h:], E2[:, :, h:], S2[:, h:], R2[:, h:]))
+    torch.cuda.synchronize()
+    for a, b in ((q, q2), (G, G2), (E, E2), (S, S2), (R, R2)):
+        assert torch.equal(a, b)
+    ref = oracle.simulate_cemaneigegr4j(layers[0], layers[1], layers[3],
+                                        layers[2], (2.0, -0.1, 0.6, 0.7), flat,
+                                        return_storages=True, nthreads=8)
+    assert np.array_equal(G.cpu().numpy(), ref[1])
+    assert np.array_equal(E.cpu().numpy(), ref[2])
+    assert rel_err(q.cpu().numpy(), ref[0]) < RTOL
+    # snow routine alone, same exercise
+    C = env["models"].Cemaneige
+    ens2 = env["device"].CemaneigeEnsemble(layers[0], layers[1], layers[2],
+                                           2.0, -0.1)
+    p2 = ens2.upload_params(flat[:, :2].copy())
+    o = ens2.new_output(n)
+    g, e = ens2.new_output(n, 5), ens2.new_output(n, 5)
+    ens2.run(p2[:h].contiguous(), o[:, :h], (g[:, :, :h], e[:, :, :h]))
+    ens2.run(p2[h:].contiguous(), o[:, h:], (g[:, :, h:], e[:, :, h:]))
+    torch.cuda.synchronize()
+    refc = oracle.simulate_cemaneige(layers[0], layers[1], layers[2],
+                                     (2.0, -0.1), flat[:, :2],
+                                     return_storages=True, nthreads=8)
+    for a, b in zip((o, g, e), refc):
+        assert np.array_equal(a.cpu().numpy(), b)
