@@ -1,0 +1,165 @@
+"""GPU fuzz tests: parameters far outside every model's bounds (zeros,
+negatives, denormals, huge values, infinities, NaN) exercise the guarded
+fallbacks of the fast paths (fastpow domain, invariant-divisor division
+ranges, tanh clamp, padded unit hydrographs) -- results must still match the
+oracle: same NaN / inf pattern everywhere; finite values within 1e-10
+relative for the in-bounds sets (every even column) and within 1e-6 for the
+wild ones, whose dynamics are ill-conditioned (e.g. Beta = 100 amplifies a
+1-ulp difference of the power a hundredfold per step)."""
+
+import numpy as np
+import pytest
+
+from .conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def _same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, what
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert np.array_equal(nan_a, nan_b), what + ": NaN pattern"
+    inf = np.isinf(b)
+    assert np.array_equal(np.isinf(a), inf), what + ": inf pattern"
+    assert np.array_equal(a[inf], b[inf]), what + ": inf sign"
+    ok = ~(nan_b | inf)
+    # |a - b| <= rtol * |b| + atol, atol scaled by the largest finite value of
+    # the set's series (a store that empties leaves a cancellation residue of
+    # ~1 ulp of what it held the day before).  Last axis = parameter sets;
+    # even sets are in bounds (rtol 1e-10), odd ones wild (rtol 1e-6).
+    with np.errstate(all="ignore"):
+        fin = np.where(ok, np.abs(b), 0.0)
+        colmax = fin.reshape(-1, fin.shape[-1]).max(axis=0)
+        diff = np.where(ok, np.abs(a - b), 0.0)
+        rtol = np.where(np.arange(b.shape[-1]) % 2 == 0, RTOL, 1e-6)
+        excess = diff - (rtol * fin + 1e-2 * rtol * np.maximum(colmax, 1e-9))
+    assert excess.max(initial=0.0) <= 0, "%s: excess %g at %s" % (
+        what, excess.max(), np.unravel_index(np.argmax(excess), excess.shape))
+
+
+def _records(cls, flat):
+    p = np.zeros(flat.shape[0], dtype=cls._dtype)
+    for k, name in enumerate(cls._param_list):
+        p[name] = flat[:, k]
+    return p
+
+
+WILD = np.array([0.0, -0.0, 1.0, -1.0, 5e-324, 1e-310, 2.3e-308, 1e-200,
+                 1e200, 1e308, -1e308, np.inf, -np.inf, np.nan, 0.5, 2.0,
+                 -0.25, 100.0, 1e-5, 7.5])
+
+
+def _wild_params(rng, lo, hi, n):
+    """n sets inside the bounds, then every parameter of every 2nd set
+    replaced at random by a wild value."""
+    k = lo.size
+    flat = lo + (hi - lo) * rng.random((n, k))
+    mask = rng.random((n, k)) < 0.25
+    mask[::2] = False
+    flat[mask] = rng.choice(WILD, mask.sum())
+    return flat
+
+
+@pytest.fixture(scope="module")
+def models():
+    from rrmpg_amd import _lib
+    _lib.load()
+    _lib.require_gpu()
+    import rrmpg_amd.models as m
+    return m
+
+
+def test_hbvedu_fuzz(models, oracle):
+    g = golden("syn_hbvedu")
+    rng = np.random.default_rng(100)
+    lo = np.array([-1, 3, 100, 1, .01, 90, .05, .01, .01, .01, 2.])
+    hi = np.array([1, 7, 200, 7, .07, 180, .2, .1, .05, .05, 5.])
+    flat = _wild_params(rng, lo, hi, 640)
+    t = 400
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_hbvedu(g["temp"][:t], g["prec"][:t],
+                                     g["month"][:t] - 1, g["PE_m"], g["T_m"],
+                                     (0., 100., 3., 10.), flat,
+                                     return_storage=True, nthreads=8)
+    out = models.HBVEdu().simulate(g["temp"][:t], g["prec"][:t],
+                                   g["month"][:t], g["PE_m"], g["T_m"], 0.,
+                                   100., 3., 10., return_storage=True,
+                                   params=_records(models.HBVEdu, flat))
+    for a, b, n in zip(out, ref, ["qsim", "snow", "soil", "s1", "s2"]):
+        _same(a, b, "hbv " + n)
+    assert np.isnan(ref[0]).any() and np.isfinite(ref[0]).any()
+
+
+def test_gr4j_fuzz(models, oracle):
+    g = golden("syn_gr4j")
+    rng = np.random.default_rng(101)
+    lo, hi = np.array([100, -5, 20, 1.1]), np.array([1200, 3, 300, 2.9])
+    flat = _wild_params(rng, lo, hi, 640)
+    # x4 must still give 1..20 ordinates (anything else is a loud error)
+    bad = ~((flat[:, 3] > 0) & (flat[:, 3] <= 20))
+    flat[bad, 3] = rng.uniform(0.2, 19.5, bad.sum())
+    t = 400
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_gr4j(g["prec"][:t], g["etp"][:t], (0.6, 0.7),
+                                   flat, return_storage=True, nthreads=8)
+    for sl in (slice(0, 640), slice(0, 64)):   # both start at an even set
+        out = models.GR4J().simulate(g["prec"][:t], g["etp"][:t], 0.6, 0.7,
+                                     return_storage=True,
+                                     params=_records(models.GR4J, flat[sl]))
+        for a, b, n in zip(out, ref, ["qsim", "s_store", "r_store"]):
+            _same(a, b[:, sl], "gr4j " + n)
+    # register tiers too: all x4 <= 3 / <= 5 / <= 10
+    for cap in (2.9, 4.9, 9.9):
+        f2 = flat.copy()
+        f2[:, 3] = rng.uniform(0.3, cap, 640)
+        with np.errstate(all="ignore"):
+            ref = oracle.simulate_gr4j(g["prec"][:t], g["etp"][:t],
+                                       (0.6, 0.7), f2, nthreads=8)
+        out = models.GR4J().simulate(g["prec"][:t], g["etp"][:t], 0.6, 0.7,
+                                     params=_records(models.GR4J, f2))
+        _same(out, ref, "gr4j tier %g" % cap)
+
+
+def test_snow_models_fuzz(models, oracle):
+    from rrmpg_amd.models import _snowgr4j as core
+    h = golden("syn_cemaneigehystgr4j")
+    rng = np.random.default_rng(102)
+    t = 500
+    layers = tuple(h[k][:t] for k in ("layer_prec", "layer_mean",
+                                      "frac_solid", "etp"))
+    forcing = (layers[0], layers[1], layers[3], layers[2])
+    fice = np.array([0.0, 0.1, 0.3, 0.6, 0.9])
+    lo = np.array([0, 0, 1, 0, 10, -5, 20, 1.1, 0.])
+    hi = np.array([1, 10, 1000, 1, 1200, 3, 5000, 10, 30.])
+    for (hyst, ice), cls, cols in [
+            ((True, True), models.CemaneigeHystGR4JIce, list(range(9))),
+            ((True, False), models.CemaneigeHystGR4J, list(range(8))),
+            ((False, True), models.CemaneigeGR4JIce, [0, 1, 4, 5, 6, 7, 8])]:
+        flat = _wild_params(rng, lo[cols], hi[cols], 320)
+        ix4 = cls._param_list.index('x4')
+        bad = ~((flat[:, ix4] > 0) & (flat[:, ix4] <= 20))
+        flat[bad, ix4] = rng.uniform(0.2, 9.9, bad.sum())
+        inits = (3.0, -0.2, 0.4, 0.5, 0.6)
+        with np.errstate(all="ignore"):
+            ref = oracle.simulate_snow_gr4j(hyst, ice, *forcing, inits, flat,
+                                            frac_ice=fice if ice else None,
+                                            return_storages=True, nthreads=8)
+        out, _ = core.run(hyst, ice, layers, fice if ice else None, inits,
+                          _records(cls, flat), True, True, None)
+        for k, a in out.items():
+            if a is not None:
+                _same(a, ref[k], "%s %s" % (cls.__name__, k))
+    # Cemaneige alone with wild CTG / Kf
+    flat = _wild_params(rng, np.array([0., 0.]), np.array([1., 10.]), 320)
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_cemaneige(layers[0], layers[1], layers[2],
+                                        (3.0, -0.2), flat,
+                                        return_storages=True, nthreads=8)
+    from rrmpg_amd.models import cemaneige as cmod
+    out, _ = cmod._run(layers[:3], (3.0, -0.2),
+                       _records(models.Cemaneige, flat), True, True, None)
+    for a, b, n in zip(out, ref, ["outflow", "G", "eTG"]):
+        _same(a, b, "cemaneige " + n)
