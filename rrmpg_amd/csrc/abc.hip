@@ -6,71 +6,91 @@
 //
 // ABC is the one model of the family that is truly HBM-bound: 6 flops per
 // 8 B (qsim) or 16 B (qsim + storage) written per model-timestep.  So the
-// kernel is built around the store stream: each lane carries TWO adjacent
+// kernel is built around the store stream: each lane carries two adjacent
 // parameter sets, so every output row is written with 16-byte
 // global_store_dwordx4 (1 KiB contiguous per wave per day); the single
 // storage state per set stays in a register; the shared precipitation is
-// read through the scalar cache, eight days per s_load.
+// read through the scalar cache.
 #include "common.h"
 
 // Q/S/E: write qsim / write storage / accumulate the fused squared error.
-template <bool Q, bool S, bool E>
-__global__ __launch_bounds__(RR_BLOCK) void abc_kernel_x2(
+// SPL = parameter sets per lane (2 is used): each lane owns SPL adjacent columns,
+// so a wave writes SPL * 512 contiguous bytes per output row with 16-byte
+// stores; more bytes in flight per wave is what a pure store stream needs.
+template <int SPL, bool Q, bool S, bool E>
+__global__ __launch_bounds__(RR_BLOCK) void abc_kernel_wide(
     const double *__restrict__ prec, int64_t T, double initial_state,
     const double *__restrict__ params, int64_t N, double *__restrict__ qsim,
     double *__restrict__ storage, int64_t ld, const double *__restrict__ qobs,
     double *__restrict__ sse)
 {
-    const int64_t i0 = 2 * ((int64_t)blockIdx.x * RR_BLOCK + threadIdx.x);
-    const bool act0 = i0 < N, act1 = i0 + 1 < N;
-    const double *p0 = params + (act0 ? i0 : N - 1) * 3;
-    const double *p1 = params + (act1 ? i0 + 1 : N - 1) * 3;
-    const double a0 = p0[0], b0 = p0[1], c0 = p0[2];
-    const double a1 = p1[0], b1 = p1[1], c1 = p1[2];
-    // loop invariants, evaluated exactly as the reference writes them
-    const double k0 = 1 - a0 - b0, k1 = 1 - a1 - b1;   // abcmodel_model.py:56
-    const double m0 = 1 - c0, m1 = 1 - c1;             // :59
-
-    double s0 = initial_state, s1 = initial_state;
-    double e0 = 0.0, e1 = 0.0;
+    const int64_t i0 = SPL * ((int64_t)blockIdx.x * RR_BLOCK + threadIdx.x);
+    bool act[SPL];
+    double a[SPL], c[SPL], k[SPL], m[SPL], st[SPL], err[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        act[j] = i0 + j < N;
+        const double *p = params + (act[j] ? i0 + j : N - 1) * 3;
+        a[j] = p[0];
+        c[j] = p[2];
+        // loop invariants, evaluated exactly as the reference writes them
+        k[j] = 1 - p[0] - p[1];                  // abcmodel_model.py:56
+        m[j] = 1 - p[2];                         // :59
+        st[j] = initial_state;
+        err[j] = 0.0;
+    }
     int64_t off = i0;
 
-    auto store = [&](double *base, double v0, double v1) {
-        if (act1) {
-            *reinterpret_cast<double2 *>(base + off) = make_double2(v0, v1);
-        } else if (act0) {
-            base[off] = v0;
+    // pairs (j, j+1) go out as one 16-byte store when both columns exist
+    auto store = [&](double *base, const double (&v)[SPL]) {
+#pragma unroll
+        for (int j = 0; j < SPL; j += 2) {
+            if (act[j + 1])
+                *reinterpret_cast<double2 *>(base + off + j) =
+                    make_double2(v[j], v[j + 1]);
+            else if (act[j])
+                base[off + j] = v[j];
         }
     };
 
     // t = 0 (abcmodel_model.py:46-50)
-    if (Q) store(qsim, 0.0, 0.0);
-    if (S) store(storage, s0, s1);
-    if (E) {
-        const double d = qobs[0] - 0.0;
-        e0 = d * d;
-        e1 = d * d;
+    {
+        double zero[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) zero[j] = 0.0;
+        if (Q) store(qsim, zero);
+        if (S) store(storage, st);
+        if (E) {
+            const double d = qobs[0] - 0.0;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) err[j] = d * d;
+        }
     }
 #pragma unroll 8
     for (int64_t t = 1; t < T; ++t) {
         const double pr = prec[t];   // wave-uniform -> scalar load
         off += ld;
-        const double q0 = k0 * pr + c0 * s0;           // :56
-        const double q1 = k1 * pr + c1 * s1;
-        s0 = m0 * s0 + a0 * pr;                        // :59
-        s1 = m1 * s1 + a1 * pr;
-        if (Q) store(qsim, q0, q1);
-        if (S) store(storage, s0, s1);
+        double q[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            q[j] = k[j] * pr + c[j] * st[j];     // :56
+            st[j] = m[j] * st[j] + a[j] * pr;    // :59
+        }
+        if (Q) store(qsim, q);
+        if (S) store(storage, st);
         if (E) {
             const double ob = qobs[t];
-            const double d0 = ob - q0, d1 = ob - q1;
-            e0 += d0 * d0;
-            e1 += d1 * d1;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const double d = ob - q[j];
+                err[j] += d * d;
+            }
         }
     }
     if (E) {
-        if (act0) sse[i0] = e0;
-        if (act1) sse[i0 + 1] = e1;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j)
+            if (act[j]) sse[i0 + j] = err[j];
     }
 }
 
@@ -142,26 +162,21 @@ extern "C" int rr_abc_simulate_dev(const double *prec, int64_t T,
     const bool q = qsim != nullptr, s = storage != nullptr, e = qobs && sse;
     const bool wide = (ld % 2 == 0) && (((uintptr_t)qsim) % 16 == 0) &&
                       (((uintptr_t)storage) % 16 == 0);
+    // two sets per lane (measured: four sets per lane is slower, 16.8 vs
+    // 13.9 ms at 1M sets -- fewer waves hide less store latency)
+    const int spl = wide ? 2 : 1;
     const dim3 block(RR_BLOCK);
-    const dim3 grid((unsigned)rr_ceil_div(wide ? rr_ceil_div(N, 2) : N,
-                                          RR_BLOCK));
-#define ABC_GO(K, Q, S, E)                                                   \
-    hipLaunchKernelGGL((K<Q, S, E>), grid, block, 0, st, prec, T,            \
-                       initial_state, params, N, qsim, storage, ld, qobs, sse)
-#define ABC_DISPATCH(K)                                                      \
-    do {                                                                     \
-        if (q) {                                                             \
-            if (s) { if (e) ABC_GO(K, true, true, true); else ABC_GO(K, true, true, false); } \
-            else   { if (e) ABC_GO(K, true, false, true); else ABC_GO(K, true, false, false); } \
-        } else {                                                             \
-            if (s) { if (e) ABC_GO(K, false, true, true); else ABC_GO(K, false, true, false); } \
-            else   { if (e) ABC_GO(K, false, false, true); else ABC_GO(K, false, false, false); } \
-        }                                                                    \
-    } while (0)
-    if (wide) ABC_DISPATCH(abc_kernel_x2);
-    else ABC_DISPATCH(abc_kernel_x1);
-#undef ABC_DISPATCH
-#undef ABC_GO
+    const dim3 grid((unsigned)rr_ceil_div(rr_ceil_div(N, spl), RR_BLOCK));
+    rr_dispatch3(q, s, e, [&](auto Q, auto S, auto E) {
+        if (spl == 2)
+            abc_kernel_wide<2, Q.value, S.value, E.value>
+                <<<grid, block, 0, st>>>(prec, T, initial_state, params, N,
+                                         qsim, storage, ld, qobs, sse);
+        else
+            abc_kernel_x1<Q.value, S.value, E.value>
+                <<<grid, block, 0, st>>>(prec, T, initial_state, params, N,
+                                         qsim, storage, ld, qobs, sse);
+    });
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
