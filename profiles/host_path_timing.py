@@ -16,7 +16,8 @@ p = m.get_random_params(n)
 kw = dict(temp=f["temp"], prec=f["prec"], month=f["month"], PE_m=f["PE_m"],
           T_m=f["T_m"], **syn.HBV_INITS)
 m.simulate(params=p[:1000], **kw)
-for rep in range(2):
+for rep in range(3):
+    q = None                      # free the previous result outside the clock
     t0 = time.perf_counter()
     q = m.simulate(params=p, **kw)
     dt = time.perf_counter() - t0

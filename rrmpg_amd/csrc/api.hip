@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -131,6 +132,38 @@ int64_t pick_block(int64_t T, int64_t N, const std::vector<OutSpec> &outs)
     return nc < N ? nc : N;
 }
 
+// First touch of a freshly allocated host array is what bounds the gather:
+// D2H into never-touched pageable memory runs at ~13 GB/s (page faults) against
+// ~50 GB/s into touched pages (profiles/README.md).  So while the first kernel
+// runs, a few host threads fault the output pages in (writing the zeros the
+// caller's np.zeros would have produced lazily anyway; every byte is
+// overwritten by the gather afterwards).
+void prefault(const std::vector<OutSpec> &outs, int64_t T, int64_t N)
+{
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads < 1) nthreads = 1;
+    const size_t page = 4096;
+    for (const OutSpec &o : outs) {
+        if (!o.host) continue;
+        const size_t bytes = (size_t)T * (size_t)o.rows_per_t * (size_t)N * 8;
+        if (bytes < ((size_t)64 << 20)) continue;      // small: not worth it
+        char *base = (char *)o.host;
+        std::vector<std::thread> pool;
+        const size_t chunk = (bytes / nthreads + page) & ~(page - 1);
+        for (unsigned k = 0; k < nthreads; ++k) {
+            const size_t lo = (size_t)k * chunk;
+            if (lo >= bytes) break;
+            const size_t hi = (lo + chunk < bytes) ? lo + chunk : bytes;
+            pool.emplace_back([base, lo, hi, page]() {
+                for (size_t p = lo; p < hi; p += page)
+                    *(volatile char *)(base + p) = 0;
+            });
+        }
+        for (std::thread &t : pool) t.join();
+    }
+}
+
 // Runs `launch(i0, nc, slabs, d_sse)` for every column block and gathers the
 // slabs into the host arrays.
 template <class Launch>
@@ -156,6 +189,7 @@ int sweep_blocks(int64_t T, int64_t N, const std::vector<OutSpec> &outs,
         const int64_t nc = (N - i0 < nc_max) ? (N - i0) : nc_max;
         int rc = launch(i0, nc, ptrs.data(), d_sse.as<double>());
         if (rc != RR_OK) return rc;
+        if (i0 == 0) prefault(outs, T, N);      // overlaps the first kernel
         RR_HIP(hipStreamSynchronize(nullptr));
         for (size_t k = 0; k < outs.size(); ++k) {
             if (!outs[k].host) continue;
