@@ -23,6 +23,8 @@
 // Arithmetic follows the reference statement by statement in fp64 without
 // FMA contraction (-ffp-contract=off); only the power (soil/FC)**Beta is not
 // libm's: it is fastmath.h's ~1-ulp evaluation (general pow as fallback).
+#include <stdlib.h>
+
 #include "common.h"
 #include "fastmath.h"
 
@@ -68,7 +70,12 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 // multi-catchment launch (rr_hbvedu_simulate_catchments_dev) lays every array
 // out catchment-major: days [C][T], params [C][N][11], outputs [C][T][ld],
 // qobs [C][T], sse [C][N], inits [C][4].
-template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE>
+// LDS_FORCING (measurement variant, RRHIP_HBV_LDS_FORCING=1): instead of one
+// scalar load per day, the wave copies 64 day records (2 KiB, coalesced) into
+// LDS and every lane reads them back by broadcast -- the staging north_star
+// sketched.  Kept to document the comparison (profiles/README.md): the scalar
+// path is the faster one, it costs no vector-memory or LDS instruction at all.
+template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, bool LDS_FORCING = false>
 __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     const HbvDay *__restrict__ days, int64_t T, double snow_init,
     double soil_init, double s1_init, double s2_init,
@@ -128,9 +135,10 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         acc = d * d;
     }
 
-#pragma unroll 2
-    for (int64_t t = 1; t < T; ++t) {
-        const HbvDay f = days[t];          // wave-uniform -> s_load_dwordx8
+    // (the record is taken BY VALUE: one s_load_dwordx8 per day up front; a
+    // reference lets hipcc re-load single fields at their use sites, each
+    // with its own wait)
+    auto day_step = [&](const HbvDay f, int64_t t) {
         off += ld;
 
         // snow routine (hbvedu_model.py:87-96)
@@ -200,6 +208,27 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
             const double d = qobs[t] - q;  // wave-uniform scalar load
             acc += d * d;
         }
+    };
+
+    if constexpr (LDS_FORCING) {
+        __shared__ HbvDay tile[RR_BLOCK];
+        for (int64_t t0 = 1; t0 < T; t0 += RR_BLOCK) {
+            const int64_t tt = t0 + threadIdx.x;
+            tile[threadIdx.x] = days[tt < T ? tt : T - 1];
+            __syncthreads();
+            const int n = (int)((T - t0 < RR_BLOCK) ? (T - t0) : RR_BLOCK);
+            for (int k = 0; k < n; ++k) {
+                const HbvDay f = tile[k];  // uniform address: LDS broadcast
+                day_step(f, t0 + k);
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll 2
+        for (int64_t t = 1; t < T; ++t) {
+            const HbvDay f = days[t];      // wave-uniform -> s_load_dwordx8
+            day_step(f, t);
+        }
     }
     if (WITH_SSE && active) sse[i] = acc;
 }
@@ -229,12 +258,20 @@ static int hbv_launch(const double *temp, const double *prec,
                        days);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK), (unsigned)C);
     const bool any_s = snow != nullptr;
+    const char *lds_env = getenv("RRHIP_HBV_LDS_FORCING");
+    const bool lds_forcing = lds_env && lds_env[0] == '1';
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
                  [&](auto Q, auto S, auto E) {
-        hbvedu_kernel<Q.value, S.value, E.value>
-            <<<grid, dim3(RR_BLOCK), 0, st>>>(
-                days, T, snow_init, soil_init, s1_init, s2_init, inits, params,
-                N, qsim, snow, soil, s1, s2, ld, qobs, sse);
+        if (lds_forcing)
+            hbvedu_kernel<Q.value, S.value, E.value, true>
+                <<<grid, dim3(RR_BLOCK), 0, st>>>(
+                    days, T, snow_init, soil_init, s1_init, s2_init, inits,
+                    params, N, qsim, snow, soil, s1, s2, ld, qobs, sse);
+        else
+            hbvedu_kernel<Q.value, S.value, E.value, false>
+                <<<grid, dim3(RR_BLOCK), 0, st>>>(
+                    days, T, snow_init, soil_init, s1_init, s2_init, inits,
+                    params, N, qsim, snow, soil, s1, s2, ld, qobs, sse);
     });
     RR_HIP(hipGetLastError());
     return RR_OK;
