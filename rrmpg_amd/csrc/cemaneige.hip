@@ -97,7 +97,13 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const bool wq = outflow != nullptr, ws = G_out != nullptr,
                we = sse != nullptr;
     for (int64_t t = 0; t < T; ++t) {
-        const double q = cema_day<L>(days + t * (3 * L), inv_gt, t == 0,
+        // the whole day record by value, up front: one wide scalar load and
+        // one wait per day (read through the pointer, hipcc fetches every
+        // field at its use site with its own s_load + wait)
+        double rec[3 * L];
+#pragma unroll
+        for (int k = 0; k < 3 * L; ++k) rec[k] = days[t * (3 * L) + k];
+        const double q = cema_day<L>(rec, inv_gt, t == 0,
                                      snow_pack_init, thermal_state_init, CTG,
                                      omc, Kf, G, eTG);
         if (active) {
@@ -151,7 +157,9 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneigegr4j_kernel(
     const bool wq = qsim != nullptr, ws = G_out != nullptr, we = sse != nullptr;
     constexpr int D = 3 * L + 1;
     for (int64_t t = 0; t < T; ++t) {
-        const double *day = days + t * D;
+        double day[D];          // by value: one wide scalar load per day
+#pragma unroll
+        for (int k = 0; k < D; ++k) day[k] = days[t * D + k];
         const double liquid = cema_day<L>(day, inv_gt, t == 0, snow_pack_init,
                                           thermal_state_init, CTG, omc, Kf, G,
                                           eTG);

@@ -119,7 +119,9 @@ __global__ __launch_bounds__(RR_BLOCK, 2) void snow_gr4j_kernel(
     const bool wq = qsim != nullptr, ws = G_out != nullptr, we = sse != nullptr;
     constexpr int D = 3 * L + 1;
     for (int64_t t = 0; t < T; ++t) {
-        const double *day = days + t * D;
+        double day[D];          // by value: one wide scalar load per day
+#pragma unroll
+        for (int k = 0; k < D; ++k) day[k] = days[t * D + k];
         double snowmelt;
         if constexpr (HYST)
             snowmelt = cema_hyst_day<L>(day, psol, t == 0, snow_pack_init,
