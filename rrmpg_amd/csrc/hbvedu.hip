@@ -8,12 +8,12 @@
 //
 // Data layout
 //   forcing  : a packed per-day record {temp, prec, temp - T_m[month],
-//              PE_m[month]} (32 B) built once by hbv_pack_forcing -- the
+//              PE_m[month], qobs} (40 B) built once by hbv_pack_forcing -- the
 //              month lookup and the (temp - T_m) subtraction are parameter
 //              independent, so they are hoisted out of the N-fold sweep with
 //              the identical fp64 operation the reference performs per set.
 //              The record address is wave-uniform, so it is fetched with ONE
-//              scalar s_load_dwordx8 per day into SGPRs (scalar cache ->
+//              scalar load burst (s_load_dwordx8 + x2) per day into SGPRs (scalar cache ->
 //              L2), never through the vector memory path.
 //   params   : the reference's AoS double[N][11]; each lane reads its 11
 //              values once (88 B per set, amortised over T steps).
@@ -28,11 +28,13 @@
 #include "common.h"
 #include "fastmath.h"
 
-struct __attribute__((aligned(32))) HbvDay {
+struct __attribute__((aligned(8))) HbvDay {
     double temp;   // temp[t]
     double prec;   // prec[t]
     double dtemp;  // temp[t] - T_m[month[t]]        (hbvedu_model.py:102)
     double pe_m;   // PE_m[month[t]]
+    double qobs;   // observed discharge of the day (0 if no score is wanted):
+                   // rides along so the score needs no second load + wait
 };
 
 // blockIdx.y = catchment (forcing arrays are [C][T], monthly tables [C][12])
@@ -40,7 +42,8 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
                                  const double *__restrict__ prec,
                                  const int8_t *__restrict__ month,
                                  const double *__restrict__ PE_m,
-                                 const double *__restrict__ T_m, int64_t T,
+                                 const double *__restrict__ T_m,
+                                 const double *__restrict__ qobs, int64_t T,
                                  HbvDay *__restrict__ days)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,6 +58,7 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
     d.prec = prec[g];
     d.dtemp = temp[g] - T_m[c * 12 + m];
     d.pe_m = PE_m[c * 12 + m];
+    d.qobs = qobs ? qobs[g] : 0.0;
     days[g] = d;
 }
 
@@ -205,9 +209,10 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
             }
         }
         if (WITH_SSE) {
-            const double d = qobs[t] - q;  // wave-uniform scalar load
+            const double d = f.qobs - q;
             acc += d * d;
         }
+        (void)t;
     };
 
     if constexpr (LDS_FORCING) {
@@ -224,7 +229,6 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
             __syncthreads();
         }
     } else {
-#pragma unroll 2
         for (int64_t t = 1; t < T; ++t) {
             const HbvDay f = days[t];      // wave-uniform -> s_load_dwordx8
             day_step(f, t);
@@ -254,8 +258,8 @@ static int hbv_launch(const double *temp, const double *prec,
     HbvDay *days = (HbvDay *)workspace;
     hipLaunchKernelGGL(hbv_pack_forcing,
                        dim3((unsigned)rr_ceil_div(T, 256), (unsigned)C),
-                       dim3(256), 0, st, temp, prec, month, PE_m, T_m, T,
-                       days);
+                       dim3(256), 0, st, temp, prec, month, PE_m, T_m,
+                       (qobs && sse) ? qobs : nullptr, T, days);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK), (unsigned)C);
     const bool any_s = snow != nullptr;
     const char *lds_env = getenv("RRHIP_HBV_LDS_FORCING");
