@@ -124,8 +124,19 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     if (we && active) sse[i] = acc;
 }
 
+// Small configurations (<= 5 layers, unit hydrographs in 3+7 registers or in
+// LDS) are held at 128 registers = 4 waves per SIMD: a handful of spills cost
+// less than the lost wave (137 -> 130 ms at L = 5).
 template <int L, class UH>
-__global__ __launch_bounds__(RR_BLOCK) void cemaneigegr4j_kernel(
+constexpr int coupled_min_waves()
+{
+    return (L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
+                       std::is_same<UH, UhLds>::value)) ? 4 : 2;
+}
+
+template <int L, class UH>
+__global__ __launch_bounds__(RR_BLOCK, (coupled_min_waves<L, UH>())) void
+cemaneigegr4j_kernel(
     const double *__restrict__ days, const double *__restrict__ gtresh,
     int64_t T, double snow_pack_init, double thermal_state_init,
     double s_init, double r_init, const double *__restrict__ params,
