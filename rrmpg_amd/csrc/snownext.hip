@@ -75,11 +75,22 @@ struct SnowParLayout {
     int npar, i_x1, i_ddf;
 };
 
-// min. 2 waves per SIMD: caps the allocation at 256 registers (the x4 <= 10
-// register tier of the hysteresis + ice variant would otherwise take a few
-// AGPRs more and drop to one wave per SIMD)
+// Minimum waves per SIMD the register allocation is held to.  At least 2: the
+// x4 <= 10 register tier of the hysteresis + ice variant would otherwise take
+// a few AGPRs more than 256 registers and drop to one wave per SIMD.  Small
+// configurations (<= 5 layers, unit hydrographs in 3+7 registers or in LDS)
+// are held at 3 (hysteresis: four states per layer) or 4 waves; a handful of
+// spills cost less than the lost wave.
+template <int L, class UH, bool HYST>
+constexpr int snow_min_waves()
+{
+    return (L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
+                       std::is_same<UH, UhLds>::value)) ? (HYST ? 3 : 4) : 2;
+}
+
 template <int L, class UH, bool HYST, bool ICE>
-__global__ __launch_bounds__(RR_BLOCK, 2) void snow_gr4j_kernel(
+__global__ __launch_bounds__(RR_BLOCK, (snow_min_waves<L, UH, HYST>())) void
+snow_gr4j_kernel(
     const double *__restrict__ days, const double *__restrict__ gtresh,
     const double *__restrict__ frac_ice, int64_t T, double snow_pack_init,
     double thermal_state_init, double sca_init, double s_init, double r_init,
