@@ -54,8 +54,15 @@ __global__ void gr4j_scan_x4(const double *__restrict__ params, int64_t N,
     }
 }
 
+template <class UH>
+constexpr int gr4j_min_waves()
+{
+    return (std::is_same<UH, UhRegs<3>>::value ||
+            std::is_same<UH, UhLds>::value) ? 6 : 2;
+}
+
 template <class UH, bool Q, bool S, bool E>
-__global__ __launch_bounds__(RR_BLOCK) void gr4j_kernel(
+__global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
     const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
     const double *__restrict__ params, int64_t N, int n1cap, int n2cap,
     double *__restrict__ qsim, double *__restrict__ s_store,
