@@ -203,27 +203,38 @@ struct UhLds {
         }
     }
 
+    // Same select-free update as UhRegs::route: ordinates and slots beyond a
+    // lane's own length are exactly 0 (the s-curves give S(j+1) - S(j) = 1 - 1
+    // there), so uh[j] = uh[j+1] + ord[j]*p for every slot up to the wave's
+    // longest hydrograph; a non-finite p makes the wave re-zero the padding.
+    // Each slot is read once (as the "next" of its left neighbour) and
+    // written once per day.
     __device__ __forceinline__ void route(double p1, double p2, double &head1,
                                           double &head2)
     {
-        // each slot is read once (as the "next" of its left neighbour) and
-        // written once per day
         for (int j = 0; j < n1w; ++j) {
             const double nxt = (j + 1 < n1w) ? U1(j + 1) : 0.0;
-            const double v = O1(j) * p1;
-            const double nv = (j + 1 < n1) ? nxt + v : v;
+            const double nv = nxt + O1(j) * p1;
             U1(j) = nv;
             if (j == 0) head1 = nv;
         }
         for (int j = 0; j < n2w; ++j) {
             const double nxt = (j + 1 < n2w) ? U2(j + 1) : 0.0;
-            const double v = O2(j) * p2;
-            const double nv = (j + 1 < n2) ? nxt + v : v;
+            const double nv = nxt + O2(j) * p2;
             U2(j) = nv;
             if (j == 0) head2 = nv;
         }
+        const bool finite = (__builtin_fabs(p1) < __builtin_inf()) &&
+                            (__builtin_fabs(p2) < __builtin_inf());
+        if (!__all(finite)) {
+            for (int j = 0; j < n1w; ++j)
+                if (j >= n1) U1(j) = 0.0;
+            for (int j = 0; j < n2w; ++j)
+                if (j >= n2) U2(j) = 0.0;
+        }
     }
 };
+
 
 // Calls f(UH{}) with the storage tier picked by rr_gr4j_plan:
 // tier 3 / 5 / 10 -> UhRegs<3> / <5> / <10>, 0 -> UhLds.
