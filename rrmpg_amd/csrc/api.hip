@@ -155,7 +155,7 @@ void prefault(const std::vector<OutSpec> &outs, int64_t T, int64_t N)
             const size_t lo = (size_t)k * chunk;
             if (lo >= bytes) break;
             const size_t hi = (lo + chunk < bytes) ? lo + chunk : bytes;
-            pool.emplace_back([base, lo, hi, page]() {
+            pool.emplace_back([base, lo, hi]() {
                 for (size_t p = lo; p < hi; p += page)
                     *(volatile char *)(base + p) = 0;
             });
