@@ -32,8 +32,8 @@ if REPO not in sys.path:
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # Algorithmic bytes per model-timestep: 8 B, the qsim
-# element, in the default mode.  Forcing (32 B/day shared by all sets) and the
-# parameter block (88 B/set, read once) amortise to ~0 (40 B/day record).
+# element, in the default mode.  Forcing (40 B/day shared by all sets) and the
+# parameter block (88 B/set, read once) amortise to ~0.
 
 
 def parse_args():
