@@ -223,3 +223,38 @@ def test_next_tier_fit_losses(models):
     qi = oi["qsim"][:, 0]
     li = himod._loss(Xi, obs, layers, g["frac_ice"], inits, "kge")
     assert abs(li - (1 - calc_kge(obs, qi))) < 1e-12
+
+
+def test_next_tier_resident_ensembles_match_host_path(models):
+    """rrmpg_amd.device.SnowGR4JEnsemble (the *_dev entry points with torch
+    memory) gives the same discharge and scores as the host-pointer path."""
+    import torch
+    from rrmpg_amd import device as rrdev
+    from rrmpg_amd.models import _snowgr4j as core
+    h = golden("syn_cemaneigehystgr4j")
+    t = 900
+    layers = tuple(h[k][:t] for k in ("layer_prec", "layer_mean",
+                                      "frac_solid", "etp"))
+    fice = np.array([0.0, 0.1, 0.3, 0.6, 0.9])
+    inits = (3.0, -0.2, 0.4, 0.5, 0.6)
+    for (hyst, ice), cls in [((True, False), models.CemaneigeHystGR4J),
+                             ((False, True), models.CemaneigeGR4JIce),
+                             ((True, True), models.CemaneigeHystGR4JIce)]:
+        np.random.seed(21)
+        p = cls().get_random_params(130)
+        out, _ = core.run(hyst, ice, layers, fice if ice else None, inits, p,
+                          True, False, None)
+        qobs_h = out["qsim"][:, 3] * 0.9 + 0.05
+        _, sse_h = core.run(hyst, ice, layers, fice if ice else None, inits,
+                            p, False, False, qobs_h)
+        ens = rrdev.SnowGR4JEnsemble(
+            hyst, ice, layers[0], layers[1], layers[2], layers[3],
+            frac_ice=fice if ice else None, snow_pack_init=inits[0],
+            thermal_state_init=inits[1], sca_init=inits[2], s_init=inits[3],
+            r_init=inits[4])
+        params = ens.upload_params(p)
+        q = ens.new_output(130)
+        sse = ens.run(params, q, qobs=torch.from_numpy(qobs_h).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(q.cpu().numpy(), out["qsim"])
+        assert np.array_equal(sse.cpu().numpy(), sse_h)
