@@ -64,6 +64,11 @@ def parse_args():
                          "ONE GPU to rehearse the multi-rank code path on a "
                          "single-GPU box (scores gathered on the host)")
     ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--sampler", default="device", choices=["device", "host"],
+                    help="device: every rank draws its shard of ONE global "
+                         "population in HBM (rr_sample_params_dev, numpy's "
+                         "Philox stream); host: Model.get_random_params + "
+                         "upload, as the reference does")
     return ap.parse_args()
 
 
@@ -127,8 +132,16 @@ def build_workload(args, device, rank):
                                           layers[3], 0., 0., 0.6, 0.7,
                                           device=device)
         name = "CemaneigeGR4J(L=5)"
-    params_host = cls().get_random_params(n)
-    params = ens.upload_params(params_host)
+    if args.sampler == "device":
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        params = rrdev.sample_params(cls(), n, syn.FORCING_SEED,
+                                     n_total=n * world, first=rank * n,
+                                     device=device)
+        params_host = params[:min(n, 400000)].cpu().numpy()
+    else:
+        rec = cls().get_random_params(n)
+        params = ens.upload_params(rec)
+        params_host = np.stack([rec[k] for k in cls._param_list], 1)
     # synthetic observations: the first set's run + 10 % noise
     q0 = ens.new_output(1)
     ens.run(params[:1].contiguous(), q0)
@@ -171,8 +184,9 @@ def build_catchments(args, device, rank):
                                  device=device)
     np.random.seed(1 + rank)
     cls = models.HBVEdu
-    params_host = cls().get_random_params(c * n)
-    flat = np.stack([params_host[k] for k in cls._param_list], 1)
+    rec = cls().get_random_params(c * n)
+    flat = np.stack([rec[k] for k in cls._param_list], 1)
+    params_host = flat
     params = torch.from_numpy(flat.reshape(c, n, 11)).to(device)
     q0 = ens.new_output(1)
     ens.run(params[:, :1].contiguous(), q0)
@@ -190,12 +204,11 @@ def cpu_baseline(args, f, params_host):
     host cores on a bounded sample of the same workload.  Checker code: it is
     only timed here, never used to produce the GPU result."""
     from oracle import pyoracle
-    from rrmpg_amd.models import HBVEdu
     from rrmpg_amd.utils import synthetic as syn
     if args.model != "hbvedu":
         return None
     cores = pyoracle.max_threads()
-    flat = np.stack([params_host[k] for k in HBVEdu._param_list], 1)
+    flat = np.ascontiguousarray(params_host)      # [sets, 11]
     m0 = (f["month"] - 1).astype(np.int8)
     inits = [syn.HBV_INITS[k] for k in ("snow_init", "soil_init", "s1_init",
                                         "s2_init")]
@@ -355,6 +368,7 @@ def main():
                 "timesteps": t,
                 "mode": args.mode,
                 "sharding": "parameter sets, one contiguous block per GPU",
+                "sampler": args.sampler if args.catchments == 0 else "host",
             },
             "roofline": {
                 "bound": "hbm",

@@ -221,6 +221,28 @@ int rr_cemaneigegr4j_simulate(const double *prec, const double *mean_temp,
 int rr_column_sums_dev(const double *qsim, int64_t ld, const double *obs,
                        int64_t T, int64_t N, double *sums, void *stream);
 
+/* ---- Monte-Carlo parameter sets drawn in HBM ------------------------------
+ * Fills params[n][k] (device, the AoS block every rr_*_simulate_dev takes)
+ * with uniform draws -- replaces BaseModel.get_random_params (reference:
+ * rrmpg/models/basemodel.py:68-91; ABC's rule b ~ U(0, 1 - a):
+ * rrmpg/models/abcmodel.py:70-103) plus the upload of its result.
+ * The stream is numpy's Philox bit generator, reproducible on a host as
+ *     rng = numpy.random.Generator(numpy.random.Philox(key=key))
+ *     for j in draw order: column_j = rng.uniform(lo[j], hi[j], size=n_total)
+ * and this call writes rows n0 .. n0+n-1 of that n_total-row population (so
+ * ranks draw their shards of one population independently).  lo, hi
+ * (host, [k]) are the bounds in parameter order; draw_pos (host, [k], or
+ * NULL = parameter order) is each parameter's rank in the draw order;
+ * hi_one_minus_first = j > 0 makes parameter j's upper bound 1 - params[i][0]
+ * (ABC: j = 1), 0 disables it.  (The reference's sampler uses numpy's legacy
+ * global MT19937 stream; that remains available, unchanged, as
+ * Model.get_random_params on the host.) */
+#define RR_SAMPLE_MAX_PARAMS 16
+int rr_sample_params_dev(uint64_t key, int k, const double *lo,
+                         const double *hi, const int *draw_pos,
+                         int hi_one_minus_first, int64_t n_total, int64_t n0,
+                         int64_t n, double *params, void *stream);
+
 /* ==== next tier: SWE-SCA hysteresis snow routine, ice melt, couplings ====
  * The reference's CemaneigeHystGR4J, CemaneigeGR4JIce, CemaneigeHystGR4JIce
  * (SURVEY.md section 8f N1).  Same conventions as above; 1 <= L <= 8;

@@ -34,6 +34,10 @@ _SIGNATURES = {
     "rr_get_device": (ctypes.c_int, []),
     "rr_column_sums_dev": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp,
                                           _vp]),
+    "rr_sample_params_dev": (ctypes.c_int,
+                             [ctypes.c_uint64, ctypes.c_int, _f64p, _f64p,
+                              ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                              _i64, _i64, _i64, _vp, _vp]),
     "rr_abc_workspace_bytes": (_sz, [_i64, _i64]),
     "rr_abc_simulate_dev": (ctypes.c_int, [_vp, _i64, _dbl, _vp, _i64, _vp,
                                            _vp, _i64, _vp, _vp, _vp, _sz,

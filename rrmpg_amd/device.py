@@ -12,6 +12,8 @@ One process drives one GPU; several GPUs = several processes, each with its
 own shard of the parameter-set axis (rrmpg_amd.sharding).
 """
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -389,3 +391,67 @@ def column_sums(qsim, obs):
                                     qsim.device).cuda_stream)
     _lib.check(rc, "rr_column_sums_dev")
     return sums
+
+
+def sample_params(model, num, key, n_total=None, first=0, device=None):
+    """Draw `num` parameter sets of `model` inside its default bounds directly
+    in HBM (rr_sample_params_dev) -- the resident counterpart of
+    ``model.get_random_params(num)`` (reference: rrmpg/models/basemodel.py:
+    68-91, ABC rule abcmodel.py:70-103) without the N x k x 8 B upload.
+
+    Returns a float64 tensor [num, k] in _param_list order, ready for the
+    ensembles' ``run``.  The draws are rows ``first .. first+num-1`` of the
+    population a host reproduces with::
+
+        rng = numpy.random.Generator(numpy.random.Philox(key=key))
+        cols = [rng.uniform(lo, hi, size=n_total) for each parameter
+                in the model's draw order]
+
+    (draw order = _param_list order; for the ABC model a, c, then b with the
+    upper bound 1 - a, as the reference draws them).  ``host_population`` below
+    is exactly that restatement.
+    """
+    lib = _lib.load()
+    _lib.require_gpu()
+    names = list(model._param_list)
+    k = len(names)
+    n_total = num if n_total is None else int(n_total)
+    lo = np.array([model._default_bounds[p][0] for p in names], np.float64)
+    hi = np.array([model._default_bounds[p][1] for p in names], np.float64)
+    pos, one_minus = _draw_plan(model)
+    dev = torch.device("cuda", torch.cuda.current_device()) \
+        if device is None else torch.device(device)
+    out = torch.empty((num, k), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rr_sample_params_dev(
+            int(key), k, _lib.f64(lo)[1], _lib.f64(hi)[1],
+            pos.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), one_minus,
+            n_total, int(first), int(num), out.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "rr_sample_params_dev")
+    return out
+
+
+def _draw_plan(model):
+    """(rank of each parameter in the draw order, index of the parameter
+    whose upper bound is 1 - first parameter or 0)."""
+    names = list(model._param_list)
+    if names == ["a", "b", "c"]:            # ABC: a, c, then b | a
+        return np.array([0, 2, 1], dtype=np.intc), 1
+    return np.arange(len(names), dtype=np.intc), 0
+
+
+def host_population(model, n_total, key):
+    """The population ``sample_params`` draws from, built on the host with
+    numpy's Philox generator -- float64 array [n_total, k]."""
+    names = list(model._param_list)
+    pos, one_minus = _draw_plan(model)
+    rng = np.random.Generator(np.random.Philox(key=int(key)))
+    out = np.empty((n_total, len(names)))
+    for rank in range(len(names)):
+        j = int(np.nonzero(pos == rank)[0][0])
+        lo, hi = model._default_bounds[names[j]]
+        if one_minus and j == one_minus:
+            hi = 1 - out[:, 0]
+        out[:, j] = rng.uniform(lo, hi, size=n_total)
+    return out
