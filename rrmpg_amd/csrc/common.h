@@ -40,11 +40,43 @@ __device__ __forceinline__ double nb_min(double a, double b) {
 // rrdbg_divide_by_invariant does the same on the device).
 #include "invdiv.h"
 
+// Wave votes as lane-mask arithmetic.  hipcc compiles __any()/__all() (and
+// the ballot of any bool that is not directly a comparison) into a
+// mask -> VGPR -> v_cmp round trip, 2 VALU instructions per vote.  The ballot
+// of a comparison is just the SGPR pair that comparison wrote, so votes over
+// combined conditions are built from per-comparison masks with scalar
+// and/or/not, which cost no VALU issue slot at all.
+typedef unsigned long long lanemask_t;
+#define RR_LANES(cmp) ((lanemask_t)__builtin_amdgcn_ballot_w64(cmp))
+__device__ __forceinline__ lanemask_t rr_exec() { return RR_LANES(true); }
+__device__ __forceinline__ bool wave_any(bool p) { return RR_LANES(p) != 0; }
+__device__ __forceinline__ bool wave_all(bool p) { return RR_LANES(!p) == 0; }
+
+// lanes whose |a| lies in the numerator range of inv_div_core
+__device__ __forceinline__ lanemask_t inv_div_numerator_mask(double a) {
+    return RR_LANES(fabs(a) >= 0x1p-900) & RR_LANES(fabs(a) <= 0x1p900);
+}
+
+// a / d.b with the vote done on masks: a_ok = inv_div_numerator_mask(a)
+// (shared by all quotients of one numerator), d_ok = RR_LANES(d.ok), hoisted
+// out of the time loop by the caller.
+__device__ __forceinline__ double div_by_invariant_m(double a, lanemask_t a_ok,
+                                                     const InvDivisor &d,
+                                                     lanemask_t d_ok) {
+    double q = inv_div_core(a, d);
+    if (rr_exec() & ~(a_ok & d_ok)) {
+        const bool ok = inv_div_numerator_ok(a) && d.ok;
+        const double exact = a / d.b;
+        q = ok ? q : exact;
+    }
+    return q;
+}
+
 __device__ __forceinline__ double div_by_invariant(double a, bool a_ok,
                                                    const InvDivisor &d) {
     double q = inv_div_core(a, d);
     const bool ok = a_ok && d.ok;
-    if (__any(!ok)) {
+    if (wave_any(!ok)) {
         const double exact = a / d.b;
         q = ok ? q : exact;
     }

@@ -132,7 +132,7 @@ struct UhRegs {
                     o2[j] * p2;
         const bool finite = (__builtin_fabs(p1) < __builtin_inf()) &&
                             (__builtin_fabs(p2) < __builtin_inf());
-        if (!__all(finite)) {
+        if (!wave_all(finite)) {
 #pragma unroll
             for (int j = 0; j < N1MAX; ++j) u1[j] = (j < n1) ? u1[j] : 0.0;
 #pragma unroll
@@ -226,7 +226,7 @@ struct UhLds {
         }
         const bool finite = (__builtin_fabs(p1) < __builtin_inf()) &&
                             (__builtin_fabs(p2) < __builtin_inf());
-        if (!__all(finite)) {
+        if (!wave_all(finite)) {
             for (int j = 0; j < n1w; ++j)
                 if (j >= n1) U1(j) = 0.0;
             for (int j = 0; j < n2w; ++j)

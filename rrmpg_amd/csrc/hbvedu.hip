@@ -119,6 +119,9 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     const double soil_lo = FC * 0x1p-9, soil_hi = FC * 0x1p9;
     const bool box_ok = (FC > 0x1p-500) && (FC < 0x1p500) &&
                         (fabs(Beta) <= 64.0);
+    // loop-invariant lane masks for the wave votes (common.h)
+    const lanemask_t box_m = RR_LANES(box_ok);
+    const lanemask_t fc_m = RR_LANES(inv_FC.ok), pwp_m = RR_LANES(inv_PWP.ok);
 
     double snow = snow_init, soil = soil_init, s1 = s1_init, s2 = s2_init;
     double acc = 0.0;
@@ -160,29 +163,37 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         // altogether.  Outside that box (NaN/inf/zero/negative operands, huge
         // Beta) both are evaluated and 0 * inf / 0 * NaN propagate exactly as
         // in the reference.
-        const bool soil_ok = inv_div_numerator_ok(soil);
-        const bool need_pow =
-            (liquid_water != 0.0) ||
-            !(soil >= soil_lo && soil <= soil_hi && box_ok);
+        const lanemask_t soil_m = inv_div_numerator_mask(soil);
+        // lanes that need the power: wet, or outside the box (votes are done
+        // on lane masks, common.h)
+        const lanemask_t need_m =
+            RR_LANES(liquid_water != 0.0) |
+            ~(RR_LANES(soil >= soil_lo) & RR_LANES(soil <= soil_hi) & box_m);
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
-        if (__any(need_pow)) {
-            const double wetness = div_by_invariant(soil, soil_ok, inv_FC);
+        if (need_m & rr_exec()) {
+            const double wetness = div_by_invariant_m(soil, soil_m, inv_FC,
+                                                      fc_m);
             // fastmath.h: ~1 ulp, a third of the general pow's instructions;
             // arguments outside its domain take the general pow (wave-wide)
             double z;
             double pw = fastpow_core(wetness, Beta, &z);
-            const bool fast_ok = fastpow_ok(wetness, z);
-            if (__any(need_pow && !fast_ok)) {
+            const lanemask_t fast_m = RR_LANES(wetness > 0.0) &
+                                      RR_LANES(wetness < __builtin_inf()) &
+                                      RR_LANES(fabs(z) < 1000.0);
+            if (rr_exec() & ~fast_m) {
                 const double general = pow_general(wetness, Beta);
-                pw = fast_ok ? pw : general;
+                pw = fastpow_ok(wetness, z) ? pw : general;
             }
-            prec_eff = need_pow ? liquid_water * pw : liquid_water;
+            // lanes of this wave that did not need the power sit inside the
+            // box with liquid_water == 0: their pw is finite (|z| <= 64 * 9.1)
+            // and 0 * pw is the 0 they already hold, so no select is needed
+            prec_eff = liquid_water * pw;
         }
 
         // potential / actual evapotranspiration (:102-108)
         const double pe = (1 + C * f.dtemp) * f.pe_m;
         const double ea = (soil > PWP)
-            ? pe : pe * div_by_invariant(soil, soil_ok, inv_PWP);
+            ? pe : pe * div_by_invariant_m(soil, soil_m, inv_PWP, pwp_m);
 
         // soil moisture (:111)
         const double soil_n = soil + liquid_water - prec_eff - ea;
