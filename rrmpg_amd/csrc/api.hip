@@ -384,14 +384,15 @@ extern "C" int rr_cemaneigegr4j_simulate(
 }
 
 // ---- device self-test hook (not part of include/rrhip.h) -------------------
-// out[i] = div_by_invariant(a[i], b[i]) and ref[i] = a[i] / b[i], host arrays.
+// out[i] = div_by_invariant_m(a[i], b[i]) and ref[i] = a[i] / b[i], host arrays.
 __global__ void dbg_div_kernel(const double *a, const double *b, double *out,
                                double *ref, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double av = (i < n) ? a[i] : 1.0, bv = (i < n) ? b[i] : 1.0;
     const InvDivisor d = make_inv_divisor(bv);
-    const double q = div_by_invariant(av, inv_div_numerator_ok(av), d);
+    const double q = div_by_invariant_m(av, inv_div_numerator_mask0(av), d,
+                                        RR_LANES(d.ok));
     if (i < n) {
         out[i] = q;
         ref[i] = av / bv;

@@ -88,10 +88,12 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const double omc = 1 - CTG;
     double G[L], eTG[L];
     InvDivisor inv_gt[L];
+    lanemask_t gt_m[L];          // lanes whose threshold suits the 3-FMA quotient
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         G[l] = 0.0; eTG[l] = 0.0;
         inv_gt[l] = make_inv_divisor(gtresh[l]);
+        gt_m[l] = RR_LANES(inv_gt[l].ok);
     }
     double acc = 0.0;
     const bool wq = outflow != nullptr, ws = G_out != nullptr,
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
         double rec[3 * L];
 #pragma unroll
         for (int k = 0; k < 3 * L; ++k) rec[k] = days[t * (3 * L) + k];
-        const double q = cema_day<L>(rec, inv_gt, t == 0,
+        const double q = cema_day<L>(rec, inv_gt, gt_m, t == 0,
                                      snow_pack_init, thermal_state_init, CTG,
                                      omc, Kf, G, eTG);
         if (active) {
@@ -155,10 +157,12 @@ cemaneigegr4j_kernel(
     const double omc = 1 - CTG;
     double G[L], eTG[L];
     InvDivisor inv_gt[L];
+    lanemask_t gt_m[L];          // lanes whose threshold suits the 3-FMA quotient
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         G[l] = 0.0; eTG[l] = 0.0;
         inv_gt[l] = make_inv_divisor(gtresh[l]);
+        gt_m[l] = RR_LANES(inv_gt[l].ok);
     }
     UH uh;
     if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
@@ -171,7 +175,7 @@ cemaneigegr4j_kernel(
         double day[D];          // by value: one wide scalar load per day
 #pragma unroll
         for (int k = 0; k < D; ++k) day[k] = days[t * D + k];
-        const double liquid = cema_day<L>(day, inv_gt, t == 0, snow_pack_init,
+        const double liquid = cema_day<L>(day, inv_gt, gt_m, t == 0, snow_pack_init,
                                           thermal_state_init, CTG, omc, Kf, G,
                                           eTG);
         const double q = gr4j_step(P, s, r, uh, liquid, day[3 * L]);

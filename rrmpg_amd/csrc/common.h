@@ -56,29 +56,32 @@ __device__ __forceinline__ bool wave_all(bool p) { return RR_LANES(!p) == 0; }
 __device__ __forceinline__ lanemask_t inv_div_numerator_mask(double a) {
     return RR_LANES(fabs(a) >= 0x1p-900) & RR_LANES(fabs(a) <= 0x1p900);
 }
+// ... or holds +0 (invdiv.h: inv_div_numerator_ok0).  One v_cmp_class_f64
+// (class bit 6 = +0) written directly into an SGPR pair; spelled as an
+// integer or class test in C++ it goes through the VGPR round trip above.
+__device__ __forceinline__ lanemask_t lanes_plus_zero(double a) {
+    lanemask_t m;
+    asm("v_cmp_class_f64 %0, %1, 0x40" : "=s"(m) : "v"(a));
+    return m;
+}
+__device__ __forceinline__ lanemask_t inv_div_numerator_mask0(double a) {
+    return (RR_LANES(fabs(a) >= 0x1p-900) | lanes_plus_zero(a)) &
+           RR_LANES(fabs(a) <= 0x1p900);
+}
 
-// a / d.b with the vote done on masks: a_ok = inv_div_numerator_mask(a)
-// (shared by all quotients of one numerator), d_ok = RR_LANES(d.ok), hoisted
-// out of the time loop by the caller.
+// a / d.b, bit-identical to `/` for EVERY input, with the vote done on lane
+// masks: a_ok = inv_div_numerator_mask[0](a) (shared by all quotients of one
+// numerator), d_ok = RR_LANES(d.ok), hoisted out of the time loop by the
+// caller.  If any active lane is outside the fast form's domain the whole
+// wave evaluates the IEEE division and those lanes take it.
 __device__ __forceinline__ double div_by_invariant_m(double a, lanemask_t a_ok,
                                                      const InvDivisor &d,
                                                      lanemask_t d_ok) {
     double q = inv_div_core(a, d);
     if (rr_exec() & ~(a_ok & d_ok)) {
-        const bool ok = inv_div_numerator_ok(a) && d.ok;
+        const bool ok = inv_div_numerator_ok0(a) && d.ok;
         const double exact = a / d.b;
-        q = ok ? q : exact;
-    }
-    return q;
-}
-
-__device__ __forceinline__ double div_by_invariant(double a, bool a_ok,
-                                                   const InvDivisor &d) {
-    double q = inv_div_core(a, d);
-    const bool ok = a_ok && d.ok;
-    if (wave_any(!ok)) {
-        const double exact = a / d.b;
-        q = ok ? q : exact;
+        q = ok ? q : exact;        // ok lanes: both values are RN(a / b)
     }
     return q;
 }

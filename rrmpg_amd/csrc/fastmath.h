@@ -176,7 +176,9 @@ FP_FN bool fastpow_ok(double x, double z)
 // makes +-inf give +-1); NaN propagates; tanh(+-0) = +-0.  Error <= ~2.5 ulp
 // (libm: 1 ulp), measured by tests/native/fastmath_harness.cpp.
 // Used for np.tanh(p_n / x1) of GR4J (reference: gr4j_model.py:95-96, 107-108).
-FP_FN double fast_tanh(double a)
+// fast_tanh_parts gives numerator and denominator (tanh(a) = num / den,
+// den >= 2) so that a caller can fold the quotient into one of its own.
+FP_FN void fast_tanh_parts(double a, double &num, double &den)
 {
     const double ax = __builtin_fabs(a);
     const double x = (ax > 20.0) ? 20.0 : ax;        // NaN stays NaN
@@ -199,8 +201,15 @@ FP_FN double fast_tanh(double a)
     const double p = FP_FMA(r * r, q, r);            // expm1(r)
     const double two_n = FP_LDEXP(1.0, (int)n);
     const double E = FP_FMA(two_n, p, two_n - 1.0);  // expm1(2|a|)
-    const double t = E / (E + 2.0);
-    return __builtin_copysign(t, a);
+    num = __builtin_copysign(E, a);
+    den = E + 2.0;
+}
+
+FP_FN double fast_tanh(double a)
+{
+    double num, den;
+    fast_tanh_parts(a, num, den);
+    return num / den;
 }
 
 // ---------------------------------------------------------------------------

@@ -13,20 +13,31 @@
 
 #include "gr4j_core.h"
 
-struct __attribute__((aligned(16))) GrDay {
-    double prec;
-    double etp;
+// One day of shared forcing as the kernel wants it (fetched by value with one
+// s_load_dwordx8 per day).  Which branch of the reference's net-rainfall /
+// net-evaporation split applies (gr4j_model.py:89-111) and the net amount do
+// not depend on the parameters, so the pre-pass evaluates them once per day
+// instead of every lane doing it with vector instructions.
+struct __attribute__((aligned(32))) GrDay {
+    double net;      // prec - etp if wet else etp - prec (:90, :102)
+    double qobs;     // the day's observation (0 when no metric is fused)
+    int wet;         // prec >= etp (:89)
+    int pad[3];
 };
 
 __global__ void gr4j_pack_forcing(const double *__restrict__ prec,
-                                  const double *__restrict__ etp, int64_t T,
+                                  const double *__restrict__ etp,
+                                  const double *__restrict__ qobs, int64_t T,
                                   GrDay *__restrict__ days)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
+    const double p = prec[t], e = etp[t];
     GrDay d;
-    d.prec = prec[t];
-    d.etp = etp[t];
+    d.wet = p >= e;
+    d.net = d.wet ? p - e : e - p;
+    d.qobs = qobs ? qobs[t] : 0.0;
+    d.pad[0] = d.pad[1] = d.pad[2] = 0;
     days[t] = d;
 }
 
@@ -86,8 +97,8 @@ __global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
     int64_t off = i;
 
     for (int64_t k = 0; k < T; ++k) {
-        const GrDay f = days[k];    // wave-uniform -> s_load_dwordx4
-        const double q = gr4j_step(P, s, r, uh, f.prec, f.etp);
+        const GrDay f = days[k];    // wave-uniform -> s_load_dwordx8
+        const double q = gr4j_step_net(P, s, r, uh, f.net, f.wet != 0);
         if (active) {
             if (Q) qsim[off] = q;
             if (S) {
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
             }
         }
         if (E) {
-            const double d = qobs[k] - q;
+            const double d = f.qobs - q;
             acc += d * d;
         }
         off += ld;
@@ -180,7 +191,7 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     rc = rr_gr4j_plan(params, N, 4, 3, d_scan, st, &tier, &n1cap, &n2cap);
     if (rc != RR_OK) return rc;
     hipLaunchKernelGGL(gr4j_pack_forcing, dim3((unsigned)rr_ceil_div(T, 256)),
-                       dim3(256), 0, st, prec, etp, T, days);
+                       dim3(256), 0, st, prec, etp, qobs, T, days);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const bool q = qsim != nullptr, s = s_store != nullptr, e = qobs && sse;
     const size_t lds_bytes =

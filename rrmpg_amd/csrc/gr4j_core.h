@@ -28,18 +28,23 @@
 struct Gr4jPar {
     double x1, x2, x3, x4;
     InvDivisor inv_x1, inv_x3;   // x1, x3 divide five quantities every day
+    lanemask_t x1_m, x3_m;       // lanes whose x1 / x3 suit the 3-FMA quotient
     __device__ __forceinline__ void set(double a, double b, double c, double d)
     {
         x1 = a; x2 = b; x3 = c; x4 = d;
         inv_x1 = make_inv_divisor(a);
         inv_x3 = make_inv_divisor(c);
+        x1_m = RR_LANES(inv_x1.ok);
+        x3_m = RR_LANES(inv_x3.ok);
     }
 };
 
-// a / x for the per-lane invariant x (bit-identical to `/`, see common.h)
-__device__ __forceinline__ double gr4j_div(double a, const InvDivisor &d)
+// a / x for the per-lane invariant x (bit-identical to `/`, see common.h);
+// stores run dry, so exact zeros stay on the fast form
+__device__ __forceinline__ double gr4j_div(double a, const InvDivisor &d,
+                                           lanemask_t d_ok)
 {
-    return div_by_invariant(a, inv_div_numerator_ok(a), d);
+    return div_by_invariant_m(a, inv_div_numerator_mask0(a), d, d_ok);
 }
 
 // _s_curve1 (gr4j_model.py:159-173); t is the integer ordinate index
@@ -115,8 +120,11 @@ struct UhRegs {
     //     uh[j] = uh[j+1] + ord[j]*p   for every j < MAX  (uh[MAX] := 0)
     // gives the same values: slot n-1 becomes 0 + ord*p and, for finite p,
     // the padding stays 0 + 0*p = 0 (only the sign of an exact zero can
-    // differ).  That is 2 instructions per slot instead of 5 (no per-lane
-    // selects).  A non-finite p (never in a sane run) leaves the real slots
+    // differ).  Each slot is ONE fused multiply-add (the product is not
+    // rounded separately as numba's fmul/fadd pair would; a <= 1/2-ulp
+    // difference per slot that belongs to the few-ulp budget of the GR4J
+    // family, see "transcendental calls" below) instead of 5 instructions
+    // with per-lane selects.  A non-finite p (never in a sane run) leaves the real slots
     // right as well -- they only read padding that was still zero -- but
     // writes 0*NaN into the padding, so on such days the wave re-zeroes it.
     __device__ __forceinline__ void route(double p1, double p2, double &head1,
@@ -124,15 +132,17 @@ struct UhRegs {
     {
 #pragma unroll
         for (int j = 0; j < N1MAX; ++j)
-            u1[j] = ((j + 1 < N1MAX) ? u1[(j + 1 < N1MAX) ? j + 1 : j] : 0.0) +
-                    o1[j] * p1;
+            u1[j] = __builtin_fma(
+                o1[j], p1,
+                (j + 1 < N1MAX) ? u1[(j + 1 < N1MAX) ? j + 1 : j] : 0.0);
 #pragma unroll
         for (int j = 0; j < N2MAX; ++j)
-            u2[j] = ((j + 1 < N2MAX) ? u2[(j + 1 < N2MAX) ? j + 1 : j] : 0.0) +
-                    o2[j] * p2;
-        const bool finite = (__builtin_fabs(p1) < __builtin_inf()) &&
-                            (__builtin_fabs(p2) < __builtin_inf());
-        if (!wave_all(finite)) {
+            u2[j] = __builtin_fma(
+                o2[j], p2,
+                (j + 1 < N2MAX) ? u2[(j + 1 < N2MAX) ? j + 1 : j] : 0.0);
+        const lanemask_t finite = RR_LANES(__builtin_fabs(p1) < __builtin_inf()) &
+                                  RR_LANES(__builtin_fabs(p2) < __builtin_inf());
+        if (rr_exec() & ~finite) {
 #pragma unroll
             for (int j = 0; j < N1MAX; ++j) u1[j] = (j < n1) ? u1[j] : 0.0;
 #pragma unroll
@@ -214,19 +224,19 @@ struct UhLds {
     {
         for (int j = 0; j < n1w; ++j) {
             const double nxt = (j + 1 < n1w) ? U1(j + 1) : 0.0;
-            const double nv = nxt + O1(j) * p1;
+            const double nv = __builtin_fma(O1(j), p1, nxt);
             U1(j) = nv;
             if (j == 0) head1 = nv;
         }
         for (int j = 0; j < n2w; ++j) {
             const double nxt = (j + 1 < n2w) ? U2(j + 1) : 0.0;
-            const double nv = nxt + O2(j) * p2;
+            const double nv = __builtin_fma(O2(j), p2, nxt);
             U2(j) = nv;
             if (j == 0) head2 = nv;
         }
-        const bool finite = (__builtin_fabs(p1) < __builtin_inf()) &&
-                            (__builtin_fabs(p2) < __builtin_inf());
-        if (!wave_all(finite)) {
+        const lanemask_t finite = RR_LANES(__builtin_fabs(p1) < __builtin_inf()) &
+                                  RR_LANES(__builtin_fabs(p2) < __builtin_inf());
+        if (rr_exec() & ~finite) {
             for (int j = 0; j < n1w; ++j)
                 if (j >= n1) U1(j) = 0.0;
             for (int j = 0; j < n2w; ++j)
@@ -252,7 +262,8 @@ static inline void gr4j_dispatch_uh(int tier, F &&f)
 // The transcendental calls of the daily step (reference: 1 tanh + 3 pow) are
 // evaluated with fastmath.h instead of OCML's general tanh / pow (165 / 224
 // VALU instructions each):
-//   np.tanh(.)            -> fast_tanh, <= ~2.5 ulp;
+//   np.tanh(.)            -> fast_tanh_parts, <= ~2.5 ulp, its quotient
+//                            merged with the store update's (gr4j_step);
 //   (1 + v**4)**(-0.25)   -> inv_fourth_root, ~1 ulp (Newton on y^-4 = b);
 //   (r/x3)**3.5           -> x*x*x*sqrt(x) with a correctly rounded sqrt,
 //                            <= ~2.5 ulp; 0 -> 0, inf -> inf, x < 0 -> NaN
@@ -267,25 +278,29 @@ __device__ __forceinline__ double pow_3_5(double x)
 
 // One day of GR4J (gr4j_model.py:86-154).  s, r: production / routing store
 // (in/out).  Returns the simulated discharge of the day.
+// `wet` / `net`: net rainfall or net evapotranspiration (:89-111) -- which
+// branch applies and the net amount.  Both branches of the reference share
+// one shape: a tanh of the net amount over x1, one quotient; only the branch
+// that applies is evaluated.  (The plain GR4J kernel gets wet/net from its
+// pre-pass, wave-uniform; the coupled kernels compute them per lane.)
 template <class UH>
-__device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
-                                            double &r, UH &uh, double prec,
-                                            double etp)
+__device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
+                                                double &r, UH &uh, double net,
+                                                bool wet)
 {
-    // net rainfall or net evapotranspiration (:89-111).  Both branches of the
-    // reference share one shape: a tanh of the net amount over x1, one
-    // quotient; only the branch that applies is evaluated.
-    const bool wet = prec >= etp;
-    const double net = wet ? prec - etp : etp - prec;
-    const double sx = gr4j_div(s, P.inv_x1);
-    const double th = fast_tanh(gr4j_div(net, P.inv_x1));
+    const double sx = gr4j_div(s, P.inv_x1, P.x1_m);
+    // tanh(net/x1) = E / D (fastmath.h); its quotient is folded into the
+    // store update's own:  c*th / (1 + k*th) == c*E / (D + k*E), one
+    // division per day instead of two
+    double E, D;
+    fast_tanh_parts(gr4j_div(net, P.inv_x1, P.x1_m), E, D);
     double num, den;
     if (wet) {
-        num = P.x1 * (1 - sx * sx) * th;            // eq. 3 (:95-96)
-        den = 1 + sx * th;
+        num = P.x1 * (1 - sx * sx) * E;             // eq. 3 (:95-96)
+        den = D + sx * E;
     } else {
-        num = s * (2 - sx) * th;                    // eq. 4 (:107-108)
-        den = 1 + (1 - sx) * th;
+        num = s * (2 - sx) * E;                     // eq. 4 (:107-108)
+        den = D + (1 - sx) * E;
     }
     const double frac = num / den;
     const double p_n = wet ? net : 0.0;
@@ -294,7 +309,7 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
 
     double sn = s - e_s + p_s;                                  // :114
     // percolation (:117); **4 is two squarings
-    const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1);
+    const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1, P.x1_m);
     const double v2 = v * v;
     const double perc = sn * (1 - inv_fourth_root(1 + v2 * v2));
     sn = sn - perc;                                             // :120
@@ -305,9 +320,10 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
     double head1, head2;
     uh.route(p_r_uh1, p_r_uh2, head1, head2);                   // :130-136
 
-    const double gw_exchange = P.x2 * pow_3_5(gr4j_div(r, P.inv_x3)); // :139
+    const double gw_exchange =
+        P.x2 * pow_3_5(gr4j_div(r, P.inv_x3, P.x3_m));          // :139
     double rn = nb_max(0.0, r + head1 + gw_exchange);           // :142
-    const double w = gr4j_div(rn, P.inv_x3);
+    const double w = gr4j_div(rn, P.inv_x3, P.x3_m);
     const double w2 = w * w;
     const double q_r = rn * (1 - inv_fourth_root(1 + w2 * w2)); // :145
     rn = rn - q_r;                                              // :148
@@ -315,4 +331,14 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
     s = sn;
     r = rn;
     return q_r + q_d;                                           // :154
+}
+
+template <class UH>
+__device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
+                                            double &r, UH &uh, double prec,
+                                            double etp)
+{
+    const bool wet = prec >= etp;                               // :89
+    const double net = wet ? prec - etp : etp - prec;           // :90, :102
+    return gr4j_step_net(P, s, r, uh, net, wet);
 }

@@ -29,7 +29,15 @@ ID_FN bool inv_div_numerator_ok(double a) {
     return (fabs(a) >= 0x1p-900) && (fabs(a) <= 0x1p900);
 }
 
-// valid (== RN(a / b)) when inv_div_numerator_ok(a) && d.ok
+// ... or a is +0: q0 = +-0, r = +0 and the final FMA returns q0, the
+// correctly signed zero a / b (stores that have run dry, an empty snow pack:
+// common numerators, worth their own compare).  Not -0: there the final FMA
+// gives (+0) + (-0) = +0 where the quotient is -0.
+ID_FN bool inv_div_numerator_ok0(double a) {
+    return inv_div_numerator_ok(a) || (a == 0.0 && !__builtin_signbit(a));
+}
+
+// valid (== RN(a / b)) when inv_div_numerator_ok[0](a) && d.ok
 ID_FN double inv_div_core(double a, const InvDivisor &d) {
     const double q0 = a * d.rb;
     const double r = __builtin_fma(-d.b, q0, a);

@@ -41,7 +41,7 @@ static inline size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp, int64_t 
 template <int L>
 __device__ __forceinline__ double cema_day(
     const double *__restrict__ day, const InvDivisor (&inv_gt)[L],
-    bool first, double snow_pack_init, double thermal_state_init, double CTG,
+    const lanemask_t (&gt_m)[L], bool first, double snow_pack_init, double thermal_state_init, double CTG,
     double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L])
 {
     double c = 0.0;
@@ -62,13 +62,25 @@ __device__ __forceinline__ double cema_day(
             pot_melt = Kf * temp;
             if (pot_melt > g) pot_melt = g;
         }
-        // G / G_tresh: the threshold is fixed for the whole run, so the
-        // quotient is the 3-instruction correctly rounded form of common.h
-        const double gt = inv_gt[l].b;
-        const double ratio =                               // :109-112
-            (g < gt) ? div_by_invariant(g, inv_div_numerator_ok(g), inv_gt[l])
-                     : 1.0;
-        const double melt = (0.9 * ratio + 0.1) * pot_melt; // :115
+        // Most days of a year nothing melts in a layer: frost (temp <= 0,
+        // the same for every lane) or no snow left (G == 0 in every lane), so
+        // pot_melt is a zero in all lanes of the wave.  Then
+        // melt = (0.9*ratio + 0.1) * pot_melt is that same zero -- the factor
+        // is finite and positive whenever G >= 0 (ratio in [0, 1]) -- and the
+        // wave skips the quotient and the melt arithmetic.
+        const lanemask_t idle = RR_LANES(pot_melt == 0.0) & RR_LANES(g >= 0.0);
+        double melt = pot_melt;
+        if (rr_exec() & ~idle) {
+            // G / G_tresh: the threshold is fixed for the whole run, so the
+            // quotient is the 3-instruction correctly rounded form of
+            // common.h
+            const double gt = inv_gt[l].b;
+            const double ratio =                           // :109-112
+                (g < gt) ? div_by_invariant_m(g, inv_div_numerator_mask0(g),
+                                              inv_gt[l], gt_m[l])
+                         : 1.0;
+            melt = (0.9 * ratio + 0.1) * pot_melt;         // :115
+        }
         g = g - melt;                                      // :118
         G[l] = g;
         eTG[l] = e;

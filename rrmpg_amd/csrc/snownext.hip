@@ -22,7 +22,8 @@ __device__ __forceinline__ double cema_hyst_day(
     const double *__restrict__ day, const double *__restrict__ psol,
     bool first, double snow_pack_init, double thermal_state_init,
     double sca_prev0, double CTG, double one_minus_CTG, double Kf,
-    const InvDivisor &inv_Thacc, double Rsp, double (&G)[L], double (&eTG)[L],
+    const InvDivisor &inv_Thacc, lanemask_t thacc_m, double Rsp,
+    double (&G)[L], double (&eTG)[L],
     double (&sca)[L], double (&swe_max)[L])
 {
     double c = 0.0;
@@ -47,9 +48,10 @@ __device__ __forceinline__ double cema_hyst_day(
         double sc;
         if (snow_balance >= 0) {                           // :126-129
             const double prev = first ? sca_prev0 : sca[l];
-            sc = prev + div_by_invariant(
-                            snow_balance, inv_div_numerator_ok(snow_balance),
-                            inv_Thacc);
+            // (a day without snowfall or melt has snow_balance == 0)
+            sc = prev + div_by_invariant_m(
+                            snow_balance, inv_div_numerator_mask0(snow_balance),
+                            inv_Thacc, thacc_m);
             swe_max[l] = nb_max(swe_max[l], g);
         } else {                                           // :130-142
             const double Thmelt = psol[l] * Rsp;
@@ -109,16 +111,19 @@ snow_gr4j_kernel(
     const double CTG = p[0], Kf = p[1];
     const double Rsp = HYST ? p[3] : 0.0;
     const InvDivisor inv_Thacc = make_inv_divisor(HYST ? p[2] : 1.0);
+    const lanemask_t thacc_m = RR_LANES(inv_Thacc.ok);
     const double ddf = ICE ? p[lay.i_ddf] : 0.0;
     Gr4jPar P;
     P.set(p[lay.i_x1], p[lay.i_x1 + 1], p[lay.i_x1 + 2], p[lay.i_x1 + 3]);
     const double omc = 1 - CTG;
     double G[L], eTG[L], sca[L], swe_max[L];
     InvDivisor inv_gt[L];
+    lanemask_t gt_m[L];          // lanes whose threshold suits the 3-FMA quotient
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         G[l] = 0.0; eTG[l] = 0.0; sca[l] = 0.0; swe_max[l] = 0.0;
         inv_gt[l] = make_inv_divisor(gtresh[l]);
+        gt_m[l] = RR_LANES(inv_gt[l].ok);
     }
     const double *psol = gtresh + L;
     const double sca_prev0 = (T == 1) ? sca_init : 0.0;
@@ -137,10 +142,10 @@ snow_gr4j_kernel(
         if constexpr (HYST)
             snowmelt = cema_hyst_day<L>(day, psol, t == 0, snow_pack_init,
                                         thermal_state_init, sca_prev0, CTG,
-                                        omc, Kf, inv_Thacc, Rsp, G, eTG, sca,
-                                        swe_max);
+                                        omc, Kf, inv_Thacc, thacc_m, Rsp, G,
+                                        eTG, sca, swe_max);
         else
-            snowmelt = cema_day<L>(day, inv_gt, t == 0, snow_pack_init,
+            snowmelt = cema_day<L>(day, inv_gt, gt_m, t == 0, snow_pack_init,
                                    thermal_state_init, CTG, omc, Kf, G, eTG);
         double liquid = snowmelt;
         double ice_total = 0.0;

@@ -33,9 +33,11 @@ int main(int argc, char **argv) {
         if (mode == 5) mb = ~0ULL;            // all ones
         if (mode == 6) { ma = mb; }           // quotient near a power of two
         const int ea = (int)(rnd() % 1801) - 900, eb = (int)(rnd() % 201) - 100;
-        const double a = mk(ma, ea, (int)(rnd() & 1)), b = mk(mb, eb, (int)(rnd() & 1));
+        double a = mk(ma, ea, (int)(rnd() & 1));
+        const double b = mk(mb, eb, (int)(rnd() & 1));
+        if ((i & 1023) == 7) a = (rnd() & 1) ? 0.0 : -0.0;   // exact zeros
         const InvDivisor d = make_inv_divisor(b);
-        if (!(d.ok && inv_div_numerator_ok(a))) continue;
+        if (!(d.ok && inv_div_numerator_ok0(a))) continue;
         checked++;
         const double q = inv_div_core(a, d), want = a / b;
         if (memcmp(&q, &want, 8) != 0) {

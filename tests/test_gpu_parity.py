@@ -504,7 +504,7 @@ def test_fit_recovers_known_parameters(models):
 
 
 def test_device_division_by_invariant_is_bit_exact():
-    """common.h div_by_invariant (3 FMAs + guarded fallback) == `/` on the
+    """common.h div_by_invariant_m (3 FMAs + guarded fallback) == `/` on the
     device for random, adversarial and special operands."""
     import ctypes
     from rrmpg_amd import _lib
@@ -526,6 +526,12 @@ def test_device_division_by_invariant_is_bit_exact():
     # significands at the ends of [1, 2)
     b[:1000] = np.nextafter(2.0, 0) * 2.0 ** rng.integers(-50, 50, 1000)
     b[1000:2000] = np.nextafter(1.0, 2) * 2.0 ** rng.integers(-50, 50, 1000)
+    # exact zeros among ordinary operands: waves that stay on the 3-FMA form
+    a[5000:9000:3] = 0.0
+    a[5001:9000:7] = -0.0
+    b[5000:9000] = np.ldexp(rng.uniform(1, 2, 4000),
+                            rng.integers(-90, 90, 4000)) \
+        * rng.choice([-1.0, 1.0], 4000)
     out, ref = np.empty_like(a), np.empty_like(a)
     p = lambda x: x.ctypes.data_as(_lib._f64p)
     rc = fn(p(a), p(b), p(out), p(ref), a.size)
