@@ -136,15 +136,26 @@ constexpr int coupled_min_waves()
                        std::is_same<UH, UhLds>::value)) ? 4 : 2;
 }
 
+// Output pointers.  Passed as the FIRST kernel argument and never touched by
+// name: on the days something is stored the kernel re-reads the struct from
+// offset 0 of its kernarg segment with one scalar load.  As ordinary
+// arguments the five pointers + ld would sit in 12 SGPRs for the whole time
+// loop of a kernel that is already short of them (the overflow goes to VGPR
+// lanes and every use then costs a v_readlane, i.e. a VALU slot).
+struct CoupledOut {
+    double *qsim, *G, *eTG, *s_store, *r_store;
+    int64_t ld;
+};
+typedef const CoupledOut __attribute__((address_space(4))) *coupled_out_ptr_t;
+
 template <int L, class UH>
 __global__ __launch_bounds__(RR_BLOCK, (coupled_min_waves<L, UH>())) void
 cemaneigegr4j_kernel(
+    CoupledOut /* read through the kernarg segment, see above */,
     const double *__restrict__ days, const double *__restrict__ gtresh,
     int64_t T, double snow_pack_init, double thermal_state_init,
     double s_init, double r_init, const double *__restrict__ params,
-    int64_t N, int n1cap, int n2cap, double *__restrict__ qsim,
-    double *__restrict__ G_out, double *__restrict__ eTG_out,
-    double *__restrict__ s_store, double *__restrict__ r_store, int64_t ld,
+    int64_t N, int n1cap, int n2cap, int wq, int ws,
     const double *__restrict__ qobs, double *__restrict__ sse)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -169,7 +180,7 @@ cemaneigegr4j_kernel(
     else uh.init(P.x4);
     double s = s_init * P.x1, r = r_init * P.x3;
     double acc = 0.0;
-    const bool wq = qsim != nullptr, ws = G_out != nullptr, we = sse != nullptr;
+    const bool we = sse != nullptr;
     constexpr int D = 3 * L + 1;
     for (int64_t t = 0; t < T; ++t) {
         double day[D];          // by value: one wide scalar load per day
@@ -178,17 +189,24 @@ cemaneigegr4j_kernel(
         const double liquid = cema_day<L>(day, inv_gt, gt_m, t == 0, snow_pack_init,
                                           thermal_state_init, CTG, omc, Kf, G,
                                           eTG);
-        const double q = gr4j_step(P, s, r, uh, liquid, day[3 * L]);
-        if (active) {
-            if (wq) qsim[t * ld + i] = q;
+        const double q = gr4j_step<UH, true>(P, s, r, uh, liquid, day[3 * L]);
+        if (active && (wq | ws)) {
+            coupled_out_ptr_t po =
+                (coupled_out_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(po));     // keeps the load at this spot
+            CoupledOut o;                    // one s_load_dwordx16
+            o.qsim = po->qsim; o.G = po->G; o.eTG = po->eTG;
+            o.s_store = po->s_store; o.r_store = po->r_store;
+            const int64_t ld = po->ld;
+            if (wq) o.qsim[t * ld + i] = q;
             if (ws) {
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    G_out[(t * L + l) * ld + i] = G[l];
-                    eTG_out[(t * L + l) * ld + i] = eTG[l];
+                    o.G[(t * L + l) * ld + i] = G[l];
+                    o.eTG[(t * L + l) * ld + i] = eTG[l];
                 }
-                s_store[t * ld + i] = s;
-                r_store[t * ld + i] = r;
+                o.s_store[t * ld + i] = s;
+                o.r_store[t * ld + i] = r;
             }
         }
         if (we) {
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
                                 ws ? G_out + (t * L) * ld + i : nullptr,
                                 ws ? eTG_out + (t * L) * ld + i : nullptr, ld,
                                 ws && active);
-        if constexpr (coupled) q = gr4j_step(P, s, r, uh, q, day[3 * L]);
+        if constexpr (coupled) q = gr4j_step<UH, true>(P, s, r, uh, q, day[3 * L]);
         if (active) {
             if (wq) qsim[t * ld + i] = q;
             if (coupled && ws) {
@@ -453,14 +471,15 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
+    const CoupledOut out = {qsim, G, eTG, s_store, r_store, ld};
     dispatch_layers((int)L, [&](auto LL) {
         gr4j_dispatch_uh(tier, [&](auto uh) {
             using UH = decltype(uh);
             cemaneigegr4j_kernel<LL.value, UH>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
-                   st>>>(days, gt, T, snow_pack_init, thermal_state_init,
-                         s_init, r_init, params, N, n1cap, n2cap, qsim, G, eTG,
-                         s_store, r_store, ld, qo, sse);
+                   st>>>(out, days, gt, T, snow_pack_init, thermal_state_init,
+                         s_init, r_init, params, N, n1cap, n2cap,
+                         qsim != nullptr, G != nullptr, qo, sse);
         });
     });
     RR_HIP(hipGetLastError());

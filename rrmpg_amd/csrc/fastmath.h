@@ -178,27 +178,60 @@ FP_FN bool fastpow_ok(double x, double z)
 // Used for np.tanh(p_n / x1) of GR4J (reference: gr4j_model.py:95-96, 107-108).
 // fast_tanh_parts gives numerator and denominator (tanh(a) = num / den,
 // den >= 2) so that a caller can fold the quotient into one of its own.
+//
+// JIT_CONST (device only): the 15 constants are fetched from constant memory
+// with scalar loads at the point of use instead of living in SGPRs for the
+// whole time loop.  The big fused kernels (snow routine + GR4J) run out of
+// SGPRs otherwise and hipcc parks the overflow in VGPR lanes, paying a
+// v_readlane -- a VALU slot -- per use.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const double __attribute__((address_space(4))) *fp_cptr_t;
+static __device__ __constant__ const double FP_TANH_TABLE[16] = {
+    1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08,
+    2.755731922398589e-07, 2.7557319223985893e-06, 2.48015873015873e-05,
+    0.0001984126984126984, 0.001388888888888889, 0.008333333333333333,
+    0.041666666666666664, 0.16666666666666666, 0.5,
+    1.4426950408889634, 6.93147180369123816490e-01,
+    1.90821492927058770002e-10, 0.0};
+#endif
+
+template <bool JIT_CONST = false>
 FP_FN void fast_tanh_parts(double a, double &num, double &den)
 {
     const double ax = __builtin_fabs(a);
     const double x = (ax > 20.0) ? 20.0 : ax;        // NaN stays NaN
     const double y = 2.0 * x;
-    const double n = FP_RINT(y * 1.4426950408889634);
-    const double r = FP_FMA(-n, 1.90821492927058770002e-10,
-                            FP_FMA(-n, 6.93147180369123816490e-01, y));
-    double q = 1.6059043836821613e-10;               // 1/13!
-    q = FP_FMA_C(q, r, 2.08767569878681e-09);        // 1/12!
-    q = FP_FMA_C(q, r, 2.505210838544172e-08);       // 1/11!
-    q = FP_FMA_C(q, r, 2.755731922398589e-07);       // 1/10!
-    q = FP_FMA_C(q, r, 2.7557319223985893e-06);      // 1/9!
-    q = FP_FMA_C(q, r, 2.48015873015873e-05);        // 1/8!
-    q = FP_FMA_C(q, r, 0.0001984126984126984);       // 1/7!
-    q = FP_FMA_C(q, r, 0.001388888888888889);        // 1/6!
-    q = FP_FMA_C(q, r, 0.008333333333333333);        // 1/5!
-    q = FP_FMA_C(q, r, 0.041666666666666664);        // 1/4!
-    q = FP_FMA_C(q, r, 0.16666666666666666);         // 1/3!
-    q = FP_FMA_C(q, r, 0.5);
-    const double p = FP_FMA(r * r, q, r);            // expm1(r)
+    double p, n;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (JIT_CONST) {
+        fp_cptr_t c = (fp_cptr_t)FP_TANH_TABLE;
+        asm volatile("" : "+s"(c));   // keeps the loads inside the time loop
+        n = FP_RINT(y * c[12]);
+        const double r = FP_FMA(-n, c[14], FP_FMA(-n, c[13], y));
+        double q = c[0];
+#pragma unroll
+        for (int j = 1; j < 12; ++j) q = FP_FMA_C(q, r, c[j]);
+        p = FP_FMA(r * r, q, r);
+    } else
+#endif
+    {
+        n = FP_RINT(y * 1.4426950408889634);
+        const double r = FP_FMA(-n, 1.90821492927058770002e-10,
+                                FP_FMA(-n, 6.93147180369123816490e-01, y));
+        double q = 1.6059043836821613e-10;           // 1/13!
+        q = FP_FMA_C(q, r, 2.08767569878681e-09);    // 1/12!
+        q = FP_FMA_C(q, r, 2.505210838544172e-08);   // 1/11!
+        q = FP_FMA_C(q, r, 2.755731922398589e-07);   // 1/10!
+        q = FP_FMA_C(q, r, 2.7557319223985893e-06);  // 1/9!
+        q = FP_FMA_C(q, r, 2.48015873015873e-05);    // 1/8!
+        q = FP_FMA_C(q, r, 0.0001984126984126984);   // 1/7!
+        q = FP_FMA_C(q, r, 0.001388888888888889);    // 1/6!
+        q = FP_FMA_C(q, r, 0.008333333333333333);    // 1/5!
+        q = FP_FMA_C(q, r, 0.041666666666666664);    // 1/4!
+        q = FP_FMA_C(q, r, 0.16666666666666666);     // 1/3!
+        q = FP_FMA_C(q, r, 0.5);
+        p = FP_FMA(r * r, q, r);                     // expm1(r)
+    }
     const double two_n = FP_LDEXP(1.0, (int)n);
     const double E = FP_FMA(two_n, p, two_n - 1.0);  // expm1(2|a|)
     num = __builtin_copysign(E, a);

@@ -283,7 +283,8 @@ __device__ __forceinline__ double pow_3_5(double x)
 // one shape: a tanh of the net amount over x1, one quotient; only the branch
 // that applies is evaluated.  (The plain GR4J kernel gets wet/net from its
 // pre-pass, wave-uniform; the coupled kernels compute them per lane.)
-template <class UH>
+// JIT_CONST: see fastmath.h fast_tanh_parts (set by the fused snow kernels).
+template <class UH, bool JIT_CONST = false>
 __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
                                                 double &r, UH &uh, double net,
                                                 bool wet)
@@ -293,7 +294,7 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     // store update's own:  c*th / (1 + k*th) == c*E / (D + k*E), one
     // division per day instead of two
     double E, D;
-    fast_tanh_parts(gr4j_div(net, P.inv_x1, P.x1_m), E, D);
+    fast_tanh_parts<JIT_CONST>(gr4j_div(net, P.inv_x1, P.x1_m), E, D);
     double num, den;
     if (wet) {
         num = P.x1 * (1 - sx * sx) * E;             // eq. 3 (:95-96)
@@ -333,12 +334,12 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     return q_r + q_d;                                           // :154
 }
 
-template <class UH>
+template <class UH, bool JIT_CONST = false>
 __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
                                             double &r, UH &uh, double prec,
                                             double etp)
 {
     const bool wet = prec >= etp;                               // :89
     const double net = wet ? prec - etp : etp - prec;           // :90, :102
-    return gr4j_step_net(P, s, r, uh, net, wet);
+    return gr4j_step_net<UH, JIT_CONST>(P, s, r, uh, net, wet);
 }

@@ -90,18 +90,27 @@ constexpr int snow_min_waves()
                        std::is_same<UH, UhLds>::value)) ? (HYST ? 3 : 4) : 2;
 }
 
+// Output pointers.  Passed as the FIRST kernel argument and never touched by
+// name: on the days something is stored the kernel re-reads the struct from
+// offset 0 of its kernarg segment with one scalar load.  As ordinary
+// arguments the eight pointers + ld would sit in 18 SGPRs for the whole time
+// loop of a kernel that is already short of them (the overflow goes to VGPR
+// lanes and every use then costs a v_readlane, i.e. a VALU slot).
+struct SnowOut {
+    double *qsim, *G, *eTG, *s_store, *r_store, *sca, *icemelt, *snowmelt;
+    int64_t ld;
+};
+typedef const SnowOut __attribute__((address_space(4))) *snow_out_ptr_t;
+
 template <int L, class UH, bool HYST, bool ICE>
 __global__ __launch_bounds__(RR_BLOCK, (snow_min_waves<L, UH, HYST>())) void
 snow_gr4j_kernel(
+    SnowOut /* read through the kernarg segment, see above */,
     const double *__restrict__ days, const double *__restrict__ gtresh,
     const double *__restrict__ frac_ice, int64_t T, double snow_pack_init,
     double thermal_state_init, double sca_init, double s_init, double r_init,
     const double *__restrict__ params, SnowParLayout lay, int64_t N,
-    int n1cap, int n2cap, double *__restrict__ qsim,
-    double *__restrict__ G_out, double *__restrict__ eTG_out,
-    double *__restrict__ s_store, double *__restrict__ r_store,
-    double *__restrict__ sca_out, double *__restrict__ icemelt_out,
-    double *__restrict__ snowmelt_out, int64_t ld,
+    int n1cap, int n2cap, int wq, int ws,
     const double *__restrict__ qobs, double *__restrict__ sse)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -132,7 +141,7 @@ snow_gr4j_kernel(
     else uh.init(P.x4);
     double s = s_init * P.x1, r = r_init * P.x3;
     double acc = 0.0;
-    const bool wq = qsim != nullptr, ws = G_out != nullptr, we = sse != nullptr;
+    const bool we = sse != nullptr;
     constexpr int D = 3 * L + 1;
     for (int64_t t = 0; t < T; ++t) {
         double day[D];          // by value: one wide scalar load per day
@@ -163,20 +172,29 @@ snow_gr4j_kernel(
             }
             liquid = snowmelt + ice_total;
         }
-        const double q = gr4j_step(P, s, r, uh, liquid, day[3 * L]);
-        if (active) {
-            if (wq) qsim[t * ld + i] = q;
+        const double q = gr4j_step<UH, true>(P, s, r, uh, liquid, day[3 * L]);
+        if (active && (wq | ws)) {
+            snow_out_ptr_t po =
+                (snow_out_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(po));     // keeps the load at this spot
+            SnowOut o;                       // one s_load_dwordx16 (+x2)
+            o.qsim = po->qsim; o.G = po->G; o.eTG = po->eTG;
+            o.s_store = po->s_store; o.r_store = po->r_store;
+            o.sca = po->sca; o.icemelt = po->icemelt;
+            o.snowmelt = po->snowmelt;
+            const int64_t ld = po->ld;
+            if (wq) o.qsim[t * ld + i] = q;
             if (ws) {
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    G_out[(t * L + l) * ld + i] = G[l];
-                    eTG_out[(t * L + l) * ld + i] = eTG[l];
-                    if (HYST) sca_out[(t * L + l) * ld + i] = sca[l];
+                    o.G[(t * L + l) * ld + i] = G[l];
+                    o.eTG[(t * L + l) * ld + i] = eTG[l];
+                    if (HYST) o.sca[(t * L + l) * ld + i] = sca[l];
                 }
-                s_store[t * ld + i] = s;
-                r_store[t * ld + i] = r;
-                if (ICE) icemelt_out[t * ld + i] = ice_total;
-                if (HYST && ICE) snowmelt_out[t * ld + i] = snowmelt;
+                o.s_store[t * ld + i] = s;
+                o.r_store[t * ld + i] = r;
+                if (ICE) o.icemelt[t * ld + i] = ice_total;
+                if (HYST && ICE) o.snowmelt[t * ld + i] = snowmelt;
             }
         }
         if (we) {
@@ -242,15 +260,17 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     const double *qo = (qobs && sse) ? qobs : nullptr;
     const size_t lds_bytes =
         (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
+    const SnowOut out = {qsim, G, eTG, s_store, r_store, sca, icemelt,
+                         snowmelt, ld};
     dispatch_layers((int)L, [&](auto LL) {
         gr4j_dispatch_uh(tier, [&](auto uh) {
             using UH = decltype(uh);
             snow_gr4j_kernel<LL.value, UH, HYST, ICE>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
-                   st>>>(days, gt, frac_ice, T, snow_pack_init,
+                   st>>>(out, days, gt, frac_ice, T, snow_pack_init,
                          thermal_state_init, sca_init, s_init, r_init, params,
-                         lay, N, n1cap, n2cap, qsim, G, eTG, s_store, r_store,
-                         sca, icemelt, snowmelt, ld, qo, sse);
+                         lay, N, n1cap, n2cap, qsim != nullptr, G != nullptr,
+                         qo, sse);
         });
     });
     RR_HIP(hipGetLastError());
