@@ -56,6 +56,9 @@ static __device__ __forceinline__ double fp_fma_sconst_(double a, double b,
 #define FP_LDEXP(v, n) __builtin_amdgcn_ldexp((v), (n))
 #define FP_RSQ_APPROX(v) __builtin_amdgcn_rsq(v)      /* v_rsq_f64, ~2^-26 */
 #define FP_SQRT_APPROX(v) __builtin_amdgcn_sqrt(v)    /* v_sqrt_f64, ~2^-26 */
+#define FP_HI32(x) __double2hiint(x)
+#define FP_LO32(x) __double2loint(x)
+#define FP_FROM_HILO(hi, lo) __hiloint2double((hi), (lo))
 #elif defined(__HIPCC__)
 // host pass of a .hip translation unit: the function is never called there
 #define FP_FN __device__ __forceinline__
@@ -68,6 +71,9 @@ static __device__ __forceinline__ double fp_fma_sconst_(double a, double b,
 #define FP_LDEXP(v, n) (v)
 #define FP_RSQ_APPROX(v) (v)
 #define FP_SQRT_APPROX(v) (v)
+#define FP_HI32(x) 0
+#define FP_LO32(x) 0
+#define FP_FROM_HILO(hi, lo) 0.0
 #else
 #define FP_FN static inline
 /* host stand-in for v_rcp_f64's ~26-bit estimate: a single-precision 1/g */
@@ -83,7 +89,19 @@ static inline int fp_frexp_exp_(double x) { int e; (void)frexp(x, &e); return e;
 /* host stand-ins for the hardware's ~26-bit estimates: single precision */
 #define FP_RSQ_APPROX(v) ((double)(1.0f / sqrtf((float)(v))))
 #define FP_SQRT_APPROX(v) ((double)sqrtf((float)(v)))
+#include <stdint.h>
+#include <string.h>
+static inline int fp_hi32_(double x) { uint64_t b; memcpy(&b, &x, 8); return (int)(uint32_t)(b >> 32); }
+static inline int fp_lo32_(double x) { uint64_t b; memcpy(&b, &x, 8); return (int)(uint32_t)b; }
+static inline double fp_from_hilo_(int hi, int lo) {
+    uint64_t b = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; memcpy(&d, &b, 8); return d;
+}
+#define FP_HI32(x) fp_hi32_(x)
+#define FP_LO32(x) fp_lo32_(x)
+#define FP_FROM_HILO(hi, lo) fp_from_hilo_((hi), (lo))
 #endif
+
+#include "pow_tables.h"
 
 // Core: valid for finite x > 0.  Returns x**y if |y*log2 x| < 1000; *z_out
 // receives y*log2(x) (rounded) for the caller's range guard.
@@ -165,6 +183,104 @@ FP_FN bool fastpow_ok(double x, double z)
     // x > 0 and finite (NaN fails both compares); |z| < 1000 keeps 2^z normal
     // and rejects NaN / inf coming from a non-finite y
     return (x > 0.0) && (x < __builtin_inf()) && (__builtin_fabs(z) < 1000.0);
+}
+
+// ---------------------------------------------------------------------------
+// Table-driven variant of fastpow_core: the same x**y for finite x > 0, with
+// the logarithm taken from a 128-entry table (pow_tables.h, generated by
+// tools/gen_pow_tables.py) instead of the division + degree-9 series above --
+// 11 instructions fewer, and slightly more accurate.  The scheme is the
+// classic one (Tang 1990; the form used by today's libms):
+//   bits(x) - bits(OFF), OFF = 0.6875, gives k and the subinterval i of
+//   z = x / 2^k in [OFF, 2 OFF);  with {invc, logc, logctail} = table[i],
+//   r = fma(z, invc, -1)  (|r| <= 2^-7, exact to one bit at 2^-62) and
+//   ln x = k ln2 + logc + logctail + r - r^2/2 + r^3 (1/3 - r/4 + ... - r^5/8),
+//   accumulated as hi + lo: k LN2HI + logc and the products feeding hi are
+//   exact by construction, the rest goes to lo (|lo| <~ 2^-14 |hi| ... ).
+// The exponent y is handed over already divided by ln 2, as a double-double
+// (y2hi + y2lo = y / ln 2, computed once per lane outside the time loop), so
+// z = y log2 x needs four FMAs and the exp2 stage of fastpow_core is reused.
+// `tab` points at FP_POWLOG_N entries of 4 doubles (LDS on the device).
+struct FpPowLogEntry { double invc, logc, logctail, pad; };
+
+FP_FN void fastpow_tab_exponent(double y, double *y2hi, double *y2lo)
+{
+    const double h = y * FP_INVLN2HI;
+    *y2hi = h;
+    *y2lo = FP_FMA(y, FP_INVLN2HI, -h) + y * FP_INVLN2LO;
+}
+
+FP_FN double fastpow_tab_core(double x, double y2hi, double y2lo,
+                              const FpPowLogEntry *tab, double *z_out)
+{
+    // k, i, z from the bit pattern (only the high word matters: OFF's low
+    // word is zero)
+    const int hi = FP_HI32(x);
+    const int tmp = hi - FP_POWLOG_OFF_HI;
+    const int i = (tmp >> 13) & (FP_POWLOG_N - 1);
+    const int k = tmp >> 20;                          // arithmetic shift
+    const double z = FP_FROM_HILO(hi - (tmp & (int)0xFFF00000), FP_LO32(x));
+    const double kd = (double)k;
+    const FpPowLogEntry e = tab[i];
+
+    const double r = FP_FMA(z, e.invc, -1.0);
+    // k ln2 + ln c + r, hi part exact up to the last addition
+    const double t1 = FP_FMA(kd, FP_LN2HI, e.logc);   // exact
+    const double t2 = t1 + r;
+    const double lo1 = FP_FMA(kd, FP_LN2LO, e.logctail);
+    const double lo2 = (t1 - t2) + r;
+    // - r^2/2 with its rounding error
+    const double ar = -0.5 * r;
+    const double ar2 = r * ar;
+    const double l_hi0 = t2 + ar2;
+    const double lo3 = FP_FMA(ar, r, -ar2);
+    const double lo4 = (t2 - l_hi0) + ar2;
+    // r^3 (1/3 - r/4 + r^2/5 - r^3/6 + r^4/7 - r^5/8) = (ar2 r) h(r),
+    // h = -2 (1/3 - r/4 + ...); truncation r^9/9 <= 2^-66
+    double h = 0.25;                                  // -2 * -1/8
+    h = FP_FMA_C(h, r, -2.0 / 7.0);
+    h = FP_FMA_C(h, r, 1.0 / 3.0);                    // -2 * -1/6
+    h = FP_FMA_C(h, r, -0.4);
+    h = FP_FMA_C(h, r, 0.5);
+    h = FP_FMA_C(h, r, -2.0 / 3.0);
+    const double p = (ar2 * r) * h;
+    const double lo = (((lo1 + lo2) + lo3) + lo4) + p;
+    // ln x = l_hi0 + lo, |lo| < 2^-13 |l_hi0| (not renormalised: the product
+    // below only needs the pair's sum)
+
+    // z = (y2hi + y2lo) (l_hi0 + lo) = y log2 x
+    const double z_hi = y2hi * l_hi0;
+    double z_lo = FP_FMA(y2hi, l_hi0, -z_hi);
+    z_lo = FP_FMA(y2hi, lo, z_lo);
+    z_lo = FP_FMA(y2lo, l_hi0, z_lo);
+    *z_out = z_hi;
+
+    // 2^(z_hi + z_lo), as in fastpow_core
+    const double n = FP_RINT(z_hi);
+    const double q0 = (z_hi - n) + z_lo;              // |.| <= 0.5 (+ tiny)
+    double q = 1.3691488853904128e-12;                // ln2^13 / 13!
+    q = FP_FMA_C(q, q0, 2.5678435993488206e-11);
+    q = FP_FMA_C(q, q0, 4.4455382718708116e-10);
+    q = FP_FMA_C(q, q0, 7.054911620801123e-09);
+    q = FP_FMA_C(q, q0, 1.01780860092397e-07);
+    q = FP_FMA_C(q, q0, 1.321548679014431e-06);
+    q = FP_FMA_C(q, q0, 1.5252733804059841e-05);
+    q = FP_FMA_C(q, q0, 0.0001540353039338161);
+    q = FP_FMA_C(q, q0, 0.0013333558146428443);
+    q = FP_FMA_C(q, q0, 0.009618129107628477);
+    q = FP_FMA_C(q, q0, 0.05550410866482158);
+    q = FP_FMA_C(q, q0, 0.24022650695910072);
+    q = FP_FMA_C(q, q0, 0.6931471805599453);
+    q = FP_FMA_C(q, q0, 1.0);
+    return FP_LDEXP(q, (int)n);
+}
+
+// Where fastpow_tab_core's result may be used: x a positive NORMAL number
+// (the bit-pattern split does not handle subnormals), |z| < 1000.
+FP_FN bool fastpow_tab_ok(double x, double z)
+{
+    return (x >= 0x1p-1022) && (x < __builtin_inf()) &&
+           (__builtin_fabs(z) < 1000.0);
 }
 
 // ---------------------------------------------------------------------------

@@ -62,6 +62,12 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
     days[g] = d;
 }
 
+// The logarithm table of fastpow_tab_core (fastmath.h, pow_tables.h): 4 KiB
+// in constant memory, copied into LDS by every wave at kernel start (each lane
+// indexes it with its own subinterval, which only LDS serves at full rate).
+static __device__ __constant__ const FpPowLogEntry HBV_POWLOG_TABLE[FP_POWLOG_N] =
+    FP_POWLOG_TABLE_INIT;
+
 // General pow for the (never expected) arguments outside fastpow's domain.
 // Out of line on purpose: inlined, OCML's pow raised the kernel from ~100 to
 // 148 VGPRs (3 instead of 4-5 waves per SIMD) for a path that never runs.
@@ -89,6 +95,10 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     double *__restrict__ s2_out, int64_t ld, const double *__restrict__ qobs,
     double *__restrict__ sse)
 {
+    __shared__ FpPowLogEntry powlog[FP_POWLOG_N];
+    for (int j = threadIdx.x; j < FP_POWLOG_N; j += RR_BLOCK)
+        powlog[j] = HBV_POWLOG_TABLE[j];
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     {
@@ -119,6 +129,9 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     const double soil_lo = FC * 0x1p-9, soil_hi = FC * 0x1p9;
     const bool box_ok = (FC > 0x1p-500) && (FC < 0x1p500) &&
                         (fabs(Beta) <= 64.0);
+    // Beta / ln 2 as a double-double, for fastpow_tab_core
+    double beta2_hi, beta2_lo;
+    fastpow_tab_exponent(Beta, &beta2_hi, &beta2_lo);
     // loop-invariant lane masks for the wave votes (common.h)
     const lanemask_t box_m = RR_LANES(box_ok);
     const lanemask_t fc_m = RR_LANES(inv_FC.ok), pwp_m = RR_LANES(inv_PWP.ok);
@@ -176,13 +189,14 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
             // fastmath.h: ~1 ulp, a third of the general pow's instructions;
             // arguments outside its domain take the general pow (wave-wide)
             double z;
-            double pw = fastpow_core(wetness, Beta, &z);
-            const lanemask_t fast_m = RR_LANES(wetness > 0.0) &
+            double pw = fastpow_tab_core(wetness, beta2_hi, beta2_lo, powlog,
+                                         &z);
+            const lanemask_t fast_m = RR_LANES(wetness >= 0x1p-1022) &
                                       RR_LANES(wetness < __builtin_inf()) &
                                       RR_LANES(fabs(z) < 1000.0);
             if (rr_exec() & ~fast_m) {
                 const double general = pow_general(wetness, Beta);
-                pw = fastpow_ok(wetness, z) ? pw : general;
+                pw = fastpow_tab_ok(wetness, z) ? pw : general;
             }
             // lanes of this wave that did not need the power sit inside the
             // box with liquid_water == 0: their pw is finite (|z| <= 64 * 9.1)

@@ -61,6 +61,41 @@ int main(int argc, char **argv) {
     }
     printf("libm_pow_worst_ulp_hbv %.4f\n", wl);
 
+    // table-driven variant (fastpow_tab_core), same three argument sets
+    {
+        static const FpPowLogEntry tab[FP_POWLOG_N] = FP_POWLOG_TABLE_INIT;
+        double tw[3] = {0, 0, 0}, tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
+        long rej = 0;
+        s = 88172645463325252ULL;
+        for (int set = 0; set < 3; ++set)
+            for (long i = 0; i < n; ++i) {
+                double x, y;
+                if (set == 0) { x = 0.02 + 2.48 * u01(); y = 0.5 + 7.5 * u01(); }
+                else if (set == 1) { x = exp2(-60 + 120 * u01()); y = -12 + 24 * u01(); }
+                else { x = 1 + 2e-3 * (u01() - 0.5); y = -300 + 600 * u01(); }
+                double y2h, y2l, zz;
+                fastpow_tab_exponent(y, &y2h, &y2l);
+                double got = fastpow_tab_core(x, y2h, y2l, tab, &zz);
+                if (!fastpow_tab_ok(x, zz)) { rej++; continue; }
+                double err = ulp_err(got, powl((long double)x, (long double)y));
+                if (err > tw[set]) { tw[set] = err; tx[set] = x; ty[set] = y; }
+            }
+        double y2h, y2l, zz;
+        auto P = [&](double x, double y) {
+            fastpow_tab_exponent(y, &y2h, &y2l);
+            return fastpow_tab_core(x, y2h, y2l, tab, &zz);
+        };
+        int ex = P(1.0, 3.7) == 1.0 && P(2.5, 0.0) == 1.0 && P(2.0, 3.0) == 8.0 &&
+                 P(0.25, 0.5) == 0.5 && P(4.0, -1.0) == 0.25 &&
+                 !fastpow_tab_ok(4e-320, 0.0) && !fastpow_tab_ok(-1.0, 0.0) &&
+                 !fastpow_tab_ok(INFINITY, 0.0) && !fastpow_tab_ok(NAN, 0.0) &&
+                 !fastpow_tab_ok(0.0, 0.0) && fastpow_tab_ok(0x1p-1022, 3.0);
+        printf("tab_worst_ulp_hbv %.4f at x=%.17g y=%.17g\n", tw[0], tx[0], ty[0]);
+        printf("tab_worst_ulp_wide %.4f at x=%.17g y=%.17g\n", tw[1], tx[1], ty[1]);
+        printf("tab_worst_ulp_near1 %.4f at x=%.17g y=%.17g\n", tw[2], tx[2], ty[2]);
+        printf("tab_guard_rejected %ld\ntab_exact_ok %d\n", rej, ex);
+    }
+
     // tanh: arguments as GR4J produces them (net / x1 in [0, ~1]) and wide
     double wt = 0, wtx = 0, wtw = 0, wtwx = 0;
     for (long i = 0; i < n; ++i) {

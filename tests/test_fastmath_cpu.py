@@ -32,6 +32,12 @@ def test_fastpow_accuracy(tmp_path):
     assert float(vals["worst_ulp_near1"]) < 1.25, out
     assert int(vals["exact_ok"]) == 1, out
     assert int(vals["guard_rejected"]) == 0, out
+    # table-driven variant used by the HBV-Edu kernel
+    assert float(vals["tab_worst_ulp_hbv"]) < 1.1, out
+    assert float(vals["tab_worst_ulp_wide"]) < 1.1, out
+    assert float(vals["tab_worst_ulp_near1"]) < 1.1, out
+    assert int(vals["tab_exact_ok"]) == 1, out
+    assert int(vals["tab_guard_rejected"]) == 0, out
     assert float(vals["worst_ulp_tanh_gr4j"]) < 3.0, out
     assert float(vals["worst_ulp_tanh_wide"]) < 3.0, out
     assert int(vals["tanh_special_ok"]) == 1, out
