@@ -86,6 +86,37 @@ __device__ __forceinline__ double div_by_invariant_m(double a, lanemask_t a_ok,
     return q;
 }
 
+// ---- one output row of a wave: 64 adjacent columns ---------------------------
+// Every output is [T][ld] row-major and a wave owns 64 adjacent columns, so a
+// day's store is (wave-uniform row base) + (lane * 8 bytes).  Issued as a raw
+// buffer store -- descriptor built from the scalar row base, the lane offset
+// the only vector operand -- the address arithmetic of the time loop is all
+// scalar (a flat pointer per lane costs a 64-bit VALU add per day), and the
+// descriptor's size drops the columns past N in hardware, so the tail wave
+// needs no exec masking either.  `bytes` = 8 * min(64, N - first column).
+typedef int rr_v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rr_store_row(double *row_base, unsigned bytes,
+                                             int lane_byte_off, double v,
+                                             bool nontemporal = false)
+{
+    // word 3: DATA_FORMAT = 32-bit, raw addressing (the value the compiler's
+    // own buffer intrinsics use on gfx90a / gfx94x / gfx950)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)row_base, (short)0, (int)bytes, 0x00020000);
+    rr_v2i d;
+    d.x = __double2loint(v);
+    d.y = __double2hiint(v);
+    if (nontemporal)
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_byte_off, 0, 2);
+    else
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_byte_off, 0, 0);
+}
+__device__ __forceinline__ unsigned rr_row_bytes(int64_t first, int64_t N)
+{
+    const int64_t rem = N - first;
+    return rem >= RR_BLOCK ? 8u * RR_BLOCK : (rem > 0 ? (unsigned)rem * 8u : 0u);
+}
+
 // ---- error plumbing (host) ------------------------------------------------
 void rr_set_error(const char *fmt, ...);
 

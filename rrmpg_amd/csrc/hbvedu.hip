@@ -126,7 +126,10 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     const InvDivisor inv_FC = make_inv_divisor(FC);
     const InvDivisor inv_PWP = make_inv_divisor(PWP);
     // box in which (soil/FC)**Beta is certainly finite (see the time loop)
-    const double soil_lo = FC * 0x1p-9, soil_hi = FC * 0x1p9;
+    double soil_lo = FC * 0x1p-9, soil_hi = FC * 0x1p9;
+    // (opaque to the compiler: otherwise it re-derives both from FC with two
+    // v_ldexp_f64 every day to save four registers)
+    asm("" : "+v"(soil_lo), "+v"(soil_hi));
     const bool box_ok = (FC > 0x1p-500) && (FC < 0x1p500) &&
                         (fabs(Beta) <= 64.0);
     // Beta / ln 2 as a double-double, for fastpow_tab_core
@@ -138,17 +141,21 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
 
     double snow = snow_init, soil = soil_init, s1 = s1_init, s2 = s2_init;
     double acc = 0.0;
-    int64_t off = i;   // t * ld + i
+    // Outputs are addressed as (wave-uniform row base, advanced by ld per day
+    // with scalar adds) + (this lane's fixed column inside the wave's 512-byte
+    // segment): no vector address arithmetic inside the time loop.
+    const int lane_off = threadIdx.x * 8;
+    const int64_t first = (int64_t)blockIdx.x * RR_BLOCK;
+    const unsigned row_bytes = rr_row_bytes(first, N);
+    int64_t row = first;                            // t * ld + first column
 
     // t = 0: qsim[0] = 0, state[0] = init (hbvedu_model.py:71-81)
-    if (active) {
-        if (WRITE_Q) qsim[off] = 0.0;
-        if (WRITE_S) {
-            snow_out[off] = snow;
-            soil_out[off] = soil;
-            s1_out[off] = s1;
-            s2_out[off] = s2;
-        }
+    if (WRITE_Q) rr_store_row(qsim + row, row_bytes, lane_off, 0.0);
+    if (WRITE_S) {
+        rr_store_row(snow_out + row, row_bytes, lane_off, snow);
+        rr_store_row(soil_out + row, row_bytes, lane_off, soil);
+        rr_store_row(s1_out + row, row_bytes, lane_off, s1);
+        rr_store_row(s2_out + row, row_bytes, lane_off, s2);
     }
     if (WITH_SSE) {
         const double d = qobs[0] - 0.0;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     // reference lets hipcc re-load single fields at their use sites, each
     // with its own wait)
     auto day_step = [&](const HbvDay f, int64_t t) {
-        off += ld;
+        row += ld;
 
         // snow routine (hbvedu_model.py:87-96)
         const double melt = DD * (f.temp - T_t);
@@ -176,12 +183,14 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         // altogether.  Outside that box (NaN/inf/zero/negative operands, huge
         // Beta) both are evaluated and 0 * inf / 0 * NaN propagate exactly as
         // in the reference.
-        const lanemask_t soil_m = inv_div_numerator_mask(soil);
+        // lanes inside the box; there soil is also a valid numerator of the
+        // 3-FMA quotients (|soil| in [2^-509, 2^509]), so the box doubles as
+        // their guard and lanes outside it take the IEEE division
+        const lanemask_t soil_m =
+            RR_LANES(soil >= soil_lo) & RR_LANES(soil <= soil_hi) & box_m;
         // lanes that need the power: wet, or outside the box (votes are done
         // on lane masks, common.h)
-        const lanemask_t need_m =
-            RR_LANES(liquid_water != 0.0) |
-            ~(RR_LANES(soil >= soil_lo) & RR_LANES(soil <= soil_hi) & box_m);
+        const lanemask_t need_m = RR_LANES(liquid_water != 0.0) | ~soil_m;
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
         if (need_m & rr_exec()) {
             const double wetness = div_by_invariant_m(soil, soil_m, inv_FC,
@@ -224,18 +233,16 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
 
         snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
 
-        if (active) {
-            if (WRITE_Q) __builtin_nontemporal_store(q, &qsim[off]);
-            if (WRITE_S) {
-                snow_out[off] = snow;
-                soil_out[off] = soil;
-                s1_out[off] = s1;
-                s2_out[off] = s2;
-            }
+        if (WRITE_Q) rr_store_row(qsim + row, row_bytes, lane_off, q, true);
+        if (WRITE_S) {
+            rr_store_row(snow_out + row, row_bytes, lane_off, snow);
+            rr_store_row(soil_out + row, row_bytes, lane_off, soil);
+            rr_store_row(s1_out + row, row_bytes, lane_off, s1);
+            rr_store_row(s2_out + row, row_bytes, lane_off, s2);
         }
         if (WITH_SSE) {
             const double d = f.qobs - q;
-            acc += d * d;
+            acc = __builtin_fma(d, d, acc);   // one rounding per day
         }
         (void)t;
     };
