@@ -120,7 +120,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
         }
         if (we) {
             const double d = qobs[t] - q;
-            acc += d * d;
+            acc = __builtin_fma(d, d, acc);
         }
     }
     if (we && active) sse[i] = acc;
@@ -211,7 +211,7 @@ cemaneigegr4j_kernel(
         }
         if (we) {
             const double d = qobs[t] - q;
-            acc += d * d;
+            acc = __builtin_fma(d, d, acc);
         }
     }
     if (we && active) sse[i] = acc;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
         }
         if (we) {
             const double d = qobs[t] - q;
-            acc += d * d;
+            acc = __builtin_fma(d, d, acc);
         }
     }
     if (we && active) sse[i] = acc;

@@ -94,23 +94,25 @@ __global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
     double s = s_init * P.x1;   // gr4j_model.py:64
     double r = r_init * P.x3;   // gr4j_model.py:65
     double acc = 0.0;
-    int64_t off = i;
+    // output rows: wave-uniform base + lane offset (common.h rr_store_row)
+    const int lane_off = threadIdx.x * 8;
+    const int64_t first = (int64_t)blockIdx.x * RR_BLOCK;
+    const unsigned row_bytes = rr_row_bytes(first, N);
+    int64_t row = first;
 
     for (int64_t k = 0; k < T; ++k) {
         const GrDay f = days[k];    // wave-uniform -> s_load_dwordx8
         const double q = gr4j_step_net(P, s, r, uh, f.net, f.wet != 0);
-        if (active) {
-            if (Q) qsim[off] = q;
-            if (S) {
-                s_store[off] = s;
-                r_store[off] = r;
-            }
+        if (Q) rr_store_row(qsim + row, row_bytes, lane_off, q);
+        if (S) {
+            rr_store_row(s_store + row, row_bytes, lane_off, s);
+            rr_store_row(r_store + row, row_bytes, lane_off, r);
         }
         if (E) {
             const double d = f.qobs - q;
-            acc += d * d;
+            acc = __builtin_fma(d, d, acc);
         }
-        off += ld;
+        row += ld;
     }
     if (E && active) sse[i] = acc;
 }

@@ -199,7 +199,7 @@ snow_gr4j_kernel(
         }
         if (we) {
             const double d = qobs[t] - q;
-            acc += d * d;
+            acc = __builtin_fma(d, d, acc);
         }
     }
     if (we && active) sse[i] = acc;
