@@ -50,3 +50,36 @@ def test_invariant_division_is_bit_exact(tmp_path):
     vals = dict(re.findall(r"^(\w+) ([0-9]+)", out, flags=re.M))
     assert int(vals["mismatches"]) == 0, out
     assert int(vals["checked"]) > 15_000_000, out
+
+
+def test_pow_tables_header_matches_its_generator(tmp_path):
+    """rrmpg_amd/csrc/pow_tables.h is generated (mpmath, 60 digits) by
+    csrc/tools/gen_pow_tables.py; the committed header must be what the
+    generator writes, entry for entry."""
+    import importlib.util
+    import pytest
+    pytest.importorskip("mpmath")
+    gen = os.path.join(REPO, "rrmpg_amd", "csrc", "tools", "gen_pow_tables.py")
+    committed = os.path.join(REPO, "rrmpg_amd", "csrc", "pow_tables.h")
+    with open(committed) as fp:
+        want = fp.read()
+    spec = importlib.util.spec_from_file_location("gen_pow_tables", gen)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        mod.main()                       # rewrites the header in place
+        with open(committed) as fp:
+            got = fp.read()
+    finally:
+        with open(committed, "w") as fp:
+            fp.write(want)
+    assert got == want
+    # shape of the table: 128 entries, the two around x = 1 are {1, 0, 0}
+    rows = re.findall(r"\{(\S+), (\S+), (\S+), 0\.0\}", want)
+    assert len(rows) == 128
+    for i in (79, 80):
+        assert [float.fromhex(v) for v in rows[i]] == [1.0, 0.0, 0.0]
+    for invc, logc, tail in rows:
+        invc, logc, tail = (float.fromhex(v) for v in (invc, logc, tail))
+        assert (invc * 2 ** 9) % 1 == 0 or (invc * 2 ** 8) % 1 == 0
+        assert (logc * 2 ** 43) % 1 == 0 and abs(tail) < 2 ** -43
