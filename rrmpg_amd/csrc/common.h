@@ -64,6 +64,17 @@ __device__ __forceinline__ lanemask_t lanes_plus_zero(double a) {
     asm("v_cmp_class_f64 %0, %1, 0x40" : "=s"(m) : "v"(a));
     return m;
 }
+// lanes whose value belongs to the given v_cmp_class_f64 classes
+// (bit 3 -normal, 4 -subnormal, 5 -0, 6 +0, 7 +subnormal, 8 +normal, 9 +inf)
+__device__ __forceinline__ lanemask_t lanes_of_class(double a, int classes) {
+    lanemask_t m;
+    asm("v_cmp_class_f64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(classes));
+    return m;
+}
+// lanes holding a finite value
+__device__ __forceinline__ lanemask_t lanes_finite(double a) {
+    return lanes_of_class(a, 0x1f8);
+}
 __device__ __forceinline__ lanemask_t inv_div_numerator_mask0(double a) {
     return (RR_LANES(fabs(a) >= 0x1p-900) | lanes_plus_zero(a)) &
            RR_LANES(fabs(a) <= 0x1p900);

@@ -140,8 +140,7 @@ struct UhRegs {
             u2[j] = __builtin_fma(
                 o2[j], p2,
                 (j + 1 < N2MAX) ? u2[(j + 1 < N2MAX) ? j + 1 : j] : 0.0);
-        const lanemask_t finite = RR_LANES(__builtin_fabs(p1) < __builtin_inf()) &
-                                  RR_LANES(__builtin_fabs(p2) < __builtin_inf());
+        const lanemask_t finite = lanes_finite(p1) & lanes_finite(p2);
         if (rr_exec() & ~finite) {
 #pragma unroll
             for (int j = 0; j < N1MAX; ++j) u1[j] = (j < n1) ? u1[j] : 0.0;
@@ -234,8 +233,7 @@ struct UhLds {
             U2(j) = nv;
             if (j == 0) head2 = nv;
         }
-        const lanemask_t finite = RR_LANES(__builtin_fabs(p1) < __builtin_inf()) &
-                                  RR_LANES(__builtin_fabs(p2) < __builtin_inf());
+        const lanemask_t finite = lanes_finite(p1) & lanes_finite(p2);
         if (rr_exec() & ~finite) {
             for (int j = 0; j < n1w; ++j)
                 if (j >= n1) U1(j) = 0.0;
@@ -265,15 +263,33 @@ static inline void gr4j_dispatch_uh(int tier, F &&f)
 //   np.tanh(.)            -> fast_tanh_parts, <= ~2.5 ulp, its quotient
 //                            merged with the store update's (gr4j_step);
 //   (1 + v**4)**(-0.25)   -> inv_fourth_root, ~1 ulp (Newton on y^-4 = b);
-//   (r/x3)**3.5           -> x*x*x*sqrt(x) with a correctly rounded sqrt,
-//                            <= ~2.5 ulp; 0 -> 0, inf -> inf, x < 0 -> NaN
-//                            (as pow for a negative base and a non-integer
-//                            exponent), NaN -> NaN.
+//   (r/x3)**3.5           -> x*x*x*sqrt(x), <= ~2.5 ulp; for finite x >= 0
+//                            the root is fast_sqrt_core (8 instructions,
+//                            <= 0.6 ulp; arguments below 2^-500 are raised
+//                            to it -- their cube is 0 anyway), any other x
+//                            takes the wave through the IEEE sqrt: 0 -> 0,
+//                            inf -> inf, x < 0 -> NaN (as pow for a negative
+//                            base and a non-integer exponent), NaN -> NaN.
 // libm's own pow/tanh are faithful to ~1 ulp; these few-ulp differences are
 // far inside the 1e-10 parity tolerance (observed ~1e-13 on 30-year runs).
+// FAST_ROOT = false keeps the compiler's IEEE sqrt inline: measured faster in
+// the UhRegs<10> kernels (2 waves per SIMD, every register taken -- there the
+// extra branch costs more than the 7 instructions it saves: 233.7 vs 226.8 ms).
+template <bool FAST_ROOT = true>
 __device__ __forceinline__ double pow_3_5(double x)
 {
-    return x * x * x * sqrt(x);
+    if constexpr (!FAST_ROOT) return x * x * x * sqrt(x);
+    // +0, positive subnormal or positive normal: one class test
+    const lanemask_t ok = lanes_of_class(x, 0x1c0);
+    double root = fast_sqrt_core(nb_max(0x1p-500, x));
+    if (rr_exec() & ~ok) {
+        // (the empty asm keeps this a branch: hipcc would otherwise evaluate
+        // the IEEE sqrt for every wave and select)
+        asm volatile("");
+        const double exact = sqrt(x);
+        root = (x >= 0.0 && x < __builtin_inf()) ? root : exact;
+    }
+    return x * x * x * root;
 }
 
 // One day of GR4J (gr4j_model.py:86-154).  s, r: production / routing store
@@ -304,17 +320,22 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
         den = D + (1 - sx) * E;
     }
     const double frac = num / den;
-    const double p_n = wet ? net : 0.0;
-    const double p_s = wet ? frac : 0.0;
-    const double e_s = wet ? 0.0 : frac;
-
-    double sn = s - e_s + p_s;                                  // :114
+    // s - e_s + p_s (:114) and p_n - p_s (:123) with the branch's zeros
+    // dropped (x - 0 and x + 0 are x)
+    double sn, excess;
+    if (wet) {
+        sn = s + frac;
+        excess = net - frac;
+    } else {
+        sn = s - frac;
+        excess = 0.0;
+    }
     // percolation (:117); **4 is two squarings
     const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1, P.x1_m);
     const double v2 = v * v;
     const double perc = sn * (1 - inv_fourth_root(1 + v2 * v2));
     sn = sn - perc;                                             // :120
-    const double p_r = perc + (p_n - p_s);                      // :123
+    const double p_r = perc + excess;                           // :123
     const double p_r_uh1 = 0.9 * p_r;                           // :126-127
     const double p_r_uh2 = 0.1 * p_r;
 
@@ -322,7 +343,8 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     uh.route(p_r_uh1, p_r_uh2, head1, head2);                   // :130-136
 
     const double gw_exchange =
-        P.x2 * pow_3_5(gr4j_div(r, P.inv_x3, P.x3_m));          // :139
+        P.x2 * pow_3_5<!std::is_same<UH, UhRegs<10>>::value>(
+                   gr4j_div(r, P.inv_x3, P.x3_m));              // :139
     double rn = nb_max(0.0, r + head1 + gw_exchange);           // :142
     const double w = gr4j_div(rn, P.inv_x3, P.x3_m);
     const double w2 = w * w;

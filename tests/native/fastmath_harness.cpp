@@ -115,6 +115,15 @@ int main(int argc, char **argv) {
                        fast_tanh(1e-300) == 1e-300 && fast_tanh(-4e-320) == -4e-320;
     printf("tanh_special_ok %d\n", tanh_special);
 
+    // fast_sqrt_core on its domain
+    double ws = 0, wsx = 0;
+    for (long i = 0; i < n; ++i) {
+        double x = (i & 1) ? 4.0 * u01() + 1e-9 : exp2(-499 + 1522 * u01());
+        double err = ulp_err(fast_sqrt_core(x), sqrtl((long double)x));
+        if (err > ws) { ws = err; wsx = x; }
+    }
+    printf("worst_ulp_fast_sqrt %.4f at x=%.17g\n", ws, wsx);
+
     // b**(-1/4), b = 1 + v^4 >= 1
     double wr = 0, wrx = 0;
     for (long i = 0; i < n; ++i) {
