@@ -391,9 +391,9 @@ FP_FN double fast_sqrt_core(double x)
 // b >= 1e300 (inf included) the result is < 1e-75, which every caller only
 // uses as 1 - result == 1.0 exactly; NaN propagates.
 // Used for (1 + v**4)**(-0.25) of GR4J (reference: gr4j_model.py:117, 145).
-FP_FN double inv_fourth_root(double b)
+// (core: finite b >= 1 only -- +inf would give NaN)
+FP_FN double inv_fourth_root_core(double bb)
 {
-    const double bb = (b > 1e300) ? 1e300 : b;       // NaN stays NaN
     double y = FP_SQRT_APPROX(FP_RSQ_APPROX(bb));
     double y2 = y * y;
     double e = FP_FMA(-bb, y2 * y2, 1.0);
@@ -402,4 +402,10 @@ FP_FN double inv_fourth_root(double b)
     e = FP_FMA(-bb, y2 * y2, 1.0);
     y = FP_FMA(y * 0.25, e, y);
     return y;
+}
+
+FP_FN double inv_fourth_root(double b)
+{
+    const double bb = (b > 1e300) ? 1e300 : b;       // NaN stays NaN
+    return inv_fourth_root_core(bb);
 }

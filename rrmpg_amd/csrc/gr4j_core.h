@@ -272,6 +272,24 @@ static inline void gr4j_dispatch_uh(int tier, F &&f)
 //                            base and a non-integer exponent), NaN -> NaN.
 // libm's own pow/tanh are faithful to ~1 ulp; these few-ulp differences are
 // far inside the 1e-10 parity tolerance (observed ~1e-13 on 30-year runs).
+// (1 + v**4)**(-0.25): b is a positive normal number (>= 1) unless v was
+// non-finite or v**4 overflowed; one class test instead of the clamp of
+// fastmath.h's inv_fourth_root (3 instructions).  +inf gives 0 (callers use
+// 1 - result), NaN propagates.
+// GUARD_BY_VOTE = false: the branch-free clamped form (UhRegs<10> kernels, see
+// pow_3_5 below).
+template <bool GUARD_BY_VOTE = true>
+__device__ __forceinline__ double gr4j_inv_fourth_root(double b)
+{
+    if constexpr (!GUARD_BY_VOTE) return inv_fourth_root(b);
+    double y = inv_fourth_root_core(b);
+    if (rr_exec() & ~lanes_of_class(b, 0x100)) {
+        asm volatile("");                   // keep this a branch
+        y = (b < __builtin_inf()) ? y : ((b != b) ? b : 0.0);
+    }
+    return y;
+}
+
 // FAST_ROOT = false keeps the compiler's IEEE sqrt inline: measured faster in
 // the UhRegs<10> kernels (2 waves per SIMD, every register taken -- there the
 // extra branch costs more than the 7 instructions it saves: 233.7 vs 226.8 ms).
@@ -333,7 +351,9 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     // percolation (:117); **4 is two squarings
     const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1, P.x1_m);
     const double v2 = v * v;
-    const double perc = sn * (1 - inv_fourth_root(1 + v2 * v2));
+    constexpr bool votes = !std::is_same<UH, UhRegs<10>>::value;
+    const double perc =
+        sn * (1 - gr4j_inv_fourth_root<votes>(1 + v2 * v2));
     sn = sn - perc;                                             // :120
     const double p_r = perc + excess;                           // :123
     const double p_r_uh1 = 0.9 * p_r;                           // :126-127
@@ -343,12 +363,12 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     uh.route(p_r_uh1, p_r_uh2, head1, head2);                   // :130-136
 
     const double gw_exchange =
-        P.x2 * pow_3_5<!std::is_same<UH, UhRegs<10>>::value>(
-                   gr4j_div(r, P.inv_x3, P.x3_m));              // :139
+        P.x2 * pow_3_5<votes>(gr4j_div(r, P.inv_x3, P.x3_m));   // :139
     double rn = nb_max(0.0, r + head1 + gw_exchange);           // :142
     const double w = gr4j_div(rn, P.inv_x3, P.x3_m);
     const double w2 = w * w;
-    const double q_r = rn * (1 - inv_fourth_root(1 + w2 * w2)); // :145
+    const double q_r =
+        rn * (1 - gr4j_inv_fourth_root<votes>(1 + w2 * w2));    // :145
     rn = rn - q_r;                                              // :148
     const double q_d = nb_max(0.0, head2 + gw_exchange);        // :151
     s = sn;
