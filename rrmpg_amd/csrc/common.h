@@ -49,41 +49,36 @@ __device__ __forceinline__ double nb_min(double a, double b) {
 typedef unsigned long long lanemask_t;
 #define RR_LANES(cmp) ((lanemask_t)__builtin_amdgcn_ballot_w64(cmp))
 __device__ __forceinline__ lanemask_t rr_exec() { return RR_LANES(true); }
-__device__ __forceinline__ bool wave_any(bool p) { return RR_LANES(p) != 0; }
-__device__ __forceinline__ bool wave_all(bool p) { return RR_LANES(!p) == 0; }
 
-// lanes whose |a| lies in the numerator range of inv_div_core
-__device__ __forceinline__ lanemask_t inv_div_numerator_mask(double a) {
-    return RR_LANES(fabs(a) >= 0x1p-900) & RR_LANES(fabs(a) <= 0x1p900);
-}
-// ... or holds +0 (invdiv.h: inv_div_numerator_ok0).  One v_cmp_class_f64
-// (class bit 6 = +0) written directly into an SGPR pair; spelled as an
-// integer or class test in C++ it goes through the VGPR round trip above.
-__device__ __forceinline__ lanemask_t lanes_plus_zero(double a) {
-    lanemask_t m;
-    asm("v_cmp_class_f64 %0, %1, 0x40" : "=s"(m) : "v"(a));
-    return m;
-}
-// lanes whose value belongs to the given v_cmp_class_f64 classes
-// (bit 3 -normal, 4 -subnormal, 5 -0, 6 +0, 7 +subnormal, 8 +normal, 9 +inf)
+// Class tests written directly into an SGPR pair with one v_cmp_class_f64
+// (spelled as an integer or class test in C++ they go through the VGPR round
+// trip above).  Class bits: 3 -normal, 4 -subnormal, 5 -0, 6 +0, 7 +subnormal,
+// 8 +normal, 9 +inf.
 __device__ __forceinline__ lanemask_t lanes_of_class(double a, int classes) {
     lanemask_t m;
     asm("v_cmp_class_f64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(classes));
     return m;
 }
-// lanes holding a finite value
+__device__ __forceinline__ lanemask_t lanes_plus_zero(double a) {
+    lanemask_t m;
+    asm("v_cmp_class_f64 %0, %1, 0x40" : "=s"(m) : "v"(a));   // inline constant
+    return m;
+}
 __device__ __forceinline__ lanemask_t lanes_finite(double a) {
     return lanes_of_class(a, 0x1f8);
 }
+
+// lanes whose a suits inv_div_core as a numerator: |a| in [2^-900, 2^900], or
+// +0 (invdiv.h: inv_div_numerator_ok0)
 __device__ __forceinline__ lanemask_t inv_div_numerator_mask0(double a) {
     return (RR_LANES(fabs(a) >= 0x1p-900) | lanes_plus_zero(a)) &
            RR_LANES(fabs(a) <= 0x1p900);
 }
 
 // a / d.b, bit-identical to `/` for EVERY input, with the vote done on lane
-// masks: a_ok = inv_div_numerator_mask[0](a) (shared by all quotients of one
-// numerator), d_ok = RR_LANES(d.ok), hoisted out of the time loop by the
-// caller.  If any active lane is outside the fast form's domain the whole
+// masks: a_ok = inv_div_numerator_mask0(a) or any mask that implies it
+// (shared by all quotients of one numerator), d_ok = RR_LANES(d.ok), hoisted
+// out of the time loop by the caller.  If any active lane is outside the fast form's domain the whole
 // wave evaluates the IEEE division and those lanes take it.
 __device__ __forceinline__ double div_by_invariant_m(double a, lanemask_t a_ok,
                                                      const InvDivisor &d,
