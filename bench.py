@@ -330,15 +330,17 @@ def main():
         bytes_per_step = {"qsim": 8, "metric": 0,
                           "storages": all_out[args.model]}[args.mode]
         achieved = bytes_per_step * n * t / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = valu = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         key = "%s:%s:%d:%d" % (args.model, args.mode, n, t)
         if os.path.exists(tpath):
             try:
                 with open(tpath) as fh:
-                    traffic = json.load(fh).get(key)
+                    pmc = json.load(fh)
+                traffic = pmc.get(key)
+                valu = pmc.get(key + ":valu_instr_per_unit")
             except Exception:
-                traffic = None
+                traffic = valu = None
         out = {
             "metric": "model-timesteps/s",
             "value": value,
@@ -380,6 +382,10 @@ def main():
                 "kernel_ms": kernel_ms,
                 "kernel": "%s ensemble kernel, %d B/model-timestep "
                           "algorithmic" % (name, bytes_per_step),
+                # what actually limits the 8 B/unit mode (profiles/README.md):
+                # fp64 VALU issue; instructions per model-timestep from the
+                # committed SQ_INSTS_VALU pass (null for other workloads)
+                "valu_instr_per_unit": valu,
             },
             "scores_finite": finite,
         }
