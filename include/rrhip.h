@@ -245,7 +245,9 @@ int rr_sample_params_dev(uint64_t key, int k, const double *lo,
 
 /* ==== next tier: SWE-SCA hysteresis snow routine, ice melt, couplings ====
  * The reference's CemaneigeHystGR4J, CemaneigeGR4JIce, CemaneigeHystGR4JIce
- * (SURVEY.md section 8f N1).  Same conventions as above; 1 <= L <= 8;
+ * (SURVEY.md section 8f N1).  Same conventions as above; any L >= 1 (more
+ * than RR_CEMANEIGE_MAX_LAYERS layers run from an HBM state scratch that is
+ * part of the workspace, so size it with the N of the call);
  * `frac_ice` is [L]; sca is [T][L][ld]; icemelt, snowmelt are [T][ld]
  * (snowmelt = the snow routine's layer-mean outflow before the ice melt is
  * added).  All variants share one workspace size. */

@@ -25,13 +25,15 @@ static inline size_t cema_days_bytes(int64_t T, int64_t L, bool with_etp)
     return rr_align256((size_t)T * (size_t)(3 * L + (with_etp ? 1 : 0)) * 8);
 }
 
-// + the [2][L][N] snow-state scratch when the layers do not fit in registers
-static inline size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp, int64_t N)
+// + the [nstate][L][N] snow-state scratch when the layers do not fit in
+// registers (nstate = 2: G, eTG; 4 with the hysteresis' sca and SWE maximum)
+static inline size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp,
+                                   int64_t N, int nstate = 2)
 {
     size_t b = 512 + rr_align256((size_t)(L > 0 ? L : 1) * 16) +
                cema_days_bytes(T, L, with_etp);
     if (L > RR_CEMANEIGE_MAX_LAYERS && N > 0)
-        b += rr_align256((size_t)2 * (size_t)L * (size_t)N * 8);
+        b += rr_align256((size_t)nstate * (size_t)L * (size_t)N * 8);
     return b;
 }
 

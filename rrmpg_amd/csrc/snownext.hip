@@ -205,6 +205,144 @@ snow_gr4j_kernel(
     if (we && active) sse[i] = acc;
 }
 
+// ---- more than RR_CEMANEIGE_MAX_LAYERS elevation layers ----------------------
+// The same day step with a run-time layer count (as cemaneige_dyn_kernel does
+// for the plain snow routine): the per-layer states -- G, eTG and, with the
+// hysteresis, sca and the pre-melt SWE maximum -- live in an HBM scratch
+// [4][L][N] (lane-contiguous: every access is a coalesced 512-byte row per
+// wave) instead of registers.  Rare, so it favours simplicity: plain `/`
+// (bit-identical to the 3-FMA quotients by construction), no unrolling.
+template <class UH, bool HYST, bool ICE>
+__global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
+    SnowOut /* read through the kernarg segment, see SnowOut */,
+    const double *__restrict__ days, const double *__restrict__ gtresh,
+    const double *__restrict__ frac_ice, int64_t T, int L,
+    double snow_pack_init, double thermal_state_init, double sca_init,
+    double s_init, double r_init, const double *__restrict__ params,
+    SnowParLayout lay, int64_t N, int n1cap, int n2cap, int wq, int ws,
+    double *__restrict__ state, const double *__restrict__ qobs,
+    double *__restrict__ sse)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = i < N;
+    // tail lanes of the last wave share (and rewrite identically) set N-1's
+    // scratch column, like the register kernels recompute it
+    const int64_t ii = active ? i : N - 1;
+    const double *p = params + ii * lay.npar;
+    const double CTG = p[0], Kf = p[1];
+    const double Thacc = HYST ? p[2] : 1.0, Rsp = HYST ? p[3] : 0.0;
+    const double ddf = ICE ? p[lay.i_ddf] : 0.0;
+    Gr4jPar P;
+    P.set(p[lay.i_x1], p[lay.i_x1 + 1], p[lay.i_x1 + 2], p[lay.i_x1 + 3]);
+    const double omc = 1 - CTG;
+    const int64_t plane = (int64_t)L * N;
+    double *Gs = state + ii, *Es = Gs + plane, *Ss = Es + plane,
+           *Ms = Ss + plane;
+    const double *psol = gtresh + L;
+    const double sca_prev0 = (T == 1) ? sca_init : 0.0;
+    UH uh;
+    if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
+    else uh.init(P.x4);
+    double s = s_init * P.x1, r = r_init * P.x3;
+    double acc = 0.0;
+    const bool we = sse != nullptr;
+    const int D = 3 * L + 1;
+    for (int64_t t = 0; t < T; ++t) {
+        const double *day = days + t * D;
+        const bool first = t == 0;
+        SnowOut o = {};
+        int64_t ld = 0;
+        if (wq | ws) {
+            snow_out_ptr_t po =
+                (snow_out_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(po));
+            o.qsim = po->qsim; o.G = po->G; o.eTG = po->eTG;
+            o.s_store = po->s_store; o.r_store = po->r_store;
+            o.sca = po->sca; o.icemelt = po->icemelt;
+            o.snowmelt = po->snowmelt;
+            ld = po->ld;
+        }
+        double c = 0.0, ice_total = 0.0;
+        for (int l = 0; l < L; ++l) {
+            const double snow = day[l], rain = day[L + l],
+                         temp = day[2 * L + l];
+            const int64_t at = (int64_t)l * N;
+            double g, e;
+            if (first) {
+                g = snow_pack_init;
+                e = thermal_state_init;
+            } else {
+                g = Gs[at] + snow;
+                e = CTG * Es[at] + omc * temp;
+            }
+            if (e > 0) e = 0.0;
+            double pot_melt = 0.0;
+            if (e == 0 && temp > 0) {
+                pot_melt = Kf * temp;
+                if (pot_melt > g) pot_melt = g;
+            }
+            double melt, sc = 0.0;
+            if constexpr (HYST) {           // cemaneigehyst_model.py:123-158
+                double mx = first ? 0.0 : Ms[at];
+                const double snow_balance = snow - pot_melt;
+                if (snow_balance >= 0) {
+                    const double prev = first ? sca_prev0 : Ss[at];
+                    sc = prev + snow_balance / Thacc;
+                    mx = nb_max(mx, g);
+                } else {
+                    const double Thmelt = psol[l] * Rsp;
+                    const double Thmax = (mx > Thmelt) ? Thmelt : mx;
+                    sc = (Thmax > 0) ? g / Thmax : 0.0;
+                }
+                sc = nb_min(nb_max(sc, 0.0), 1.0);
+                melt = (0.9 * sc + 0.1) * pot_melt;
+                melt = nb_min(melt, g);
+                g = g - melt;
+                if (g == 0) mx = 0.0;
+                Ss[at] = sc;
+                Ms[at] = mx;
+            } else {                        // cemaneige_model.py:109-118
+                const double gt = gtresh[l];
+                const double ratio = (g < gt) ? g / gt : 1.0;
+                melt = (0.9 * ratio + 0.1) * pot_melt;
+                g = g - melt;
+            }
+            Gs[at] = g;
+            Es[at] = e;
+            if constexpr (ICE) {            // icemelt_model.py:55-63
+                double im = ddf * temp;
+                if (im < 0) im = 0.0;
+                const double lw = (g > 1) ? 0.0 : im;
+                ice_total += lw * frac_ice[l];
+            }
+            if (ws && active) {
+                o.G[(t * L + l) * ld + i] = g;
+                o.eTG[(t * L + l) * ld + i] = e;
+                if (HYST) o.sca[(t * L + l) * ld + i] = sc;
+            }
+            c += rain + melt;
+        }
+        const double snowmelt = c / (double)L;
+        const double liquid = ICE ? snowmelt + ice_total : snowmelt;
+        const double q = gr4j_step<UH, true>(P, s, r, uh, liquid, day[3 * L]);
+        if (active) {
+            if (wq) o.qsim[t * ld + i] = q;
+            if (ws) {
+                o.s_store[t * ld + i] = s;
+                o.r_store[t * ld + i] = r;
+                if (ICE) o.icemelt[t * ld + i] = ice_total;
+                if (HYST && ICE) o.snowmelt[t * ld + i] = snowmelt;
+            }
+        }
+        if (we) {
+            const double d = qobs[t] - q;
+            acc = __builtin_fma(d, d, acc);
+        }
+    }
+    if (we && active) sse[i] = acc;
+}
+
 template <bool HYST, bool ICE>
 static int snow_gr4j_dev(const char *who, const double *prec,
                          const double *mean_temp, const double *etp,
@@ -221,9 +359,8 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     int rc = rr_check_common(who, T, N, ld, params, qobs, sse);
     if (rc != RR_OK) return rc;
     if (T == 0 || N == 0) return RR_OK;
-    if (L < 1 || L > RR_CEMANEIGE_MAX_LAYERS) {
-        rr_set_error("%s: %lld elevation layers; this model supports 1..%d",
-                     who, (long long)L, RR_CEMANEIGE_MAX_LAYERS);
+    if (L < 1 || L > 100000) {
+        rr_set_error("%s: %lld elevation layers", who, (long long)L);
         return RR_E_PARAM;
     }
     if (!prec || !mean_temp || !etp || !frac_solid_prec || (ICE && !frac_ice)) {
@@ -239,7 +376,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
         rr_set_error("%s: pass all %d storage outputs or none", who, want);
         return RR_E_NULL;
     }
-    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true, 0)) {
+    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true, N, 4)) {
         rr_set_error("%s: workspace too small", who);
         return RR_E_WORKSPACE;
     }
@@ -262,6 +399,19 @@ static int snow_gr4j_dev(const char *who, const double *prec,
         (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
     const SnowOut out = {qsim, G, eTG, s_store, r_store, sca, icemelt,
                          snowmelt, ld};
+    if (L > RR_CEMANEIGE_MAX_LAYERS) {
+        gr4j_dispatch_uh(tier, [&](auto uh) {
+            using UH = decltype(uh);
+            snow_gr4j_dyn_kernel<UH, HYST, ICE>
+                <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
+                   st>>>(out, days, gt, frac_ice, T, (int)L, snow_pack_init,
+                         thermal_state_init, sca_init, s_init, r_init, params,
+                         lay, N, n1cap, n2cap, qsim != nullptr, G != nullptr,
+                         state, qo, sse);
+        });
+        RR_HIP(hipGetLastError());
+        return RR_OK;
+    }
     dispatch_layers((int)L, [&](auto LL) {
         gr4j_dispatch_uh(tier, [&](auto uh) {
             using UH = decltype(uh);
@@ -279,8 +429,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
 
 extern "C" size_t rr_snowgr4j_workspace_bytes(int64_t T, int64_t L, int64_t N)
 {
-    (void)N;
-    return cema_ws_bytes(T, L, true, 0);
+    return cema_ws_bytes(T, L, true, N, 4);   // N only matters for L > 8
 }
 
 extern "C" int rr_cemaneigehystgr4j_simulate_dev(

@@ -175,11 +175,58 @@ def test_next_tier_validation_and_limits(models):
     with pytest.raises(ValueError, match="Invalid loss_metric"):
         models.CemaneigeHystGR4J().fit(s, s, s, s, s, s, 500,
                                        loss_metric="nse")
-    # more than 8 layers: loud error for these models
-    alts = list(np.linspace(500, 3000, 9))
-    with pytest.raises(RuntimeError, match="RR_E_PARAM"):
-        models.CemaneigeHystGR4J().simulate(s, s, s, s, s, 500,
-                                            altitudes=alts)
+
+
+def test_next_tier_many_layers_vs_oracle(models, oracle):
+    """More than 8 elevation layers run through the HBM-scratch kernel
+    (snow_gr4j_dyn_kernel): every series against the oracle, snow states
+    bit-exact, for the three couplings, with register- and LDS-tier unit
+    hydrographs, ragged set counts and the fused error sum."""
+    from rrmpg_amd.models import _snowgr4j as core
+    from rrmpg_amd.models import cemaneige_utils as cu
+    from rrmpg_amd.utils import synthetic as syn
+    from rrmpg_amd.utils.metrics import calc_mse
+    t = 700
+    f = syn.make_forcing(t)
+    for nl in (9, 13):
+        alts = np.linspace(520, 3100, nl)
+        lp = cu.extrapolate_precipitation(f["prec"], alts, 500)
+        lmin, lmean, lmax = cu.extrapolate_temperature(
+            f["tmin"] - 2, f["temp"] - 2, f["tmax"] - 2, alts, 500)
+        fr = cu.calculate_solid_fraction(lp, alts, lmean, lmin, lmax)
+        layers = (lp, lmean, fr, f["etp"])
+        fice = np.linspace(0.0, 0.8, nl)
+        inits = (2.0, -0.1, 0.3, 0.5, 0.6)
+        for (hyst, ice), cls in [((True, False), models.CemaneigeHystGR4J),
+                                 ((False, True), models.CemaneigeGR4JIce),
+                                 ((True, True), models.CemaneigeHystGR4JIce)]:
+            np.random.seed(31 + nl)
+            n = 77
+            p = cls().get_random_params(n)
+            flat = np.stack([p[k] for k in cls._param_list], 1)
+            if nl == 13:            # long unit hydrographs: LDS tier
+                flat[:, cls._param_list.index("x4")] = \
+                    np.random.uniform(0.6, 14.0, n)
+                for j, k in enumerate(cls._param_list):
+                    p[k] = flat[:, j]
+            out, _ = core.run(hyst, ice, layers, fice if ice else None, inits,
+                              p, True, True, None)
+            ref = oracle.simulate_snow_gr4j(
+                hyst, ice, lp, lmean, f["etp"], fr, inits, flat,
+                frac_ice=fice if ice else None, return_storages=True)
+            for key in ("G", "eTG") + (("sca",) if hyst else ()):
+                assert np.array_equal(out[key], ref[key]), (nl, hyst, ice, key)
+            for key in ("qsim", "s_store", "r_store") + \
+                    (("icemelt",) if ice else ()) + \
+                    (("snowmelt",) if hyst and ice else ()):
+                assert rel_err(out[key], ref[key], floor=1e-9) < 1e-10, \
+                    (nl, hyst, ice, key)
+            qobs = ref["qsim"][:, 5] * 1.05
+            _, sse = core.run(hyst, ice, layers, fice if ice else None, inits,
+                              p, False, False, qobs)
+            for j in (0, 5, n - 1):
+                want = calc_mse(qobs, out["qsim"][:, j])
+                assert abs(sse[j] / t - want) <= 1e-10 * max(want, 1e-12)
 
 
 def test_next_tier_fit_losses(models):
