@@ -69,10 +69,12 @@ __device__ __forceinline__ lanemask_t lanes_finite(double a) {
 }
 
 // lanes whose a suits inv_div_core as a numerator: |a| in [2^-900, 2^900], or
-// +0 (invdiv.h: inv_div_numerator_ok0)
-__device__ __forceinline__ lanemask_t inv_div_numerator_mask0(double a) {
+// +0 (invdiv.h: inv_div_numerator_ok0).  A caller may tighten the upper
+// bound (`hi` <= 2^900).
+__device__ __forceinline__ lanemask_t inv_div_numerator_mask0(
+    double a, double hi = 0x1p900) {
     return (RR_LANES(fabs(a) >= 0x1p-900) | lanes_plus_zero(a)) &
-           RR_LANES(fabs(a) <= 0x1p900);
+           RR_LANES(fabs(a) <= hi);
 }
 
 // a / d.b, bit-identical to `/` for EVERY input, with the vote done on lane
@@ -82,10 +84,11 @@ __device__ __forceinline__ lanemask_t inv_div_numerator_mask0(double a) {
 // wave evaluates the IEEE division and those lanes take it.
 __device__ __forceinline__ double div_by_invariant_m(double a, lanemask_t a_ok,
                                                      const InvDivisor &d,
-                                                     lanemask_t d_ok) {
+                                                     lanemask_t d_ok,
+                                                     double hi = 0x1p900) {
     double q = inv_div_core(a, d);
     if (rr_exec() & ~(a_ok & d_ok)) {
-        const bool ok = inv_div_numerator_ok0(a) && d.ok;
+        const bool ok = inv_div_numerator_ok0(a) && fabs(a) <= hi && d.ok;
         const double exact = a / d.b;
         q = ok ? q : exact;        // ok lanes: both values are RN(a / b)
     }

@@ -297,7 +297,7 @@ FP_FN bool fastpow_tab_ok(double x, double z)
 // (libm: 1 ulp), measured by tests/native/fastmath_harness.cpp.
 // Used for np.tanh(p_n / x1) of GR4J (reference: gr4j_model.py:95-96, 107-108).
 // fast_tanh_parts gives numerator and denominator (tanh(a) = num / den,
-// den >= 2) so that a caller can fold the quotient into one of its own.
+// den >= 1) so that a caller can fold the quotient into one of its own.
 //
 // JIT_CONST (device only): the 15 constants are fetched from constant memory
 // with scalar loads at the point of use instead of living in SGPRs for the
@@ -352,10 +352,14 @@ FP_FN void fast_tanh_parts(double a, double &num, double &den)
         q = FP_FMA_C(q, r, 0.5);
         p = FP_FMA(r * r, q, r);                     // expm1(r)
     }
-    const double two_n = FP_LDEXP(1.0, (int)n);
-    const double E = FP_FMA(two_n, p, two_n - 1.0);  // expm1(2|a|)
-    num = __builtin_copysign(E, a);
-    den = E + 2.0;
+    // H = expm1(2|a|) / 2 and H + 1: tanh = H / (H + 1).  (Halved so that a
+    // caller multiplying num by a huge factor -- GR4J with x1 ~ 1e308 and a
+    // net rainfall tiny next to it -- overflows exactly where the product
+    // with tanh itself would: for |a| -> 0, H + 1 -> 1.)
+    const double half_two_n = FP_LDEXP(1.0, (int)n - 1);
+    const double H = FP_FMA(half_two_n, p, half_two_n - 0.5);
+    num = __builtin_copysign(H, a);
+    den = H + 1.0;
 }
 
 FP_FN double fast_tanh(double a)

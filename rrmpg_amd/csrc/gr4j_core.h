@@ -39,12 +39,18 @@ struct Gr4jPar {
     }
 };
 
+// Numerators of the 3-FMA quotients of this model stay below 2^196 (~1e59)
+// on the fast form: no store or flux of a sane run comes near, and with it
+// the folded update of gr4j_step_net cannot overflow early.
+#define GR4J_NUM_HI 0x1p196
+
 // a / x for the per-lane invariant x (bit-identical to `/`, see common.h);
 // stores run dry, so exact zeros stay on the fast form
 __device__ __forceinline__ double gr4j_div(double a, const InvDivisor &d,
                                            lanemask_t d_ok)
 {
-    return div_by_invariant_m(a, inv_div_numerator_mask0(a), d, d_ok);
+    return div_by_invariant_m(a, inv_div_numerator_mask0(a, GR4J_NUM_HI), d,
+                              d_ok, GR4J_NUM_HI);
 }
 
 // _s_curve1 (gr4j_model.py:159-173); t is the integer ordinate index
@@ -310,6 +316,33 @@ __device__ __forceinline__ double pow_3_5(double x)
     return x * x * x * root;
 }
 
+// The production store's gain (wet day, eq. 3, gr4j_model.py:95-96) or loss
+// (dry day, eq. 4, :107-108) is c*th / (1 + k*th), th = tanh(net/x1), with
+__device__ __forceinline__ void gr4j_store_coefficients(bool wet, double s,
+                                                        double x1, double sx,
+                                                        double &c, double &k)
+{
+    if (wet) {
+        c = x1 * (1 - sx * sx);
+        k = sx;
+    } else {
+        c = s * (2 - sx);
+        k = 1 - sx;
+    }
+}
+
+// ... evaluated the reference's way (IEEE quotient s/x1, two divisions) for
+// the lanes gr4j_step_net's vote sends here (out-of-line variant, used by the
+// UhRegs<10> kernels).
+__device__ __attribute__((noinline)) double gr4j_store_change_reference(
+    bool wet, double s, double x1, double E, double D)
+{
+    double c, k;
+    gr4j_store_coefficients(wet, s, x1, s / x1, c, k);
+    const double th = E / D;
+    return c * th / (1 + k * th);
+}
+
 // One day of GR4J (gr4j_model.py:86-154).  s, r: production / routing store
 // (in/out).  Returns the simulated discharge of the day.
 // `wet` / `net`: net rainfall or net evapotranspiration (:89-111) -- which
@@ -323,21 +356,42 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
                                                 double &r, UH &uh, double net,
                                                 bool wet)
 {
-    const double sx = gr4j_div(s, P.inv_x1, P.x1_m);
-    // tanh(net/x1) = E / D (fastmath.h); its quotient is folded into the
-    // store update's own:  c*th / (1 + k*th) == c*E / (D + k*E), one
-    // division per day instead of two
+    // tanh(net/x1) = E / D (fastmath.h: E = expm1(2a)/2, D = E + 1); its
+    // quotient is folded into the store update's own:
+    //     c*th / (1 + k*th) == c*E / (D + k*E),
+    // one division per day instead of two.
     double E, D;
     fast_tanh_parts<JIT_CONST>(gr4j_div(net, P.inv_x1, P.x1_m), E, D);
-    double num, den;
-    if (wet) {
-        num = P.x1 * (1 - sx * sx) * E;             // eq. 3 (:95-96)
-        den = D + sx * E;
-    } else {
-        num = s * (2 - sx) * E;                     // eq. 4 (:107-108)
-        den = D + (1 - sx) * E;
+    // One vote covers the 3-FMA quotient s/x1 and the folded form: with
+    // |s| in {0} u [2^-900, 2^196] and |x1| in [2^-100, 2^100] (invdiv.h) the
+    // quotient is exact and |s/x1| <= 2^296, so c*E and k*E (E <= 1.2e17,
+    // |c| <= 2^692) stay finite
+    // -- they are D times the reference's own c*th, k*th and would otherwise
+    // overflow before those do.  Any other lane sends the wave through the
+    // reference's own sequence (IEEE quotient, two divisions).
+    const lanemask_t fast =
+        inv_div_numerator_mask0(s, GR4J_NUM_HI) & P.x1_m;
+    const double sx = inv_div_core(s, P.inv_x1);
+    double c, k;
+    gr4j_store_coefficients(wet, s, P.x1, sx, c, k);
+    double frac = c * E / (D + k * E);
+    if (rr_exec() & ~fast) {
+        double exact;
+        if constexpr (std::is_same<UH, UhRegs<10>>::value) {
+            // measured: out of line is 2 % faster in these kernels, 1-2 %
+            // slower in the others
+            exact = gr4j_store_change_reference(wet, s, P.x1, E, D);
+        } else {
+            asm volatile("");                       // keep this a branch
+            double ce, ke;
+            gr4j_store_coefficients(wet, s, P.x1, s / P.x1, ce, ke);
+            const double th = E / D;
+            exact = ce * th / (1 + ke * th);
+        }
+        const bool ok = inv_div_numerator_ok0(s) && fabs(s) <= GR4J_NUM_HI &&
+                        P.inv_x1.ok;
+        frac = ok ? frac : exact;
     }
-    const double frac = num / den;
     // s - e_s + p_s (:114) and p_n - p_s (:123) with the branch's zeros
     // dropped (x - 0 and x + 0 are x)
     double sn, excess;
