@@ -25,7 +25,7 @@ def flat(p, cls):
 def main():
     f = syn.make_forcing()
     n = 1000
-    np.random.seed(7)
+    np.random.seed(int(os.environ.get("RR_PARITY_SEED", "7")))
     rows = []
     p = models.ABCModel().get_random_params(n)
     out = models.ABCModel().simulate(f["prec"], 2.0, True, p)
