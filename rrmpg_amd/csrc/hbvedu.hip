@@ -13,16 +13,22 @@
 //              independent, so they are hoisted out of the N-fold sweep with
 //              the identical fp64 operation the reference performs per set.
 //              The record address is wave-uniform, so it is fetched with ONE
-//              scalar load burst (s_load_dwordx8 + x2) per day into SGPRs (scalar cache ->
-//              L2), never through the vector memory path.
+//              scalar load burst (s_load_dwordx8 + x2) per day into SGPRs
+//              (scalar cache -> L2), never through the vector memory path.
 //   params   : the reference's AoS double[N][11]; each lane reads its 11
 //              values once (88 B per set, amortised over T steps).
 //   outputs  : [T][ld] row-major, lane i <-> column i, so each wave stores
-//              512 contiguous bytes per output per day.
+//              512 contiguous bytes per output per day -- as a buffer store
+//              whose descriptor is the wave's row segment (common.h
+//              rr_store_row): scalar address arithmetic, tail columns
+//              dropped by the hardware.
+//   tables   : the logarithm table of the power function, 4 KiB in LDS.
 //
 // Arithmetic follows the reference statement by statement in fp64 without
 // FMA contraction (-ffp-contract=off); only the power (soil/FC)**Beta is not
-// libm's: it is fastmath.h's ~1-ulp evaluation (general pow as fallback).
+// libm's: it is fastmath.h's ~1-ulp table-driven evaluation (general pow as
+// fallback), and the two quotients by per-lane constants use invdiv.h's
+// correctly rounded 3-FMA form (bit-identical to `/`).
 #include <stdlib.h>
 
 #include "common.h"
