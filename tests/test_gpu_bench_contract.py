@@ -1,0 +1,68 @@
+"""bench.py's output contract, checked on a small workload: one JSON line on
+stdout with the keys the driver reads, roofline and cpu_baseline objects, and
+the two-rank path (gloo, both ranks on the one GPU of the test box) giving
+twice the single-rank units."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from .conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, cwd=REPO, env=e, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3",
+              "--warmup", "1", "--sets", "20000", "--days", "800"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "model-timesteps/s" and d["unit"] == d["metric"]
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["scores_finite"] is True
+    # value is units / time
+    units = 20000 * 800 * 3
+    assert abs(d["value"] - units / (d["ms_per_step"] * 3e-3)) \
+        <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - 8 * 20000 * 800 / (r["kernel_ms"] * 1e-3) / 1e9) \
+        <= 1e-6 * r["achieved"]
+    assert r["traffic"] is None          # PMC numbers exist for the default
+    c = d["cpu_baseline"]                # workload only
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert c["unit"] == "model-timesteps/s" and "sets" in c["sample"]
+
+
+def test_two_ranks_share_the_gpu_over_gloo():
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+              "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29577", "bench.py", "--gpus", "2", "--steps",
+              "2", "--warmup", "1", "--sets", "20000", "--days", "800",
+              "--backend", "gloo", "--share-gpu"],
+             env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 2 and "cpu_baseline" not in d
+    assert d["scores_finite"] is True
+    units = 2 * 20000 * 800 * 2
+    assert abs(d["value"] - units / (d["ms_per_step"] * 2e-3)) \
+        <= 1e-6 * d["value"]
