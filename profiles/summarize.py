@@ -14,13 +14,16 @@ import os
 import sys
 
 
+MIN_GRID = 0      # launches with fewer work-items are ignored (argv[4])
+
+
 def counters(path, match):
     acc = collections.defaultdict(list)
     dur = []
     meta = {}
     for f in glob.glob(os.path.join(path, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if match in r["Kernel_Name"]:
+            if match in r["Kernel_Name"] and float(r["Grid_Size"]) >= MIN_GRID:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size",
@@ -30,9 +33,28 @@ def counters(path, match):
             (sum(dur) / len(dur) / 1e6) if dur else None, meta)
 
 
+def trace_stats(root, match):
+    """Launch durations of the matching kernel from the kernel trace (the
+    stats CSV cannot tell a one-set helper launch of the same kernel from the
+    sweep)."""
+    dur = []
+    name = None
+    for f in glob.glob(os.path.join(root, "trace", "*", "*_kernel_trace.csv")):
+        for r in csv.DictReader(open(f)):
+            if match in r["Kernel_Name"] and float(r["Grid_Size_X"]) >= MIN_GRID:
+                dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                name = r["Kernel_Name"]
+    if not dur:
+        return None
+    return {"name": name, "calls": len(dur), "avg_ms": sum(dur) / len(dur) / 1e6,
+            "min_ms": min(dur) / 1e6, "max_ms": max(dur) / 1e6}
+
+
 def main():
+    global MIN_GRID
     tag, match = sys.argv[1], sys.argv[2]
     algo_bytes = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    MIN_GRID = float(sys.argv[4]) if len(sys.argv) > 4 else 0
     root = os.path.join("gpurun_out", "prof_" + tag)
     out = {"tag": tag, "kernel_match": match}
     stats = glob.glob(os.path.join(root, "trace", "*", "*_kernel_stats.csv"))
@@ -47,6 +69,10 @@ def main():
                     "min_ms": float(r["MinNs"]) / 1e6,
                     "max_ms": float(r["MaxNs"]) / 1e6,
                     "pct_of_gpu_time": float(r["Percentage"])}
+    if MIN_GRID:
+        ts = trace_stats(root, match)
+        if ts:
+            out["kernel_stats"] = ts
     fetch, d1, meta = counters(os.path.join(root, "pmc_fetch"), match)
     write, d2, _ = counters(os.path.join(root, "pmc_write"), match)
     sq, d3, _ = counters(os.path.join(root, "pmc_sq"), match)
