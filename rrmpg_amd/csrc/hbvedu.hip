@@ -86,12 +86,12 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 // multi-catchment launch (rr_hbvedu_simulate_catchments_dev) lays every array
 // out catchment-major: days [C][T], params [C][N][11], outputs [C][T][ld],
 // qobs [C][T], sse [C][N], inits [C][4].
-// LDS_FORCING (measurement variant, RRHIP_HBV_LDS_FORCING=1): instead of one
+// FORCING = 1 (measurement variant, RRHIP_HBV_LDS_FORCING=1): instead of one
 // scalar load per day, the wave copies 64 day records (2 KiB, coalesced) into
 // LDS and every lane reads them back by broadcast -- the staging north_star
 // sketched.  Kept to document the comparison (profiles/README.md): the scalar
 // path is the faster one, it costs no vector-memory or LDS instruction at all.
-template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, bool LDS_FORCING = false>
+template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0>
 __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     const HbvDay *__restrict__ days, int64_t T, double snow_init,
     double soil_init, double s1_init, double s2_init,
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         (void)t;
     };
 
-    if constexpr (LDS_FORCING) {
+    if constexpr (FORCING == 1) {
         __shared__ HbvDay tile[RR_BLOCK];
         for (int64_t t0 = 1; t0 < T; t0 += RR_BLOCK) {
             const int64_t tt = t0 + threadIdx.x;
@@ -265,6 +265,16 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
                 day_step(f, t0 + k);
             }
             __syncthreads();
+        }
+    } else if constexpr (FORCING == 2) {
+        // small sweeps (fewer than ~3 waves per SIMD): nothing hides the
+        // scalar load's latency, so the next day's record is requested
+        // before this day's arithmetic
+        HbvDay f = days[T > 1 ? 1 : 0];
+        for (int64_t t = 1; t < T; ++t) {
+            const HbvDay next = days[t + 1 < T ? t + 1 : t];
+            day_step(f, t);
+            f = next;
         }
     } else {
         for (int64_t t = 1; t < T; ++t) {
@@ -300,20 +310,28 @@ static int hbv_launch(const double *temp, const double *prec,
                        (qobs && sse) ? qobs : nullptr, T, days);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK), (unsigned)C);
     const bool any_s = snow != nullptr;
+    // forcing variant: 0 scalar load per day (default), 1 LDS staging
+    // (RRHIP_HBV_LDS_FORCING=1, measurement only), 2 scalar load with the next
+    // day prefetched: sweeps of at most one wave per SIMD (<= 65,536 sets,
+    // down to fit()'s single candidate), where nothing else hides the load --
+    // measured 3.72 vs 4.10 ms at 20k sets, but 4.52 vs 4.21 at 100k and
+    // 29.5 vs 28.4 at 1M (RRHIP_HBV_PREFETCH=0/1 overrides)
     const char *lds_env = getenv("RRHIP_HBV_LDS_FORCING");
-    const bool lds_forcing = lds_env && lds_env[0] == '1';
+    const char *pf_env = getenv("RRHIP_HBV_PREFETCH");
+    int variant = (rr_ceil_div(N, RR_BLOCK) * C <= 1024) ? 2 : 0;
+    if (pf_env) variant = pf_env[0] == '1' ? 2 : 0;
+    if (lds_env && lds_env[0] == '1') variant = 1;
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
                  [&](auto Q, auto S, auto E) {
-        if (lds_forcing)
-            hbvedu_kernel<Q.value, S.value, E.value, true>
+        auto go = [&](auto V) {
+            hbvedu_kernel<Q.value, S.value, E.value, V.value>
                 <<<grid, dim3(RR_BLOCK), 0, st>>>(
                     days, T, snow_init, soil_init, s1_init, s2_init, inits,
                     params, N, qsim, snow, soil, s1, s2, ld, qobs, sse);
-        else
-            hbvedu_kernel<Q.value, S.value, E.value, false>
-                <<<grid, dim3(RR_BLOCK), 0, st>>>(
-                    days, T, snow_init, soil_init, s1_init, s2_init, inits,
-                    params, N, qsim, snow, soil, s1, s2, ld, qobs, sse);
+        };
+        if (variant == 1) go(std::integral_constant<int, 1>{});
+        else if (variant == 2) go(std::integral_constant<int, 2>{});
+        else go(std::integral_constant<int, 0>{});
     });
     RR_HIP(hipGetLastError());
     return RR_OK;
