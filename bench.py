@@ -9,17 +9,26 @@ array materialised in HBM AND the per-set squared error accumulated in the
 kernel (what rrmpg.tools.monte_carlo computes: simulate + per-set MSE),
 followed (N > 1) by the single all-gather of the per-set scores over RCCL.
 Inputs (forcing, parameter block, output buffers) are resident in HBM before
-the timed region starts.  Weak scaling: every rank owns its own block of
---sets parameter sets.
+the timed region starts.
+
+Launch: one process per GPU over RCCL.  Under torchrun (WORLD_SIZE set) the
+ranks are taken from the environment; started plainly with --gpus N > 1 the
+script spawns its own N ranks (127.0.0.1 rendezvous) and rank 0 prints the
+line.  --scaling strong (default): --sets is the size of the WHOLE sweep,
+sharded into contiguous blocks of sets (rrmpg_amd.sharding.shard_bounds;
+1M sets -> 125k per GPU at N=8, BASELINE.json's "HBV 1M-param MC at 1/2/4/8
+MI355X"); --scaling weak: --sets per GPU.
 
 Default workload = the one BASELINE.json's metric is quoted on: HBV-Edu,
-1,000,000 parameter sets per GPU, 10,957 daily steps (30 years), fp64.
+1,000,000 parameter sets, 10,957 daily steps (30 years), fp64.
 Rank 0 prints ONE JSON line.
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,7 +56,11 @@ def parse_args():
                              "cemaneigehystgr4j", "cemaneigegr4jice",
                              "cemaneigehystgr4jice"])
     ap.add_argument("--sets", type=int, default=1_000_000,
-                    help="parameter sets per GPU")
+                    help="parameter sets: of the whole sweep (--scaling "
+                         "strong) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: --sets is the global count, sharded over "
+                         "the GPUs; weak: every GPU gets --sets")
     ap.add_argument("--days", type=int, default=10957)
     ap.add_argument("--catchments", type=int, default=0,
                     help="HBV-Edu only: C independent catchments x --sets "
@@ -69,11 +82,52 @@ def parse_args():
                          "population in HBM (rr_sample_params_dev, numpy's "
                          "Philox stream); host: Model.get_random_params + "
                          "upload, as the reference does")
+    ap.add_argument("--hbv-variant", type=int, default=-1,
+                    help="measurement hook: pin the HBV-Edu kernel variant "
+                         "(rr_debug_set_option RR_OPT_HBV_VARIANT)")
+    ap.add_argument("--no-parity-spot", action="store_true")
     return ap.parse_args()
 
 
-def build_workload(args, device, rank):
-    """Resident ensemble + parameter block + output buffers for one rank."""
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start N copies of this script, one
+    rank per GPU, rendezvous on 127.0.0.1.  Rank 0 inherits stdout (its one
+    JSON line is ours); any failing rank fails the job."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+            env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs and rc == 0:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = code
+            time.sleep(0.05)
+    finally:
+        for p in procs:                 # a rank failed: stop the others
+            p.kill()
+        for p in procs:
+            p.wait()
+    return rc
+
+
+def build_workload(args, device, rank, n, first, total_sets):
+    """Resident ensemble + parameter block + output buffers for one rank:
+    sets [first, first + n) of the total_sets-set sweep."""
     import torch
     from rrmpg_amd import device as rrdev
     from rrmpg_amd import models
@@ -81,7 +135,6 @@ def build_workload(args, device, rank):
 
     f = syn.make_forcing(args.days)
     np.random.seed(1 + rank)            # each rank: its own block of sets
-    n = args.sets
     if args.model == "hbvedu" and args.catchments > 0:
         return build_catchments(args, device, rank)
     if args.model == "hbvedu":
@@ -133,18 +186,23 @@ def build_workload(args, device, rank):
                                           device=device)
         name = "CemaneigeGR4J(L=5)"
     if args.sampler == "device":
-        world = int(os.environ.get("WORLD_SIZE", "1"))
+        # every rank draws ITS rows of one global population (counter-based
+        # Philox: no communication, same population for any number of GPUs)
         params = rrdev.sample_params(cls(), n, syn.FORCING_SEED,
-                                     n_total=n * world, first=rank * n,
+                                     n_total=total_sets, first=first,
                                      device=device)
         params_host = params[:min(n, 400000)].cpu().numpy()
+        p0 = rrdev.sample_params(cls(), 1, syn.FORCING_SEED,
+                                 n_total=total_sets, first=0, device=device)
     else:
         rec = cls().get_random_params(n)
         params = ens.upload_params(rec)
         params_host = np.stack([rec[k] for k in cls._param_list], 1)
-    # synthetic observations: the first set's run + 10 % noise
+        p0 = params[:1].contiguous()
+    # synthetic observations: the sweep's first set's run + 10 % noise (the
+    # same series on every rank with the device sampler)
     q0 = ens.new_output(1)
-    ens.run(params[:1].contiguous(), q0)
+    ens.run(p0, q0)
     torch.cuda.synchronize(device)
     qobs = torch.from_numpy(syn.make_qobs(q0.cpu().numpy())).to(device)
     qsim = ens.new_output(n) if args.mode != "metric" else None
@@ -244,11 +302,53 @@ def cpu_baseline(args, f, params_host):
     }
 
 
+def parity_spot(args, f, params_host, qsim, sse, qobs, n_cols=16):
+    """After the timed region: columns of the RESIDENT result against the CPU
+    oracle (checker only).  Returns the max relative error, or None where the
+    oracle has no direct entry for the workload."""
+    import torch
+    from oracle import pyoracle
+    from rrmpg_amd.utils import synthetic as syn
+    if args.catchments > 0 or args.model not in ("hbvedu", "gr4j", "abc"):
+        return None
+    m = params_host.shape[0]
+    cols = np.unique(np.linspace(0, m - 1, n_cols).astype(np.int64))
+    flat = np.ascontiguousarray(params_host[cols])
+    if args.model == "hbvedu":
+        inits = [syn.HBV_INITS[k] for k in ("snow_init", "soil_init",
+                                            "s1_init", "s2_init")]
+        ref = pyoracle.simulate_hbvedu(f["temp"], f["prec"], f["month"] - 1,
+                                       f["PE_m"], f["T_m"], inits, flat,
+                                       nthreads=4)
+    elif args.model == "gr4j":
+        ref = pyoracle.simulate_gr4j(f["prec"], f["etp"],
+                                     (syn.GR4J_INITS["s_init"],
+                                      syn.GR4J_INITS["r_init"]), flat)
+    else:
+        ref = pyoracle.simulate_abc(f["prec"], 2.5, flat)
+    if isinstance(ref, tuple):
+        ref = ref[0]
+    tcols = torch.from_numpy(cols).to(sse.device)
+    if qsim is not None:
+        got = qsim[:, tcols].cpu().numpy()
+        err = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-9)
+    else:                       # score-only mode: the fused sums themselves
+        qo = qobs.cpu().numpy()
+        want = ((qo[:, None] - ref) ** 2).sum(0)
+        err = np.abs(sse[tcols].cpu().numpy() - want) / want
+    if not np.all(np.isfinite(err)):
+        return float("nan")
+    return float(err.max())
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
-    from rrmpg_amd.sharding import allgather_scores
+    from rrmpg_amd import _lib
+    from rrmpg_amd.sharding import allgather_scores, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -269,11 +369,26 @@ def main():
         else:
             dist.init_process_group("gloo")
     on_host = world > 1 and args.backend == "gloo"
+    if args.hbv_variant >= 0:
+        _lib.check(_lib.load().rr_debug_set_option(
+            _lib.OPTIONS["hbv_variant"], args.hbv_variant),
+            "rr_debug_set_option")
 
+    # this rank's block of the parameter-set axis
+    scaling = "weak" if args.catchments > 0 else args.scaling
+    if scaling == "strong":
+        total_sets = args.sets
+        first, stop = shard_bounds(total_sets, world, rank)
+        n_sets = stop - first
+    else:
+        n_sets = args.sets
+        total_sets = n_sets * world
+        first = rank * n_sets
     (ens, params, params_host, qsim, storages, qobs, sse, name,
-     f) = build_workload(args, device, rank)
-    n, t = args.sets * max(1, args.catchments), args.days
-    total_sets = n * world
+     f) = build_workload(args, device, rank, n_sets, first, total_sets)
+    cmul = max(1, args.catchments)
+    n, t = n_sets * cmul, args.days
+    total_units = total_sets * cmul
 
     def launch():
         if storages is None:
@@ -281,12 +396,11 @@ def main():
         else:
             ens.run(params, qsim, storages, qobs=qobs, sse=sse)
 
-    def step():
-        launch()
+    def gather():
         # per-set MSE of this rank's block, then the one collective of the
         # whole job: all-gather of the scores (8 B per set)
         mse = sse.reshape(-1) / t
-        return allgather_scores(mse.cpu() if on_host else mse, total_sets)
+        return allgather_scores(mse.cpu() if on_host else mse, total_units)
 
     def fence():
         if world > 1:
@@ -294,35 +408,41 @@ def main():
         torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
-        scores = step()
+        launch()
+        scores = gather()
     fence()
 
     # kernel time: HIP events on the stream the kernel is launched on (torch's
-    # current stream), bracketing only the library call of each step
-    ev = [(torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # current stream), bracketing only the library call of each step; a third
+    # event closes the score exchange
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+          for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
         launch()
         ev[k][1].record()
-        mse = sse.reshape(-1) / t
-        scores = allgather_scores(mse.cpu() if on_host else mse, total_sets)
+        scores = gather()
+        ev[k][2].record()
     fence()
     elapsed = time.perf_counter() - t0
 
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+    gather_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev]))
+    k_min = k_max = kernel_ms
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64,
-                            device="cpu" if on_host else device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    assert scores.numel() == total_sets
+        red = torch.tensor([elapsed, kernel_ms, -kernel_ms, gather_ms],
+                           dtype=torch.float64,
+                           device="cpu" if on_host else device)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        elapsed, k_max, k_min, gather_ms = (float(red[0]), float(red[1]),
+                                            -float(red[2]), float(red[3]))
+    assert scores.numel() == total_units
     finite = bool(torch.isfinite(scores).all().item())
 
     if rank == 0:
-        value = total_sets * t * args.steps / elapsed
+        value = total_units * t * args.steps / elapsed
         all_out = {"hbvedu": 40, "abc": 16, "gr4j": 24, "cemaneigegr4j": 104,
                    "cemaneige": 88,
                    "cemaneigehystgr4j": 0, "cemaneigegr4jice": 0,
@@ -341,6 +461,15 @@ def main():
                 valu = pmc.get(key + ":valu_instr_per_unit")
             except Exception:
                 traffic = valu = None
+        what = {"qsim": "qsim[T,N] written to HBM + fused per-set MSE",
+                "metric": "fused per-set MSE only",
+                "storages": "qsim and every state series written to HBM + "
+                            "fused per-set MSE"}[args.mode]
+        if scaling == "strong":
+            size = ("%d parameter sets in total (contiguous shards of %d per "
+                    "GPU)" % (total_units, n))
+        else:
+            size = "%d parameter sets per GPU" % n
         out = {
             "metric": "model-timesteps/s",
             "value": value,
@@ -350,22 +479,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s Monte-Carlo sweep, %d parameter sets per GPU x "
-                            "%d daily steps, %s, RCCL all-gather of per-set "
-                            "MSE" % (name, n, t,
-                                     {"qsim": "qsim[T,N] written to HBM + "
-                                              "fused per-set MSE",
-                                      "metric": "fused per-set MSE only",
-                                      "storages": "qsim and every state "
-                                                  "series written to HBM + "
-                                                  "fused per-set MSE"
-                                      }[args.mode]),
+                "workload": "%s Monte-Carlo sweep, %s x %d daily steps, %s, "
+                            "RCCL all-gather of per-set MSE"
+                            % (name, size, t, what),
                 "model": args.model,
+                "sets_total": total_units,
                 "sets_per_gpu": n,
                 "timesteps": t,
                 "mode": args.mode,
@@ -387,12 +510,20 @@ def main():
                 # committed SQ_INSTS_VALU pass (null for other workloads)
                 "valu_instr_per_unit": valu,
             },
+            # HIP-event time of the sweep kernel on the slowest / fastest
+            # rank, and of the score exchange (MSE division + all-gather)
+            "kernel_ms_per_rank": {"min": k_min, "max": k_max},
+            "allgather_ms": gather_ms,
             "scores_finite": finite,
         }
+        if not args.no_parity_spot:
+            # columns of the resident result vs the CPU oracle, after timing
+            out["parity_spot"] = parity_spot(args, f, params_host, qsim, sse,
+                                             qobs)
         if (not args.no_cpu_baseline and world == 1
                 and args.catchments == 0):
             out["cpu_baseline"] = cpu_baseline(args, f, params_host)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -79,6 +79,24 @@ const char *rr_last_error(void);
 int rr_set_device(int device);
 int rr_get_device(void);
 
+/* Measurement / test hooks.  Process-wide integer options that select a
+ * specific kernel variant for A/B measurements and for parity tests that
+ * must reach a variant the size heuristics would not pick.  The launch paths
+ * read them as plain ints (no environment variables are consulted anywhere
+ * in the library).  rr_debug_set_option returns RR_E_PARAM for an unknown
+ * option or value; rr_debug_get_option returns the current value (or
+ * INT64_MIN for an unknown option). */
+#define RR_OPT_HBV_VARIANT     1 /* -1 heuristic (default); 0 one scalar load
+                                  * per day; 1 forcing staged in LDS; 2 next
+                                  * day's record prefetched                 */
+#define RR_OPT_GR4J_FORCE_LDS  2 /* 0 (default) / 1: unit hydrographs in LDS
+                                  * even where a register tier would do      */
+#define RR_OPT_MAX_BLOCK_COLS  3 /* 0 (default) = sized to free HBM; > 0 caps
+                                  * the host-pointer family's column blocks  */
+#define RR_OPT_COUNT_          4
+int rr_debug_set_option(int option, int64_t value);
+int64_t rr_debug_get_option(int option);
+
 /* ---- ABC model -------------------------------------------------------
  * replaces run_abcmodel(prec, initial_state, params)
  * (reference: rrmpg/models/abcmodel_model.py:15-60); params = {a, b, c}. */

@@ -32,6 +32,8 @@ _SIGNATURES = {
     "rr_last_error": (ctypes.c_char_p, []),
     "rr_set_device": (ctypes.c_int, [ctypes.c_int]),
     "rr_get_device": (ctypes.c_int, []),
+    "rr_debug_set_option": (ctypes.c_int, [ctypes.c_int, _i64]),
+    "rr_debug_get_option": (_i64, [ctypes.c_int]),
     "rr_column_sums_dev": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp,
                                           _vp]),
     "rr_sample_params_dev": (ctypes.c_int,
@@ -173,6 +175,31 @@ def set_device(index):
     """Run this process's later sweeps on HIP device `index` (one process per
     GPU: pass the local rank)."""
     check(load().rr_set_device(int(index)), "rr_set_device")
+
+
+# include/rrhip.h RR_OPT_*
+OPTIONS = {"hbv_variant": 1, "gr4j_force_lds": 2, "max_block_cols": 3}
+
+
+class debug_option:
+    """``with debug_option("hbv_variant", 0): ...`` pins a measurement / test
+    option of the library (rr_debug_set_option) and restores the previous
+    value afterwards."""
+
+    def __init__(self, name, value):
+        self.opt, self.value = OPTIONS[name], int(value)
+
+    def __enter__(self):
+        lib = load()
+        self.prev = int(lib.rr_debug_get_option(self.opt))
+        check(lib.rr_debug_set_option(self.opt, self.value),
+              "rr_debug_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        check(load().rr_debug_set_option(self.opt, self.prev),
+              "rr_debug_set_option")
+        return False
 
 
 def require_gpu():

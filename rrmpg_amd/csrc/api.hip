@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -29,6 +30,39 @@ void rr_set_error(const char *fmt, ...)
 
 extern "C" const char *rr_last_error(void) { return g_err; }
 extern "C" int rr_version(void) { return 100; }
+
+// ---- measurement / test options (rrhip.h RR_OPT_*) ---------------------------
+static std::atomic<int64_t> g_options[RR_OPT_COUNT_] = {
+    {0}, {-1} /* HBV variant: heuristic */, {0}, {0}};
+
+int64_t rr_option(int option)
+{
+    return g_options[option].load(std::memory_order_relaxed);
+}
+
+extern "C" int rr_debug_set_option(int option, int64_t value)
+{
+    bool ok = false;
+    switch (option) {
+    case RR_OPT_HBV_VARIANT: ok = value >= -1 && value <= 2; break;
+    case RR_OPT_GR4J_FORCE_LDS: ok = value == 0 || value == 1; break;
+    case RR_OPT_MAX_BLOCK_COLS: ok = value >= 0; break;
+    default: break;
+    }
+    if (!ok) {
+        rr_set_error("rr_debug_set_option: option %d does not take %lld",
+                     option, (long long)value);
+        return RR_E_PARAM;
+    }
+    g_options[option].store(value, std::memory_order_relaxed);
+    return RR_OK;
+}
+
+extern "C" int64_t rr_debug_get_option(int option)
+{
+    if (option < 1 || option >= RR_OPT_COUNT_) return INT64_MIN;
+    return rr_option(option);
+}
 
 extern "C" int rr_device_count(void)
 {
@@ -125,10 +159,8 @@ int64_t pick_block(int64_t T, int64_t N, const std::vector<OutSpec> &outs)
     nc = (nc / 256) * 256;
     if (nc < 256) nc = 256;
     // test hook: force a small column block to exercise the pitched gather
-    if (const char *env = getenv("RRHIP_MAX_BLOCK_COLS")) {
-        const long v = atol(env);
-        if (v > 0 && v < nc) nc = v;
-    }
+    const int64_t cap = rr_option(RR_OPT_MAX_BLOCK_COLS);
+    if (cap > 0 && cap < nc) nc = cap;
     return nc < N ? nc : N;
 }
 

@@ -129,6 +129,10 @@ __device__ __forceinline__ unsigned rr_row_bytes(int64_t first, int64_t N)
 // ---- error plumbing (host) ------------------------------------------------
 void rr_set_error(const char *fmt, ...);
 
+// Current value of a measurement / test option (rrhip.h RR_OPT_*): a relaxed
+// atomic load, nothing else -- this is what the launch paths consult.
+int64_t rr_option(int option);
+
 #define RR_HIP(call)                                                        \
     do {                                                                    \
         hipError_t _e = (call);                                             \

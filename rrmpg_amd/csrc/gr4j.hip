@@ -9,8 +9,6 @@
 // convolution state in registers (x4 <= 3 launch-wide) or staged in LDS
 // (gr4j_core.h).  The shared {prec, etp} day record is wave-uniform and is
 // fetched with one scalar s_load_dwordx4 per day.
-#include <stdlib.h>
-
 #include "gr4j_core.h"
 
 // One day of shared forcing as the kernel wants it (fetched by value with one
@@ -151,10 +149,9 @@ int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
                      (double)RR_GR4J_MAX_X4);
         return RR_E_PARAM;
     }
-    // RRHIP_GR4J_FORCE_LDS=1 (measurement hook): use the LDS tier even when
-    // a register tier would do
-    const char *force = getenv("RRHIP_GR4J_FORCE_LDS");
-    const bool lds = (force && force[0] == '1') || h[0] > 10;
+    // RR_OPT_GR4J_FORCE_LDS (measurement hook): use the LDS tier even when a
+    // register tier would do
+    const bool lds = rr_option(RR_OPT_GR4J_FORCE_LDS) == 1 || h[0] > 10;
     *tier = lds ? 0 : (h[0] <= 3 ? 3 : (h[0] <= 5 ? 5 : 10));
     *n1cap = lds ? h[0] : 0;
     *n2cap = lds ? 2 * h[0] + 1 : 0;

@@ -29,8 +29,6 @@
 // libm's: it is fastmath.h's ~1-ulp table-driven evaluation (general pow as
 // fallback), and the two quotients by per-lane constants use invdiv.h's
 // correctly rounded 3-FMA form (bit-identical to `/`).
-#include <stdlib.h>
-
 #include "common.h"
 #include "fastmath.h"
 
@@ -86,7 +84,7 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 // multi-catchment launch (rr_hbvedu_simulate_catchments_dev) lays every array
 // out catchment-major: days [C][T], params [C][N][11], outputs [C][T][ld],
 // qobs [C][T], sse [C][N], inits [C][4].
-// FORCING = 1 (measurement variant, RRHIP_HBV_LDS_FORCING=1): instead of one
+// FORCING = 1 (measurement variant, RR_OPT_HBV_VARIANT = 1): instead of one
 // scalar load per day, the wave copies 64 day records (2 KiB, coalesced) into
 // LDS and every lane reads them back by broadcast -- the staging north_star
 // sketched.  Kept to document the comparison (profiles/README.md): the scalar
@@ -311,16 +309,14 @@ static int hbv_launch(const double *temp, const double *prec,
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK), (unsigned)C);
     const bool any_s = snow != nullptr;
     // forcing variant: 0 scalar load per day (default), 1 LDS staging
-    // (RRHIP_HBV_LDS_FORCING=1, measurement only), 2 scalar load with the next
-    // day prefetched: sweeps of at most one wave per SIMD (<= 65,536 sets,
-    // down to fit()'s single candidate), where nothing else hides the load --
-    // measured 3.72 vs 4.10 ms at 20k sets, but 4.52 vs 4.21 at 100k and
-    // 29.5 vs 28.4 at 1M (RRHIP_HBV_PREFETCH=0/1 overrides)
-    const char *lds_env = getenv("RRHIP_HBV_LDS_FORCING");
-    const char *pf_env = getenv("RRHIP_HBV_PREFETCH");
+    // (measurement only), 2 scalar load with the next day prefetched: sweeps
+    // of at most one wave per SIMD (<= 65,536 sets, down to fit()'s single
+    // candidate), where nothing else hides the load -- measured 3.72 vs
+    // 4.10 ms at 20k sets, but 4.52 vs 4.21 at 100k and 29.5 vs 28.4 at 1M.
+    // rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one (tests, A/B runs).
     int variant = (rr_ceil_div(N, RR_BLOCK) * C <= 1024) ? 2 : 0;
-    if (pf_env) variant = pf_env[0] == '1' ? 2 : 0;
-    if (lds_env && lds_env[0] == '1') variant = 1;
+    const int64_t pinned = rr_option(RR_OPT_HBV_VARIANT);
+    if (pinned >= 0) variant = (int)pinned;
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
                  [&](auto Q, auto S, auto E) {
         auto go = [&](auto V) {

@@ -143,6 +143,24 @@ class BaseModel(object):
                 params = np.expand_dims(params, params.ndim)
         return params
 
+    def _sweep(self, params, qobs, want_qsim, **kwargs):
+        """What rrmpg_amd.tools.monte_carlo runs for every model: simulate all
+        parameter sets, return (qsim or None, per-set squared-error sums or
+        None).  This generic form goes through ``simulate`` exactly as the
+        reference's monte_carlo does (monte_carlo.py:64) and scores the
+        returned array; the model classes override it with a call that
+        accumulates the squared errors inside the GPU kernel."""
+        qsim = self.simulate(params=params, **kwargs)
+        if isinstance(qsim, tuple):          # return_storage(s)=True was set
+            qsim = qsim[0]
+        sse = None
+        if qobs is not None:
+            if qsim.shape[0] != len(qobs):
+                raise ValueError("Arrays must have the same size.")
+            d = np.asarray(qobs, dtype=np.float64)[:, None] - qsim
+            sse = np.einsum("tn,tn->n", d, d)
+        return (qsim if want_qsim else None), sse
+
     @classmethod
     def _params_from_population(cls, X):
         """Parameter records from the optimiser's candidates.

@@ -74,6 +74,21 @@ class CemaneigeGR4JIce(BaseModel):
                     out["r_store"], out["icemelt"])
         return out["qsim"]
 
+    def _sweep(self, params, qobs, want_qsim, prec, mean_temp, min_temp,
+               max_temp, etp, frac_ice, met_station_height, snow_pack_init=0,
+               thermal_state_init=0, s_init=0, r_init=0,
+               altitudes=[]):
+        """monte_carlo's sweep: one GPU call, squared errors accumulated in
+        the kernel."""
+        layers, fice, inits = core.prepare(
+            False, True, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
+            met_station_height, snow_pack_init, thermal_state_init, 0,
+            s_init, r_init, altitudes)
+        params = self._resolve_params(params)
+        out, sse = core.run(False, True, layers, fice, inits, params,
+                            want_qsim, False, qobs)
+        return out["qsim"], sse
+
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
             met_station_height, snow_pack_init=0, thermal_state_init=0,
             s_init=0, r_init=0, altitudes=[], batched=False):

@@ -69,6 +69,21 @@ class CemaneigeHystGR4JIce(BaseModel):
                     out["snowmelt"], core.rain_per_layer(layers, params.size))
         return out["qsim"]
 
+    def _sweep(self, params, qobs, want_qsim, prec, mean_temp, min_temp,
+               max_temp, etp, frac_ice, met_station_height, snow_pack_init=0,
+               thermal_state_init=0, sca_init=0, s_init=0, r_init=0,
+               altitudes=[]):
+        """monte_carlo's sweep: one GPU call, squared errors accumulated in
+        the kernel."""
+        layers, fice, inits = core.prepare(
+            True, True, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
+            met_station_height, snow_pack_init, thermal_state_init, sca_init,
+            s_init, r_init, altitudes)
+        params = self._resolve_params(params)
+        out, sse = core.run(True, True, layers, fice, inits, params,
+                            want_qsim, False, qobs)
+        return out["qsim"], sse
+
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
             met_station_height, loss_metric="mse", snow_pack_init=0,
             thermal_state_init=0, sca_init=0, s_init=0, r_init=0,

@@ -8,6 +8,8 @@ reference's per-set Python loop over calc_mse (monte_carlo.py:66-71) and its
 strided column reads disappear.
 """
 
+import inspect
+
 import numpy as np
 
 from ..models.basemodel import BaseModel
@@ -49,7 +51,14 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, **kwargs):
         raise ValueError("return_qsim=False needs qobs to score the sets.")
 
     params = model.get_random_params(num=num)
-    qsim, sse = model._sweep(params, qobs, bool(return_qsim), **kwargs)
+    sweep = model._sweep
+    accepted = inspect.signature(sweep).parameters
+    if (not any(p.kind is p.VAR_KEYWORD for p in accepted.values())
+            and any(k not in accepted for k in kwargs)):
+        # a simulate() keyword the fused sweep does not take (return_storage
+        # ...): go through simulate itself, as the reference does
+        sweep = lambda *a, **kw: BaseModel._sweep(model, *a, **kw)  # noqa
+    qsim, sse = sweep(params, qobs, bool(return_qsim), **kwargs)
 
     result = {'params': params}
     if return_qsim:

@@ -17,7 +17,11 @@ pytestmark = pytest.mark.gpu
 
 def _run(cmd, env=None):
     e = dict(os.environ)
-    e.update(env or {})
+    for k, v in (env or {}).items():
+        if v is None:
+            e.pop(k, None)
+        else:
+            e[k] = v
     out = subprocess.run(cmd, cwd=REPO, env=e, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -35,7 +39,13 @@ def test_single_gpu_line():
         assert key in d, key
     assert d["metric"] == "model-timesteps/s" and d["unit"] == d["metric"]
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
-    assert d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["higher_is_better"] is True and d["scaling"] == "strong"
+    assert d["config"]["sets_total"] == 20000
+    assert d["config"]["sets_per_gpu"] == 20000
+    # columns of the resident qsim against the oracle, after the timed region
+    assert 0 <= d["parity_spot"] < 1e-10
+    assert d["kernel_ms_per_rank"]["min"] == d["kernel_ms_per_rank"]["max"]
+    assert d["allgather_ms"] >= 0
     assert d["vs_baseline"] is None and d["dtype"] == "f64"
     assert d["data"] == "synthetic" and "workload" in d["config"]
     assert d["scores_finite"] is True
@@ -55,14 +65,46 @@ def test_single_gpu_line():
 
 
 def test_two_ranks_share_the_gpu_over_gloo():
+    """The driver's launch line (torch.distributed.run), weak scaling."""
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
               "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
               "--master-port", "29577", "bench.py", "--gpus", "2", "--steps",
               "2", "--warmup", "1", "--sets", "20000", "--days", "800",
-              "--backend", "gloo", "--share-gpu"],
+              "--backend", "gloo", "--share-gpu", "--scaling", "weak"],
              env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
-    assert d["scores_finite"] is True
+    assert d["scores_finite"] is True and d["scaling"] == "weak"
+    assert d["config"]["sets_total"] == 40000
     units = 2 * 20000 * 800 * 2
     assert abs(d["value"] - units / (d["ms_per_step"] * 2e-3)) \
         <= 1e-6 * d["value"]
+
+
+def test_self_launched_ranks_strong_scaling():
+    """`python bench.py --gpus 2` with no launcher spawns its own two ranks;
+    strong scaling shards --sets (odd, so the blocks are ragged)."""
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2",
+              "--warmup", "1", "--sets", "30001", "--days", "800",
+              "--backend", "gloo", "--share-gpu"],
+             env={"WORLD_SIZE": None, "RANK": None, "LOCAL_RANK": None})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["sets_total"] == 30001
+    assert d["config"]["sets_per_gpu"] == 15001        # rank 0: longer block
+    assert d["scores_finite"] is True and 0 <= d["parity_spot"] < 1e-10
+    units = 30001 * 800 * 2
+    assert abs(d["value"] - units / (d["ms_per_step"] * 2e-3)) \
+        <= 1e-6 * d["value"]
+    k = d["kernel_ms_per_rank"]
+    assert 0 < k["min"] <= k["max"]
+
+
+def test_self_launched_ranks_over_rccl():
+    """The product path: one GPU per rank, backend nccl (= RCCL)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2",
+              "--warmup", "1", "--sets", "40000", "--days", "800"],
+             env={"WORLD_SIZE": None, "RANK": None, "LOCAL_RANK": None})
+    assert d["n_gpus"] == 2 and d["scores_finite"] is True
+    assert 0 <= d["parity_spot"] < 1e-10

@@ -117,6 +117,66 @@ def test_config1_hbv_100k_properties(env, oracle):
         assert rel_err(a[:, :32].cpu().numpy(), b) < RTOL
 
 
+def test_metric_config_hbv_1m(env, oracle):
+    """The workload BASELINE.json's metric is quoted on (bench.py default):
+    HBV-Edu, 1,000,000 sets x 10,957 days, qsim[T,N] written + fused SSE --
+    the kernel variant bench.py times (one scalar load per day), checked
+    against the oracle on 64 random columns, and bit for bit against the
+    next-day-prefetch variant the small fixtures run."""
+    from rrmpg_amd import _lib
+    torch, syn, f = env["torch"], env["syn"], env["f"]
+    HBV = env["models"].HBVEdu
+    n, t = 1_000_000, syn.T_30YR
+    ens = env["device"].HBVEduEnsemble(f["temp"], f["prec"], f["month"],
+                                       f["PE_m"], f["T_m"], **syn.HBV_INITS)
+    params = env["device"].sample_params(HBV(), n, syn.FORCING_SEED)
+    inits = [syn.HBV_INITS[k] for k in ("snow_init", "soil_init", "s1_init",
+                                        "s2_init")]
+    rng = np.random.default_rng(2)
+    cols = np.sort(rng.choice(n, 64, replace=False))
+    cols[0], cols[-1] = 0, n - 1                 # first and last (tail wave)
+    tcols = torch.from_numpy(cols).cuda()
+    flat = params[tcols].cpu().numpy()
+    ref = oracle.simulate_hbvedu(f["temp"], f["prec"], f["month"] - 1,
+                                 f["PE_m"], f["T_m"], inits, flat, nthreads=8)
+    qobs_h = syn.make_qobs(ref[:, :1])
+    qobs = torch.from_numpy(qobs_h).cuda()
+    assert _lib.load().rr_debug_get_option(_lib.OPTIONS["hbv_variant"]) == -1
+    qsim = ens.new_output(n)
+    sse = ens.run(params, qsim, qobs=qobs)       # heuristic: variant 0 here
+    torch.cuda.synchronize()
+    got = qsim[:, tcols].cpu().numpy()
+    assert rel_err(got, ref) < RTOL
+    ref_sse = ((qobs_h[:, None] - ref) ** 2).sum(0)
+    assert np.max(np.abs(sse[tcols].cpu().numpy() - ref_sse) / ref_sse) < 1e-10
+    assert bool((qsim[0] == 0).all()) and bool(torch.isfinite(sse).all())
+    with _lib.debug_option("hbv_variant", 0):
+        q0 = ens.new_output(n)
+        sse0 = ens.run(params, q0, qobs=qobs)
+        torch.cuda.synchronize()
+        assert torch.equal(q0, qsim) and torch.equal(sse0, sse)
+        del q0
+        # all four storages on this variant (5,000 sets): vs oracle
+        m = 5_000
+        st = tuple(ens.new_output(m) for _ in range(4))
+        qm = ens.new_output(m)
+        ens.run(params[:m].contiguous(), qm, st)
+        torch.cuda.synchronize()
+        assert torch.equal(qm, qsim[:, :m])
+        refs = oracle.simulate_hbvedu(
+            f["temp"], f["prec"], f["month"] - 1, f["PE_m"], f["T_m"], inits,
+            params[:32].cpu().numpy(), return_storage=True)
+        for a, b in zip(st, refs[1:]):
+            assert rel_err(a[:, :32].cpu().numpy(), b) < RTOL
+        assert np.array_equal(st[0][:, :32].cpu().numpy(), refs[1])  # snow
+        del st, qm
+    with _lib.debug_option("hbv_variant", 2):
+        q2 = ens.new_output(n)
+        sse2 = ens.run(params, q2, qobs=qobs)
+        torch.cuda.synchronize()
+        assert torch.equal(q2, qsim) and torch.equal(sse2, sse)
+
+
 def test_config2_gr4j_1m_scores(env, oracle):
     torch, syn, f = env["torch"], env["syn"], env["f"]
     GR4J = env["models"].GR4J

@@ -92,7 +92,7 @@ def models():
     return m
 
 
-def test_hbvedu_fuzz(models, oracle):
+def test_hbvedu_fuzz(models, oracle, hbv_variant):
     g = golden("syn_hbvedu")
     rng = np.random.default_rng(100 + 1000 * SEED)
     lo = np.array([-1, 3, 100, 1, .01, 90, .05, .01, .01, .01, 2.])

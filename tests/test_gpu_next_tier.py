@@ -305,3 +305,52 @@ def test_next_tier_resident_ensembles_match_host_path(models):
         torch.cuda.synchronize()
         assert np.array_equal(q.cpu().numpy(), out["qsim"])
         assert np.array_equal(sse.cpu().numpy(), sse_h)
+
+
+def test_monte_carlo_every_model_class(models):
+    """rrmpg_amd.tools.monte_carlo works for EVERY model class, as the
+    reference's does (monte_carlo.py:64 goes through model.simulate): the
+    fused score equals calc_mse of the returned columns, and a simulate()
+    keyword the fused sweep does not know (return_storages) still works."""
+    from rrmpg_amd.tools import monte_carlo
+    from rrmpg_amd.utils.metrics import calc_mse
+    from rrmpg_amd.utils import synthetic as syn
+    f = syn.make_forcing(500)
+    snow = dict(prec=f["prec"], mean_temp=f["temp"] - 3,
+                min_temp=f["tmin"] - 3, max_temp=f["tmax"] - 3,
+                met_station_height=500, altitudes=[550, 620, 700])
+    cases = [
+        (models.ABCModel, dict(prec=f["prec"])),
+        (models.HBVEdu, dict(temp=f["temp"], prec=f["prec"],
+                             month=f["month"], PE_m=f["PE_m"], T_m=f["T_m"],
+                             soil_init=100.)),
+        (models.GR4J, dict(prec=f["prec"], etp=f["etp"], s_init=.6)),
+        (models.Cemaneige, dict(snow)),
+        (models.CemaneigeGR4J, dict(snow, etp=f["etp"], s_init=.5)),
+        (models.CemaneigeHystGR4J, dict(snow, etp=f["etp"], r_init=.4)),
+        (models.CemaneigeGR4JIce, dict(snow, etp=f["etp"],
+                                       frac_ice=[.1, .3, .6])),
+        (models.CemaneigeHystGR4JIce, dict(snow, etp=f["etp"],
+                                           frac_ice=[.1, .3, .6],
+                                           sca_init=0.2)),
+    ]
+    qobs = np.abs(np.sin(np.arange(500) / 17.0)) * 3
+    for cls, kw in cases:
+        np.random.seed(4)
+        res = monte_carlo(cls(), 70, qobs=qobs, **kw)
+        assert res["qsim"].shape == (500, 70), cls.__name__
+        want = np.array([calc_mse(qobs, res["qsim"][:, j])
+                         for j in range(70)])
+        assert np.max(np.abs(res["mse"] - want) / want) < 1e-12, cls.__name__
+        np.random.seed(4)
+        only = monte_carlo(cls(), 70, qobs=qobs, return_qsim=False, **kw)
+        assert np.array_equal(only["mse"], res["mse"]), cls.__name__
+        assert "qsim" not in only
+    # a simulate() keyword outside the fused sweep: generic path
+    np.random.seed(4)
+    kw = dict(cases[5][1], return_storages=True)
+    res = monte_carlo(models.CemaneigeHystGR4J(), 9, qobs=qobs, **kw)
+    np.random.seed(4)
+    ref = monte_carlo(models.CemaneigeHystGR4J(), 9, qobs=qobs, **cases[5][1])
+    assert np.array_equal(res["qsim"], ref["qsim"])
+    assert np.max(np.abs(res["mse"] - ref["mse"]) / ref["mse"]) < 1e-12

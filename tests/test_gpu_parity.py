@@ -90,7 +90,7 @@ def test_abc_zero_rain_and_model_params(models):
 
 
 # --------------------------------------------------------------- HBV-Edu
-def test_hbvedu_kat_matlab(models):
+def test_hbvedu_kat_matlab(models, hbv_variant):
     g = golden("kat_hbvedu")
     m = models.HBVEdu(params=dict(zip(models.HBVEdu._param_list,
                                       g["params"].tolist())))
@@ -103,7 +103,7 @@ def test_hbvedu_kat_matlab(models):
     assert rel_err(qsim, g["ref_qsim"]) < RTOL
 
 
-def test_hbvedu_golden_and_oracle(models, oracle):
+def test_hbvedu_golden_and_oracle(models, oracle, hbv_variant):
     g = golden("syn_hbvedu")
     p = _records(models.HBVEdu, g["params"])
     i = g["inits"]
@@ -124,7 +124,7 @@ def test_hbvedu_golden_and_oracle(models, oracle):
     assert np.array_equal(out[1], ref[1])
 
 
-def test_hbvedu_ragged_sizes_vs_oracle(models, oracle):
+def test_hbvedu_ragged_sizes_vs_oracle(models, oracle, hbv_variant):
     g = golden("syn_hbvedu")
     rng = np.random.default_rng(11)
     lo = np.array([-1, 3, 100, 1, .01, 90, .05, .01, .01, .01, 2.])
@@ -144,7 +144,7 @@ def test_hbvedu_ragged_sizes_vs_oracle(models, oracle):
             assert rel_err(a, b) < RTOL, (n, t)
 
 
-def test_hbvedu_zero_rain(models):
+def test_hbvedu_zero_rain(models, hbv_variant):
     m = models.HBVEdu()
     qsim = m.simulate(temp=np.random.uniform(-15, 25, 100), prec=np.zeros(100),
                       month=np.random.randint(1, 12, 100),
@@ -153,7 +153,7 @@ def test_hbvedu_zero_rain(models):
     assert np.sum(qsim) == 0
 
 
-def test_nan_propagation_matches_reference(models):
+def test_nan_propagation_matches_reference(models, hbv_variant):
     g = golden("edge")
     syn = golden("syn_hbvedu")
     p = _records(models.HBVEdu, g["hbv_nan_params"])
@@ -473,18 +473,20 @@ def test_host_path_column_blocks(models, oracle, monkeypatch):
     args = (g["temp"][:t], g["prec"][:t], g["month"][:t], g["PE_m"], g["T_m"])
     whole = models.HBVEdu().simulate(*args, 0., 100., 3., 10.,
                                      return_storage=True, params=p)
-    monkeypatch.setenv("RRHIP_MAX_BLOCK_COLS", "256")
-    blocks = models.HBVEdu().simulate(*args, 0., 100., 3., 10.,
-                                      return_storage=True, params=p)
+    from rrmpg_amd import _lib
+    with _lib.debug_option("max_block_cols", 256):
+        blocks = models.HBVEdu().simulate(*args, 0., 100., 3., 10.,
+                                          return_storage=True, params=p)
     for a, b in zip(whole, blocks):
         assert np.array_equal(a, b)
     pc = golden("syn_cemaneige_prep")
     fl = rng.random((600, 2)) * np.array([1., 10.])
     kw = dict(met_station_height=500, altitudes=[550, 620, 700],
               return_storages=True, params=_records(models.Cemaneige, fl))
-    blocks = models.Cemaneige().simulate(pc["prec"][:t], pc["temp"][:t],
-                                         pc["tmin"][:t], pc["tmax"][:t], **kw)
-    monkeypatch.delenv("RRHIP_MAX_BLOCK_COLS")
+    with _lib.debug_option("max_block_cols", 256):
+        blocks = models.Cemaneige().simulate(pc["prec"][:t], pc["temp"][:t],
+                                             pc["tmin"][:t], pc["tmax"][:t],
+                                             **kw)
     whole = models.Cemaneige().simulate(pc["prec"][:t], pc["temp"][:t],
                                         pc["tmin"][:t], pc["tmax"][:t], **kw)
     for a, b in zip(whole, blocks):
