@@ -171,6 +171,17 @@ int rr_gr4j_simulate_dev(const double *prec, const double *etp, int64_t T,
                          int64_t ld, const double *qobs, double *sse,
                          void *workspace, size_t workspace_bytes,
                          void *stream);
+/* Deferred parameter check of the GR4J family.  Every *_simulate_dev entry
+ * whose model contains GR4J (rr_gr4j_, rr_cemaneigegr4j_, rr_cemaneigehyst
+ * gr4j_, rr_cemaneigegr4jice_, rr_cemaneigehystgr4jice_simulate_dev) is
+ * fully asynchronous: the scan of x4 that picks the unit-hydrograph storage
+ * runs on the GPU and is never read back by the call.  A parameter block
+ * with a set the kernels cannot run (ceil(x4) < 1 or NaN: the reference
+ * raises IndexError; x4 > RR_GR4J_MAX_X4) makes that sweep write NOTHING;
+ * this function, given the workspace of the call, waits for `stream` and
+ * returns RR_E_PARAM (with rr_last_error() text) or RR_OK.  The host-pointer
+ * family calls it itself and returns the error directly. */
+int rr_gr4j_plan_status(const void *workspace, void *stream);
 int rr_gr4j_simulate(const double *prec, const double *etp, int64_t T,
                      double s_init, double r_init,
                      const double *params, int64_t N,

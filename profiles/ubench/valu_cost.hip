@@ -197,6 +197,65 @@ UB_KERNEL(writelane_b32,
     "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n",
     "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n" "v_writelane_b32 %8, s2, 0\n")
 
+
+#define UB_OPERANDS_I(A0, A1, A2, A3, A4, A5, A6, A7)                        \
+    : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6),  \
+      "+v"(A7), "+v"(iv), "+s"(sm), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3),  \
+      "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(b), "v"(c), "v"(d0)       \
+    : "vcc", "s2"
+
+// int accumulators x[0..7] (%0..%7), y[0..7] (%10..%17), %8 int, %9 SGPR pair,
+// %18 / %19 / %20 double VGPR pairs
+#define UB_KERNEL_I(NAME, THR, NPER)                                         \
+    __global__ void NAME##_thr(unsigned long long *out, double b, double c,  \
+                               int iters, unsigned long long mask)           \
+    {                                                                        \
+        int x[CHAINS];                                                       \
+        for (int k = 0; k < CHAINS; ++k) x[k] = threadIdx.x + k;             \
+        int y0 = 1, y1 = 2, y2 = 3, y3 = 4, y4 = 5, y5 = 6, y6 = 7, y7 = 8;  \
+        int iv = threadIdx.x & 3;                                            \
+        unsigned long long sm = mask;                                        \
+        double d0 = 1.0 + 0.001 * threadIdx.x;                               \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();          \
+        for (int it = 0; it < iters; ++it) {                                 \
+            _Pragma("unroll") for (int r = 0; r < REP; ++r)                  \
+                asm volatile(THR UB_OPERANDS_I(x[0], x[1], x[2], x[3], x[4], \
+                                               x[5], x[6], x[7]));           \
+        }                                                                    \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();          \
+        int s = y0 + y1 + y2 + y3 + y4 + y5 + y6 + y7;                       \
+        for (int k = 0; k < CHAINS; ++k) s += x[k];                          \
+        if (s == 123456789 && iv == 77 && sm == 3) out[4096] = 1;            \
+        if ((threadIdx.x & 63) == 0)                                         \
+            out[threadIdx.x >> 6] = (t1 - t0) / NPER;                        \
+    }                                                                        \
+    __global__ void NAME##_dep(unsigned long long *out, double b, double c,  \
+                               int iters, unsigned long long mask)           \
+    {                                                                        \
+        if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = 0;              \
+    }
+
+UB_KERNEL_I(sel_vop2_vcc,
+    "v_cndmask_b32_e32 %0, %0, %8, vcc\n" "v_cndmask_b32_e32 %1, %1, %8, vcc\n" "v_cndmask_b32_e32 %2, %2, %8, vcc\n" "v_cndmask_b32_e32 %3, %3, %8, vcc\n" "v_cndmask_b32_e32 %4, %4, %8, vcc\n" "v_cndmask_b32_e32 %5, %5, %8, vcc\n" "v_cndmask_b32_e32 %6, %6, %8, vcc\n" "v_cndmask_b32_e32 %7, %7, %8, vcc\n", 1)
+UB_KERNEL_I(sel_vop3_vcc,
+    "v_cndmask_b32_e64 %0, %0, %8, vcc\n" "v_cndmask_b32_e64 %1, %1, %8, vcc\n" "v_cndmask_b32_e64 %2, %2, %8, vcc\n" "v_cndmask_b32_e64 %3, %3, %8, vcc\n" "v_cndmask_b32_e64 %4, %4, %8, vcc\n" "v_cndmask_b32_e64 %5, %5, %8, vcc\n" "v_cndmask_b32_e64 %6, %6, %8, vcc\n" "v_cndmask_b32_e64 %7, %7, %8, vcc\n", 1)
+UB_KERNEL_I(sel_vop3_sgpr,
+    "v_cndmask_b32_e64 %0, %0, %8, %9\n" "v_cndmask_b32_e64 %1, %1, %8, %9\n" "v_cndmask_b32_e64 %2, %2, %8, %9\n" "v_cndmask_b32_e64 %3, %3, %8, %9\n" "v_cndmask_b32_e64 %4, %4, %8, %9\n" "v_cndmask_b32_e64 %5, %5, %8, %9\n" "v_cndmask_b32_e64 %6, %6, %8, %9\n" "v_cndmask_b32_e64 %7, %7, %8, %9\n", 1)
+UB_KERNEL_I(cmp_sel2_vcc,
+    "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %0, %0, %8, vcc\nv_cndmask_b32_e32 %10, %10, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %1, %1, %8, vcc\nv_cndmask_b32_e32 %11, %11, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %2, %2, %8, vcc\nv_cndmask_b32_e32 %12, %12, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %3, %3, %8, vcc\nv_cndmask_b32_e32 %13, %13, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %4, %4, %8, vcc\nv_cndmask_b32_e32 %14, %14, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %5, %5, %8, vcc\nv_cndmask_b32_e32 %15, %15, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %6, %6, %8, vcc\nv_cndmask_b32_e32 %16, %16, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %7, %7, %8, vcc\nv_cndmask_b32_e32 %17, %17, %8, vcc\n", 3)
+UB_KERNEL_I(cmp_sel2_sgpr,
+    "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %0, %0, %8, %9\nv_cndmask_b32_e64 %10, %10, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %1, %1, %8, %9\nv_cndmask_b32_e64 %11, %11, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %2, %2, %8, %9\nv_cndmask_b32_e64 %12, %12, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %3, %3, %8, %9\nv_cndmask_b32_e64 %13, %13, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %4, %4, %8, %9\nv_cndmask_b32_e64 %14, %14, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %5, %5, %8, %9\nv_cndmask_b32_e64 %15, %15, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %6, %6, %8, %9\nv_cndmask_b32_e64 %16, %16, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %7, %7, %8, %9\nv_cndmask_b32_e64 %17, %17, %8, %9\n", 3)
+UB_KERNEL_I(addc_co_vcc,
+    "v_addc_co_u32 %0, vcc, %0, %8, vcc\n" "v_addc_co_u32 %1, vcc, %1, %8, vcc\n" "v_addc_co_u32 %2, vcc, %2, %8, vcc\n" "v_addc_co_u32 %3, vcc, %3, %8, vcc\n" "v_addc_co_u32 %4, vcc, %4, %8, vcc\n" "v_addc_co_u32 %5, vcc, %5, %8, vcc\n" "v_addc_co_u32 %6, vcc, %6, %8, vcc\n" "v_addc_co_u32 %7, vcc, %7, %8, vcc\n", 1)
+UB_KERNEL_I(add_co_vcc,
+    "v_add_co_u32 %0, vcc, %0, %8\n" "v_add_co_u32 %1, vcc, %1, %8\n" "v_add_co_u32 %2, vcc, %2, %8\n" "v_add_co_u32 %3, vcc, %3, %8\n" "v_add_co_u32 %4, vcc, %4, %8\n" "v_add_co_u32 %5, vcc, %5, %8\n" "v_add_co_u32 %6, vcc, %6, %8\n" "v_add_co_u32 %7, vcc, %7, %8\n", 1)
+UB_KERNEL_I(mov_b32_indep,
+    "v_mov_b32 %0, %8\n" "v_mov_b32 %1, %8\n" "v_mov_b32 %2, %8\n" "v_mov_b32 %3, %8\n" "v_mov_b32 %4, %8\n" "v_mov_b32 %5, %8\n" "v_mov_b32 %6, %8\n" "v_mov_b32 %7, %8\n", 1)
+UB_KERNEL_I(fma_f32_indep,
+    "v_fma_f32 %0, %0, %8, %8\n" "v_fma_f32 %1, %1, %8, %8\n" "v_fma_f32 %2, %2, %8, %8\n" "v_fma_f32 %3, %3, %8, %8\n" "v_fma_f32 %4, %4, %8, %8\n" "v_fma_f32 %5, %5, %8, %8\n" "v_fma_f32 %6, %6, %8, %8\n" "v_fma_f32 %7, %7, %8, %8\n", 1)
+UB_KERNEL_I(lshl_add_u32_indep,
+    "v_lshl_add_u32 %0, %0, 1, %8\n" "v_lshl_add_u32 %1, %1, 1, %8\n" "v_lshl_add_u32 %2, %2, 1, %8\n" "v_lshl_add_u32 %3, %3, 1, %8\n" "v_lshl_add_u32 %4, %4, 1, %8\n" "v_lshl_add_u32 %5, %5, 1, %8\n" "v_lshl_add_u32 %6, %6, 1, %8\n" "v_lshl_add_u32 %7, %7, 1, %8\n", 1)
+
 typedef void (*kern_t)(unsigned long long *, double, double, int,
                        unsigned long long);
 struct Entry { const char *name; kern_t thr, dep; };
@@ -211,7 +270,8 @@ static const Entry entries[] = {
     E(cndmask_b32_vcc), E(cndmask_b32_sgpr), E(mov_b32), E(add_u32),
     E(and_b32), E(lshl_add_u32), E(ashrrev_i32), E(lshl_add_u64),
     E(mad_u64_u32), E(fma_f32), E(cvt_f32_f64), E(cvt_f64_f32),
-    E(readlane_b32), E(readfirstlane_b32), E(writelane_b32)};
+    E(readlane_b32), E(readfirstlane_b32), E(writelane_b32),
+    E(sel_vop2_vcc), E(sel_vop3_vcc), E(sel_vop3_sgpr), E(cmp_sel2_vcc), E(cmp_sel2_sgpr), E(addc_co_vcc), E(add_co_vcc), E(mov_b32_indep), E(fma_f32_indep), E(lshl_add_u32_indep)};
 
 static double run(kern_t k, int waves_per_simd, int iters,
                   unsigned long long *d_out, unsigned long long mask)

@@ -59,6 +59,7 @@ _SIGNATURES = {
                                                        _i64] + [_vp] * 5
                                           + [_i64, _vp, _vp, _vp, _sz, _vp]),
     "rr_gr4j_workspace_bytes": (_sz, [_i64, _i64]),
+    "rr_gr4j_plan_status": (ctypes.c_int, [_vp, _vp]),
     "rr_gr4j_simulate_dev": (ctypes.c_int,
                              [_vp, _vp, _i64, _dbl, _dbl, _vp, _i64]
                              + [_vp] * 3 + [_i64, _vp, _vp, _vp, _sz, _vp]),

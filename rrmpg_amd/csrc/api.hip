@@ -329,11 +329,12 @@ extern "C" int rr_gr4j_simulate(const double *prec, const double *etp,
     std::vector<OutSpec> outs = {{qsim, 1}, {s_store, 1}, {r_store, 1}};
     return sweep_blocks(T, N, outs, sse,
         [&](int64_t i0, int64_t nc, double **o, double *d_sse) {
-            return rr_gr4j_simulate_dev(
+            int r = rr_gr4j_simulate_dev(
                 d_prec.as<double>(), d_etp.as<double>(), T, s_init, r_init,
                 d_par.as<double>() + i0 * 4, nc, o[0], o[1], o[2], nc,
                 qobs ? d_qobs.as<double>() : nullptr, qobs ? d_sse : nullptr,
                 ws.p, wsb, nullptr);
+            return r != RR_OK ? r : rr_gr4j_plan_status(ws.p, nullptr);
         });
 }
 
@@ -406,12 +407,13 @@ extern "C" int rr_cemaneigegr4j_simulate(
                                  {r_store, 1}};
     return sweep_blocks(T, N, outs, sse,
         [&](int64_t i0, int64_t nc, double **o, double *d_sse) {
-            return rr_cemaneigegr4j_simulate_dev(
+            int r = rr_cemaneigegr4j_simulate_dev(
                 d_prec.as<double>(), d_temp.as<double>(), d_etp.as<double>(),
                 d_frac.as<double>(), T, L, snow_pack_init, thermal_state_init,
                 s_init, r_init, d_par.as<double>() + i0 * 6, nc, o[0], o[1],
                 o[2], o[3], o[4], nc, qobs ? d_qobs.as<double>() : nullptr,
                 qobs ? d_sse : nullptr, ws.p, wsb, nullptr);
+            return r != RR_OK ? r : rr_gr4j_plan_status(ws.p, nullptr);
         });
 }
 
@@ -494,26 +496,29 @@ int snow_gr4j_host(const char *who, int variant, const double *prec,
             const double *p = d_par.as<double>() + i0 * npar;
             const double *qo = qobs ? d_qobs.as<double>() : nullptr;
             double *so = qobs ? d_sse : nullptr;
+            int r;
             if (hyst && ice)
-                return rr_cemaneigehystgr4jice_simulate_dev(
+                r = rr_cemaneigehystgr4jice_simulate_dev(
                     d_prec.as<double>(), d_temp.as<double>(),
                     d_etp.as<double>(), d_fice.as<double>(),
                     d_frac.as<double>(), T, L, snow_pack_init,
                     thermal_state_init, sca_init, s_init, r_init, p, nc, o[0],
                     o[1], o[2], o[3], o[4], o[5], o[6], o[7], nc, qo, so, ws.p,
                     wsb, nullptr);
-            if (hyst)
-                return rr_cemaneigehystgr4j_simulate_dev(
+            else if (hyst)
+                r = rr_cemaneigehystgr4j_simulate_dev(
                     d_prec.as<double>(), d_temp.as<double>(),
                     d_etp.as<double>(), d_frac.as<double>(), T, L,
                     snow_pack_init, thermal_state_init, sca_init, s_init,
                     r_init, p, nc, o[0], o[1], o[2], o[3], o[4], o[5], nc, qo,
                     so, ws.p, wsb, nullptr);
-            return rr_cemaneigegr4jice_simulate_dev(
+            else
+                r = rr_cemaneigegr4jice_simulate_dev(
                 d_prec.as<double>(), d_temp.as<double>(), d_etp.as<double>(),
                 d_fice.as<double>(), d_frac.as<double>(), T, L, snow_pack_init,
                 thermal_state_init, s_init, r_init, p, nc, o[0], o[1], o[2],
                 o[3], o[4], o[6], nc, qo, so, ws.p, wsb, nullptr);
+            return r != RR_OK ? r : rr_gr4j_plan_status(ws.p, nullptr);
         });
 }
 

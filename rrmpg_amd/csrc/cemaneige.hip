@@ -155,10 +155,12 @@ cemaneigegr4j_kernel(
     const double *__restrict__ days, const double *__restrict__ gtresh,
     int64_t T, double snow_pack_init, double thermal_state_init,
     double s_init, double r_init, const double *__restrict__ params,
-    int64_t N, int n1cap, int n2cap, int wq, int ws,
+    int64_t N, const int *__restrict__ plan, int force_lds, int wq, int ws,
     const double *__restrict__ qobs, double *__restrict__ sse)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    int n1cap, n2cap;
+    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 6;
@@ -267,7 +269,8 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
     const double *__restrict__ days, const double *__restrict__ gtresh,
     int64_t T, int L, int D, double snow_pack_init, double thermal_state_init,
     double s_init, double r_init, const double *__restrict__ params, int npar,
-    int64_t N, int n1cap, int n2cap, double *__restrict__ state,
+    int64_t N, const int *__restrict__ plan, int force_lds,
+    double *__restrict__ state,
     double *__restrict__ qsim, double *__restrict__ G_out,
     double *__restrict__ eTG_out, double *__restrict__ s_store,
     double *__restrict__ r_store, int64_t ld,
@@ -275,6 +278,10 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr bool coupled = !std::is_same<UH, void>::value;
+    int n1cap = 0, n2cap = 0;
+    if constexpr (coupled) {
+        if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
+    }
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     const int64_t ii = active ? i : N - 1;
@@ -401,8 +408,8 @@ extern "C" int rr_cemaneige_simulate_dev(
     if (L > RR_CEMANEIGE_MAX_LAYERS) {
         cemaneige_dyn_kernel<void><<<grid, block, 0, st>>>(
             days, gt, T, (int)L, 3 * (int)L, snow_pack_init,
-            thermal_state_init, 0., 0., params, 2, N, 0, 0, state, outflow, G,
-            eTG, nullptr, nullptr, ld, qo, sse);
+            thermal_state_init, 0., 0., params, 2, N, nullptr, 0, state,
+            outflow, G, eTG, nullptr, nullptr, ld, qo, sse);
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
@@ -446,39 +453,40 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
         return RR_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int tier = 3, n1cap = 0, n2cap = 0;
-    rc = rr_gr4j_plan(params, N, 6, 5, (int *)workspace, st, &tier, &n1cap,
-                      &n2cap);
+    const int *d_plan = (const int *)workspace;
+    rc = rr_gr4j_plan_async(params, N, 6, 5, (int *)workspace, st);
     if (rc != RR_OK) return rc;
+    const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     double *days, *gt, *state;
     rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp, T, (int)L,
                       workspace, st, &days, &gt, &state);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
-    const size_t lds_bytes =
-        (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
+    // every unit-hydrograph tier is enqueued; the kernels pick the one the
+    // plan selects (gr4j_core.h)
+    const size_t lds_bytes = GR4J_LDS_BYTES;
     if (L > RR_CEMANEIGE_MAX_LAYERS) {
-        gr4j_dispatch_uh(tier, [&](auto uh) {
+        gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
             cemaneige_dyn_kernel<UH>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
                    st>>>(days, gt, T, (int)L, 3 * (int)L + 1, snow_pack_init,
                          thermal_state_init, s_init, r_init, params, 6, N,
-                         n1cap, n2cap, state, qsim, G, eTG, s_store, r_store,
-                         ld, qo, sse);
+                         d_plan, force_lds, state, qsim, G, eTG, s_store,
+                         r_store, ld, qo, sse);
         });
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
     const CoupledOut out = {qsim, G, eTG, s_store, r_store, ld};
     dispatch_layers((int)L, [&](auto LL) {
-        gr4j_dispatch_uh(tier, [&](auto uh) {
+        gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
             cemaneigegr4j_kernel<LL.value, UH>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
                    st>>>(out, days, gt, T, snow_pack_init, thermal_state_init,
-                         s_init, r_init, params, N, n1cap, n2cap,
+                         s_init, r_init, params, N, d_plan, force_lds,
                          qsim != nullptr, G != nullptr, qo, sse);
         });
     });

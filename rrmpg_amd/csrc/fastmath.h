@@ -50,6 +50,18 @@ static __device__ __forceinline__ double fp_fma_sconst_(double a, double b,
     return d;
 }
 #define FP_FMA_C(a, b, c) fp_fma_sconst_((a), (b), (c))
+// ... or in a VGPR pair: kernels that run at one or two waves per SIMD have
+// registers to spare but need their SGPRs for the prefetched forcing record
+// (hbvedu.hip, small sweeps).  Written as asm so that the constant stays a
+// loop-invariant register instead of becoming v_mov_b64 + v_fmac_f64.
+static __device__ __forceinline__ double fp_fma_vconst_(double a, double b,
+                                                        double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+#define FP_FMA_CV(a, b, c) fp_fma_vconst_((a), (b), (c))
 #define FP_RINT(v) __builtin_rint(v)
 #define FP_FREXP_MANT(x) __builtin_amdgcn_frexp_mant(x)
 #define FP_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
@@ -65,6 +77,7 @@ static __device__ __forceinline__ double fp_fma_sconst_(double a, double b,
 #define FP_RCP(g) (1.0 / (g))
 #define FP_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #define FP_FMA_C(a, b, c) __builtin_fma((a), (b), (c))
+#define FP_FMA_CV(a, b, c) __builtin_fma((a), (b), (c))
 #define FP_RINT(v) __builtin_rint(v)
 #define FP_FREXP_MANT(x) (x)
 #define FP_FREXP_EXP(x) 0
@@ -80,6 +93,7 @@ static __device__ __forceinline__ double fp_fma_sconst_(double a, double b,
 #define FP_RCP(g) ((double)(1.0f / (float)(g)))
 #define FP_FMA(a, b, c) fma((a), (b), (c))
 #define FP_FMA_C(a, b, c) fma((a), (b), (c))
+#define FP_FMA_CV(a, b, c) fma((a), (b), (c))
 #define FP_RINT(v) rint(v)
 static inline double fp_frexp_mant_(double x) { int e; return frexp(x, &e); }
 static inline int fp_frexp_exp_(double x) { int e; (void)frexp(x, &e); return e; }
@@ -214,6 +228,10 @@ FP_FN void fastpow_tab_exponent(double y, double *y2hi, double *y2lo)
     *y2lo = FP_FMA(y, FP_INVLN2HI, -h) + y * FP_INVLN2LO;
 }
 
+// VCONST: polynomial coefficients in VGPRs instead of SGPRs (see FP_FMA_CV)
+#define FP_FMA_K(a, b, c) \
+    (VCONST ? FP_FMA_CV((a), (b), (c)) : FP_FMA_C((a), (b), (c)))
+template <bool VCONST = false>
 FP_FN double fastpow_tab_core(double x, double y2hi, double y2lo,
                               const FpPowLogEntry *tab, double *z_out)
 {
@@ -242,11 +260,11 @@ FP_FN double fastpow_tab_core(double x, double y2hi, double y2lo,
     // r^3 (1/3 - r/4 + r^2/5 - r^3/6 + r^4/7 - r^5/8) = (ar2 r) h(r),
     // h = -2 (1/3 - r/4 + ...); truncation r^9/9 <= 2^-66
     double h = 0.25;                                  // -2 * -1/8
-    h = FP_FMA_C(h, r, -2.0 / 7.0);
-    h = FP_FMA_C(h, r, 1.0 / 3.0);                    // -2 * -1/6
-    h = FP_FMA_C(h, r, -0.4);
-    h = FP_FMA_C(h, r, 0.5);
-    h = FP_FMA_C(h, r, -2.0 / 3.0);
+    h = FP_FMA_K(h, r, -2.0 / 7.0);
+    h = FP_FMA_K(h, r, 1.0 / 3.0);                    // -2 * -1/6
+    h = FP_FMA_K(h, r, -0.4);
+    h = FP_FMA(h, r, 0.5);                            // inline constant
+    h = FP_FMA_K(h, r, -2.0 / 3.0);
     const double p = (ar2 * r) * h;
     const double lo = (((lo1 + lo2) + lo3) + lo4) + p;
     // ln x = l_hi0 + lo, |lo| < 2^-13 |l_hi0| (not renormalised: the product
@@ -263,19 +281,19 @@ FP_FN double fastpow_tab_core(double x, double y2hi, double y2lo,
     const double n = FP_RINT(z_hi);
     const double q0 = (z_hi - n) + z_lo;              // |.| <= 0.5 (+ tiny)
     double q = 1.3691488853904128e-12;                // ln2^13 / 13!
-    q = FP_FMA_C(q, q0, 2.5678435993488206e-11);
-    q = FP_FMA_C(q, q0, 4.4455382718708116e-10);
-    q = FP_FMA_C(q, q0, 7.054911620801123e-09);
-    q = FP_FMA_C(q, q0, 1.01780860092397e-07);
-    q = FP_FMA_C(q, q0, 1.321548679014431e-06);
-    q = FP_FMA_C(q, q0, 1.5252733804059841e-05);
-    q = FP_FMA_C(q, q0, 0.0001540353039338161);
-    q = FP_FMA_C(q, q0, 0.0013333558146428443);
-    q = FP_FMA_C(q, q0, 0.009618129107628477);
-    q = FP_FMA_C(q, q0, 0.05550410866482158);
-    q = FP_FMA_C(q, q0, 0.24022650695910072);
-    q = FP_FMA_C(q, q0, 0.6931471805599453);
-    q = FP_FMA_C(q, q0, 1.0);
+    q = FP_FMA_K(q, q0, 2.5678435993488206e-11);
+    q = FP_FMA_K(q, q0, 4.4455382718708116e-10);
+    q = FP_FMA_K(q, q0, 7.054911620801123e-09);
+    q = FP_FMA_K(q, q0, 1.01780860092397e-07);
+    q = FP_FMA_K(q, q0, 1.321548679014431e-06);
+    q = FP_FMA_K(q, q0, 1.5252733804059841e-05);
+    q = FP_FMA_K(q, q0, 0.0001540353039338161);
+    q = FP_FMA_K(q, q0, 0.0013333558146428443);
+    q = FP_FMA_K(q, q0, 0.009618129107628477);
+    q = FP_FMA_K(q, q0, 0.05550410866482158);
+    q = FP_FMA_K(q, q0, 0.24022650695910072);
+    q = FP_FMA_K(q, q0, 0.6931471805599453);
+    q = FP_FMA(q, q0, 1.0);                           // inline constant
     return FP_LDEXP(q, (int)n);
 }
 

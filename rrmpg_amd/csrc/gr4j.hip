@@ -73,12 +73,15 @@ constexpr int gr4j_min_waves()
 template <class UH, bool Q, bool S, bool E>
 __global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
     const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
-    const double *__restrict__ params, int64_t N, int n1cap, int n2cap,
+    const double *__restrict__ params, int64_t N,
+    const int *__restrict__ plan, int force_lds,
     double *__restrict__ qsim, double *__restrict__ s_store,
     double *__restrict__ r_store, int64_t ld,
     const double *__restrict__ qobs, double *__restrict__ sse)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    int n1cap, n2cap;
+    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 4;
@@ -122,21 +125,29 @@ extern "C" size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N)
     return 256 + rr_align256((size_t)T * sizeof(GrDay));
 }
 
-// Shared by gr4j.hip, cemaneige.hip and snownext.hip: scans x4 and picks the
-// unit-hydrograph storage tier (3, 5, 10 = register tiers for max ceil(x4)
-// up to that; 0 = LDS tier with the returned capacities).  Synchronises the
-// stream once.
-int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
-                 int *d_scan, hipStream_t st, int *tier, int *n1cap,
-                 int *n2cap)
+// Shared by gr4j.hip, cemaneige.hip and snownext.hip: enqueues the scan of
+// x4 that leaves the plan {max ceil(x4), #bad sets} in d_plan (gr4j_core.h).
+// Asynchronous: nothing is read back.
+int rr_gr4j_plan_async(const double *params, int64_t N, int stride,
+                       int x4_index, int *d_plan, hipStream_t st)
 {
-    RR_HIP(hipMemsetAsync(d_scan, 0, 2 * sizeof(int), st));
+    RR_HIP(hipMemsetAsync(d_plan, 0, GR4J_PLAN_INTS * sizeof(int), st));
     int blocks = (int)rr_ceil_div(N, 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(gr4j_scan_x4, dim3(blocks), dim3(256), 0, st, params, N,
-                       stride, x4_index, d_scan);
-    int h[2] = {0, 0};
-    RR_HIP(hipMemcpyAsync(h, d_scan, sizeof(h), hipMemcpyDeviceToHost, st));
+                       stride, x4_index, d_plan);
+    return RR_OK;
+}
+
+extern "C" int rr_gr4j_plan_status(const void *workspace, void *stream)
+{
+    if (!workspace) {
+        rr_set_error("rr_gr4j_plan_status: workspace is NULL");
+        return RR_E_NULL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int h[GR4J_PLAN_INTS] = {0, 0};
+    RR_HIP(hipMemcpyAsync(h, workspace, sizeof(h), hipMemcpyDeviceToHost, st));
     RR_HIP(hipStreamSynchronize(st));
     if (h[1] > 0) {
         rr_set_error("GR4J: %d parameter set(s) have ceil(x4) < 1 (or NaN): "
@@ -149,12 +160,6 @@ int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
                      (double)RR_GR4J_MAX_X4);
         return RR_E_PARAM;
     }
-    // RR_OPT_GR4J_FORCE_LDS (measurement hook): use the LDS tier even when a
-    // register tier would do
-    const bool lds = rr_option(RR_OPT_GR4J_FORCE_LDS) == 1 || h[0] > 10;
-    *tier = lds ? 0 : (h[0] <= 3 ? 3 : (h[0] <= 5 ? 5 : 10));
-    *n1cap = lds ? h[0] : 0;
-    *n2cap = lds ? 2 * h[0] + 1 : 0;
     return RR_OK;
 }
 
@@ -184,24 +189,24 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
         return RR_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int *d_scan = (int *)workspace;
+    int *d_plan = (int *)workspace;
     GrDay *days = (GrDay *)((char *)workspace + 256);
-    int tier = 3, n1cap = 0, n2cap = 0;
-    rc = rr_gr4j_plan(params, N, 4, 3, d_scan, st, &tier, &n1cap, &n2cap);
+    rc = rr_gr4j_plan_async(params, N, 4, 3, d_plan, st);
     if (rc != RR_OK) return rc;
     hipLaunchKernelGGL(gr4j_pack_forcing, dim3((unsigned)rr_ceil_div(T, 256)),
                        dim3(256), 0, st, prec, etp, qobs, T, days);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const bool q = qsim != nullptr, s = s_store != nullptr, e = qobs && sse;
-    const size_t lds_bytes =
-        (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
+    const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
+    // every tier is enqueued; the kernels pick the one the plan selects
     rr_dispatch3(q, s, e, [&](auto Q, auto S, auto E) {
-        gr4j_dispatch_uh(tier, [&](auto uh) {
+        gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
             gr4j_kernel<UH, Q.value, S.value, E.value>
-                <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
-                   st>>>(days, T, s_init, r_init, params, N, n1cap, n2cap,
-                         qsim, s_store, r_store, ld, qobs, sse);
+                <<<grid, block,
+                   std::is_same<UH, UhLds>::value ? GR4J_LDS_BYTES : 0, st>>>(
+                    days, T, s_init, r_init, params, N, d_plan, force_lds,
+                    qsim, s_store, r_store, ld, qobs, sse);
         });
     });
     RR_HIP(hipGetLastError());

@@ -88,6 +88,7 @@ __device__ __forceinline__ int gr4j_num_uh2(double x4)
 // ---- register tier ---------------------------------------------------------
 template <int N1MAX>
 struct UhRegs {
+    static constexpr int TIER = N1MAX;
     static constexpr int N2MAX = 2 * N1MAX + 1;
     double u1[N1MAX], u2[N2MAX], o1[N1MAX], o2[N2MAX];
     int n1, n2;
@@ -164,6 +165,7 @@ struct UhRegs {
 //   [n1cap,     n1cap+n2cap)     uh2 slots
 //   then the same again for the ordinates.
 struct UhLds {
+    static constexpr int TIER = 0;
     double *base;        // this lane's column: base[slot * RR_BLOCK]
     int n1cap, n2cap;    // launch-wide capacities (host scan of max x4)
     int n1, n2;          // this lane's lengths
@@ -250,17 +252,56 @@ struct UhLds {
 };
 
 
-// Calls f(UH{}) with the storage tier picked by rr_gr4j_plan:
-// tier 3 / 5 / 10 -> UhRegs<3> / <5> / <10>, 0 -> UhLds.
-template <class F>
-static inline void gr4j_dispatch_uh(int tier, F &&f)
+// ---- which tier runs: decided ON THE DEVICE ----------------------------------
+// The tier depends on the largest ceil(x4) of the launch, which only the GPU
+// knows when the parameter block is resident in HBM.  Reading it back would
+// cost a stream synchronisation per call (and make the *_simulate_dev entry
+// points blocking), so the host never learns it: gr4j_scan_x4 leaves
+// {max ceil(x4), number of sets without ordinates} in the first ints of the
+// workspace, the host enqueues the kernel of EVERY tier, and each kernel
+// decodes the plan in its first instructions and returns at once unless it
+// is the selected one (three empty launches, ~10 us each at a million sets).
+// A parameter block the kernels cannot run (ceil(x4) < 1, NaN, or
+// x4 > RR_GR4J_MAX_X4) selects no tier: nothing is written, and
+// rr_gr4j_plan_status() reports it.
+#define GR4J_PLAN_INTS 2   // plan[0] = max ceil(x4), plan[1] = #bad sets
+// LDS-tier launches are sized for the longest hydrographs the tier holds
+#define GR4J_LDS_N1CAP ((int)RR_GR4J_MAX_X4)
+#define GR4J_LDS_N2CAP (2 * GR4J_LDS_N1CAP + 1)
+#define GR4J_LDS_BYTES \
+    ((size_t)2 * (GR4J_LDS_N1CAP + GR4J_LDS_N2CAP) * RR_BLOCK * sizeof(double))
+
+// tier for a plan: 3 / 5 / 10 = UhRegs<3/5/10>, 0 = UhLds, -1 = none (error)
+static __host__ __device__ __forceinline__ int gr4j_plan_tier(int max_n1,
+                                                              int bad,
+                                                              int force_lds)
 {
-    switch (tier) {
-    case 3: f(UhRegs<3>{}); break;
-    case 5: f(UhRegs<5>{}); break;
-    case 10: f(UhRegs<10>{}); break;
-    default: f(UhLds{}); break;
-    }
+    if (bad > 0 || max_n1 < 1 || max_n1 > (int)RR_GR4J_MAX_X4) return -1;
+    if (force_lds || max_n1 > 10) return 0;
+    return max_n1 <= 3 ? 3 : (max_n1 <= 5 ? 5 : 10);
+}
+
+// true if this kernel instantiation (UH) is the one the plan selects; the
+// LDS tier also gets its capacities (the launch's longest hydrographs)
+template <class UH>
+__device__ __forceinline__ bool gr4j_plan_selects(const int *__restrict__ plan,
+                                                  int force_lds, int &n1cap,
+                                                  int &n2cap)
+{
+    const int mx = plan[0], bad = plan[1];        // wave-uniform scalar loads
+    n1cap = mx;
+    n2cap = 2 * mx + 1;
+    return gr4j_plan_tier(mx, bad, force_lds) == UH::TIER;
+}
+
+// Calls f(UH{}) for every tier (the launch loop of the GR4J-family entries).
+template <class F>
+static inline void gr4j_for_each_tier(F &&f)
+{
+    f(UhRegs<3>{});
+    f(UhRegs<5>{});
+    f(UhRegs<10>{});
+    f(UhLds{});
 }
 
 // The transcendental calls of the daily step (reference: 1 tanh + 3 pow) are

@@ -169,7 +169,13 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     // (the record is taken BY VALUE: one s_load_dwordx8 per day up front; a
     // reference lets hipcc re-load single fields at their use sites, each
     // with its own wait)
-    auto day_step = [&](const HbvDay f, int64_t t) {
+    // `mid` runs between the effective-precipitation block and the rest of
+    // the day: the small-sweep variant requests the next day's record there
+    // (32-bit day counters: hbv_launch rejects T >= 2^31; a 64-bit count
+    // costs a second scalar add per day and, in the unrolled loop, a VALU
+    // compare -- there is no 64-bit signed scalar compare)
+    const int Ti = (int)T;
+    auto day_step = [&](const HbvDay f, int t, auto &&mid) {
         row += ld;
 
         // snow routine (hbvedu_model.py:87-96)
@@ -177,6 +183,11 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         const bool cold = f.temp < T_t;
         const double snow_n = cold ? snow + f.prec : nb_max(0.0, snow - melt);
         const double liquid_water = cold ? 0.0 : f.prec + nb_min(snow, melt);
+        // first operation of the soil update (:111), taken here so that
+        // liquid_water itself is dead after the power block (it lives on as
+        // prec_eff, in place, on the days without the power)
+        double soil_lw = soil + liquid_water;
+        asm("" : "+v"(soil_lw));      // (evaluated HERE, not sunk below)
 
         // effective precipitation (:99): liquid_water * (soil/FC)**Beta.
         // On dry or frozen days liquid_water is exactly 0 for every lane of
@@ -202,20 +213,29 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
             // fastmath.h: ~1 ulp, a third of the general pow's instructions;
             // arguments outside its domain take the general pow (wave-wide)
             double z;
-            double pw = fastpow_tab_core(wetness, beta2_hi, beta2_lo, powlog,
-                                         &z);
-            const lanemask_t fast_m = RR_LANES(wetness >= 0x1p-1022) &
-                                      RR_LANES(wetness < __builtin_inf()) &
-                                      RR_LANES(fabs(z) < 1000.0);
-            if (rr_exec() & ~fast_m) {
+            // (small sweeps, FORCING == 2: polynomial constants in VGPRs so
+            // that the prefetched record fits the SGPR file without spills)
+            double pw = fastpow_tab_core<FORCING == 2>(wetness, beta2_hi,
+                                                       beta2_lo, powlog, &z);
+            // Inside the box the arguments are in fastpow's domain by
+            // construction: wetness in [2^-9, 2^9] is a positive normal
+            // number and |z| = |Beta log2 wetness| <= 64 * 9 < 1000 -- so
+            // the box mask is the vote, and no compare is spent on it.  If any lane
+            // is outside the box the wave also evaluates the general pow and
+            // every lane fastpow cannot serve takes it.
+            if (rr_exec() & ~soil_m) {
                 const double general = pow_general(wetness, Beta);
                 pw = fastpow_tab_ok(wetness, z) ? pw : general;
             }
             // lanes of this wave that did not need the power sit inside the
             // box with liquid_water == 0: their pw is finite (|z| <= 64 * 9.1)
             // and 0 * pw is the 0 they already hold, so no select is needed
-            prec_eff = liquid_water * pw;
+            // (in place: spelled as `prec_eff = liquid_water * pw` hipcc
+            // gives the product a register of its own and pays a v_mov_b64
+            // on every day WITHOUT the power to join the two)
+            asm("v_mul_f64 %0, %0, %1" : "+v"(prec_eff) : "v"(pw));
         }
+        mid();
 
         // potential / actual evapotranspiration (:102-108)
         const double pe = (1 + C * f.dtemp) * f.pe_m;
@@ -223,7 +243,7 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
             ? pe : pe * div_by_invariant_m(soil, soil_m, inv_PWP, pwp_m);
 
         // soil moisture (:111)
-        const double soil_n = soil + liquid_water - prec_eff - ea;
+        const double soil_n = soil_lw - prec_eff - ea;
 
         // near-surface reservoir (:114-118)
         const double over = nb_max(0.0, s1 - L) * K_0;
@@ -253,31 +273,54 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
 
     if constexpr (FORCING == 1) {
         __shared__ HbvDay tile[RR_BLOCK];
-        for (int64_t t0 = 1; t0 < T; t0 += RR_BLOCK) {
-            const int64_t tt = t0 + threadIdx.x;
-            tile[threadIdx.x] = days[tt < T ? tt : T - 1];
+        for (int t0 = 1; t0 < Ti; t0 += RR_BLOCK) {
+            const int tt = t0 + threadIdx.x;
+            tile[threadIdx.x] = days[tt < Ti ? tt : Ti - 1];
             __syncthreads();
-            const int n = (int)((T - t0 < RR_BLOCK) ? (T - t0) : RR_BLOCK);
+            const int n = (Ti - t0 < RR_BLOCK) ? (Ti - t0) : RR_BLOCK;
             for (int k = 0; k < n; ++k) {
                 const HbvDay f = tile[k];  // uniform address: LDS broadcast
-                day_step(f, t0 + k);
+                day_step(f, t0 + k, [] {});
             }
             __syncthreads();
         }
     } else if constexpr (FORCING == 2) {
-        // small sweeps (fewer than ~3 waves per SIMD): nothing hides the
-        // scalar load's latency, so the next day's record is requested
-        // before this day's arithmetic
-        HbvDay f = days[T > 1 ? 1 : 0];
-        for (int64_t t = 1; t < T; ++t) {
-            const HbvDay next = days[t + 1 < T ? t + 1 : t];
-            day_step(f, t);
-            f = next;
+        // small sweeps (at most two waves per SIMD): nothing hides the
+        // scalar load's latency, so the next day's record is requested in
+        // the middle of this day's arithmetic -- after the power block, whose
+        // wait for its table entry (lgkmcnt counts LDS and scalar loads
+        // alike) would otherwise wait for the record as well.  Two records
+        // alternate (loop unrolled by two: no register copies); the fetch
+        // runs one record ahead, so it may touch record T -- the workspace
+        // holds one spare record for that, its content is never used.
+        // (constant address space: the records are read-only for this
+        // kernel, which is what lets the load stay scalar once its address
+        // has gone through the asm that pins it in place)
+        typedef const HbvDay __attribute__((address_space(4))) *cp_t;
+        cp_t pn = (cp_t)(days + 2);
+        auto fetch = [&](HbvDay &dst) {
+            asm volatile("" : "+s"(pn));
+            dst.temp = pn->temp; dst.prec = pn->prec;     // one load burst
+            dst.dtemp = pn->dtemp; dst.pe_m = pn->pe_m; dst.qobs = pn->qobs;
+            pn += 1;
+        };
+        HbvDay a = days[1], b;
+        // (a "use" of the first record ahead of the loop: otherwise hipcc
+        // leaves half of its load in flight across the loop entry and then
+        // waits for ALL scalar loads -- the prefetch included -- at that
+        // half's first use in every iteration)
+        asm volatile("" : : "s"(a.temp), "s"(a.prec), "s"(a.dtemp),
+                     "s"(a.pe_m), "s"(a.qobs));
+        int t = 1;
+        for (; t + 1 < Ti; t += 2) {
+            day_step(a, t, [&] { fetch(b); });
+            day_step(b, t + 1, [&] { fetch(a); });
         }
+        if (t < Ti) day_step(a, t, [] {});
     } else {
-        for (int64_t t = 1; t < T; ++t) {
+        for (int t = 1; t < Ti; ++t) {
             const HbvDay f = days[t];      // wave-uniform -> s_load_dwordx8
-            day_step(f, t);
+            day_step(f, t, [] {});
         }
     }
     if (WITH_SSE && active) sse[i] = acc;
@@ -287,7 +330,8 @@ extern "C" size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N)
 {
     (void)N;
     if (T < 0) T = 0;
-    return rr_align256((size_t)(T > 0 ? T : 1) * sizeof(HbvDay));
+    // + 1: the spare record the prefetching kernel variant may touch
+    return rr_align256((size_t)((T > 0 ? T : 1) + 1) * sizeof(HbvDay));
 }
 
 // Shared by the single- and multi-catchment entry points.
@@ -301,6 +345,11 @@ static int hbv_launch(const double *temp, const double *prec,
                       int64_t ld, const double *qobs, double *sse,
                       void *workspace, hipStream_t st)
 {
+    if (T > 0x7fffffff) {
+        rr_set_error("HBV-Edu: T=%lld timesteps; supported up to 2^31 - 1",
+                     (long long)T);
+        return RR_E_SIZE;
+    }
     HbvDay *days = (HbvDay *)workspace;
     hipLaunchKernelGGL(hbv_pack_forcing,
                        dim3((unsigned)rr_ceil_div(T, 256), (unsigned)C),
@@ -380,7 +429,7 @@ extern "C" size_t rr_hbvedu_catchments_workspace_bytes(int64_t T, int64_t C,
     (void)N;
     if (T < 1) T = 1;
     if (C < 1) C = 1;
-    return rr_align256((size_t)T * (size_t)C * sizeof(HbvDay));
+    return rr_align256(((size_t)T * (size_t)C + 1) * sizeof(HbvDay));
 }
 
 extern "C" int rr_hbvedu_simulate_catchments_dev(

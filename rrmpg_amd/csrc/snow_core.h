@@ -5,10 +5,10 @@
 
 #include "gr4j_core.h"
 
-// defined in gr4j.hip: scans x4 and picks the unit-hydrograph tier
-int rr_gr4j_plan(const double *params, int64_t N, int stride, int x4_index,
-                 int *d_scan, hipStream_t st, int *tier, int *n1cap,
-                 int *n2cap);
+// defined in gr4j.hip: enqueues the scan of x4 that leaves the plan
+// {max ceil(x4), #bad sets} at the start of the workspace (gr4j_core.h)
+int rr_gr4j_plan_async(const double *params, int64_t N, int stride,
+                       int x4_index, int *d_plan, hipStream_t st);
 
 // defined in cemaneige.hip: packs the per-day records {snow[L], rain[L],
 // temp[L] (, etp)} and the per-layer G_tresh[L] / Psolannual[L] into the

@@ -110,10 +110,12 @@ snow_gr4j_kernel(
     const double *__restrict__ frac_ice, int64_t T, double snow_pack_init,
     double thermal_state_init, double sca_init, double s_init, double r_init,
     const double *__restrict__ params, SnowParLayout lay, int64_t N,
-    int n1cap, int n2cap, int wq, int ws,
+    const int *__restrict__ plan, int force_lds, int wq, int ws,
     const double *__restrict__ qobs, double *__restrict__ sse)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    int n1cap, n2cap;
+    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * lay.npar;
@@ -219,11 +221,14 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
     const double *__restrict__ frac_ice, int64_t T, int L,
     double snow_pack_init, double thermal_state_init, double sca_init,
     double s_init, double r_init, const double *__restrict__ params,
-    SnowParLayout lay, int64_t N, int n1cap, int n2cap, int wq, int ws,
+    SnowParLayout lay, int64_t N, const int *__restrict__ plan,
+    int force_lds, int wq, int ws,
     double *__restrict__ state, const double *__restrict__ qobs,
     double *__restrict__ sse)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    int n1cap, n2cap;
+    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     // tail lanes of the last wave share (and rewrite identically) set N-1's
@@ -385,42 +390,44 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     lay.npar = 6 + (HYST ? 2 : 0) + (ICE ? 1 : 0);
     lay.i_x1 = HYST ? 4 : 2;
     lay.i_ddf = lay.npar - 1;
-    int tier = 3, n1cap = 0, n2cap = 0;
-    rc = rr_gr4j_plan(params, N, lay.npar, lay.i_x1 + 3, (int *)workspace, st,
-                      &tier, &n1cap, &n2cap);
+    const int *d_plan = (const int *)workspace;
+    rc = rr_gr4j_plan_async(params, N, lay.npar, lay.i_x1 + 3,
+                            (int *)workspace, st);
     if (rc != RR_OK) return rc;
+    const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     double *days, *gt, *state;
     rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp, T, (int)L,
                       workspace, st, &days, &gt, &state);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
-    const size_t lds_bytes =
-        (size_t)2 * (n1cap + n2cap) * RR_BLOCK * sizeof(double);
+    // every unit-hydrograph tier is enqueued; the kernels pick the one the
+    // plan selects (gr4j_core.h)
+    const size_t lds_bytes = GR4J_LDS_BYTES;
     const SnowOut out = {qsim, G, eTG, s_store, r_store, sca, icemelt,
                          snowmelt, ld};
     if (L > RR_CEMANEIGE_MAX_LAYERS) {
-        gr4j_dispatch_uh(tier, [&](auto uh) {
+        gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
             snow_gr4j_dyn_kernel<UH, HYST, ICE>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
                    st>>>(out, days, gt, frac_ice, T, (int)L, snow_pack_init,
                          thermal_state_init, sca_init, s_init, r_init, params,
-                         lay, N, n1cap, n2cap, qsim != nullptr, G != nullptr,
-                         state, qo, sse);
+                         lay, N, d_plan, force_lds, qsim != nullptr,
+                         G != nullptr, state, qo, sse);
         });
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
     dispatch_layers((int)L, [&](auto LL) {
-        gr4j_dispatch_uh(tier, [&](auto uh) {
+        gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
             snow_gr4j_kernel<LL.value, UH, HYST, ICE>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
                    st>>>(out, days, gt, frac_ice, T, snow_pack_init,
                          thermal_state_init, sca_init, s_init, r_init, params,
-                         lay, N, n1cap, n2cap, qsim != nullptr, G != nullptr,
-                         qo, sse);
+                         lay, N, d_plan, force_lds, qsim != nullptr,
+                         G != nullptr, qo, sse);
         });
     });
     RR_HIP(hipGetLastError());

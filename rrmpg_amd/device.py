@@ -70,13 +70,98 @@ class _Ensemble:
                  (self.num_timesteps, rows_per_t, num_sets))
         return torch.empty(shape, dtype=torch.float64, device=self.device)
 
+    def _check_tensor(self, t, shape, what):
+        """The kernels take raw pointers: a tensor of the wrong dtype, device,
+        shape or layout would mean silent out-of-bounds HBM traffic, so every
+        caller-provided tensor is checked here.  The last axis (parameter
+        sets) must be dense; the row stride may exceed it (a column block of
+        a wider array)."""
+        if t is None:
+            return
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s must be a torch tensor" % what)
+        if t.dtype != torch.float64:
+            raise TypeError("%s must be float64, got %s" % (what, t.dtype))
+        if t.device != self.device:
+            raise ValueError("%s lives on %s, the ensemble on %s"
+                             % (what, t.device, self.device))
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("%s must have shape %s, got %s"
+                             % (what, tuple(shape), tuple(t.shape)))
+        if t.numel() and t.stride(-1) != 1:
+            raise ValueError("%s: the parameter-set axis must be contiguous"
+                             % what)
+
+    def _check_outputs(self, n, outs2d=(), outs3d=(), layers=1):
+        """2-D outputs [T, n] and 3-D storages [T, layers, n] of one call must
+        share one leading dimension ld (>= n); returns it."""
+        t = self.num_timesteps
+        lds = []
+        for k, o in enumerate(outs2d):
+            self._check_tensor(o, (t, n), "output %d" % k)
+            if o is not None and t > 1:
+                lds.append(o.stride(0))
+        for k, o in enumerate(outs3d):
+            self._check_tensor(o, (t, layers, n), "storage %d" % k)
+            if o is None:
+                continue
+            if layers > 1:
+                lds.append(o.stride(1))
+                if t > 1 and o.stride(0) != layers * o.stride(1):
+                    raise ValueError("3-D storages must be [T][L][ld] with "
+                                     "dense layer planes")
+            elif t > 1:
+                lds.append(o.stride(0))
+        if len(set(lds)) > 1:
+            raise ValueError("all outputs of one call must share the row "
+                             "stride, got %s" % sorted(set(lds)))
+        return int(lds[0]) if lds else n
+
     def _common(self, params, qobs, sse):
-        if params.dim() != 2 or params.shape[1] != self.NUM_PARAMS:
-            raise ValueError("params must be [N, %d]" % self.NUM_PARAMS)
+        if not isinstance(params, torch.Tensor) or params.dim() != 2 \
+                or params.shape[1] != self.NUM_PARAMS:
+            raise ValueError("params must be a tensor [N, %d]"
+                             % self.NUM_PARAMS)
         n = params.shape[0]
-        if qobs is not None and sse is None:
-            sse = torch.empty(n, dtype=torch.float64, device=self.device)
+        self._check_tensor(params, (n, self.NUM_PARAMS), "params")
+        if not params.is_contiguous():
+            raise ValueError("params must be contiguous (double[N][k])")
+        if qobs is not None:
+            self._check_tensor(qobs, (self.num_timesteps,), "qobs")
+            if sse is None:
+                sse = torch.empty(n, dtype=torch.float64, device=self.device)
+            else:
+                self._check_tensor(sse, (n,), "sse")
         return n, sse
+
+    def _layer_shapes(self, etp=None):
+        """[T, L] layer forcing of the snow models: equal shapes, etp [T]."""
+        if self.prec.dim() != 2 or self.temp.shape != self.prec.shape \
+                or self.frac.shape != self.prec.shape:
+            raise RuntimeError("The layer arrays (precipitation, mean "
+                               "temperature, solid fraction) must be "
+                               "[timesteps, layers] and of the same size.")
+        self.num_timesteps, self.num_layers = (int(x) for x in
+                                               self.prec.shape)
+        if etp is not None and (etp.dim() != 1
+                                or etp.numel() != self.num_timesteps):
+            raise RuntimeError("etp must hold one value per timestep.")
+
+    def check(self):
+        """GR4J-family ensembles only: wait for the sweeps enqueued so far and
+        raise if the last parameter block held a set the kernels cannot run
+        (ceil(x4) < 1 or NaN, or x4 > 20) -- such a sweep writes nothing.
+        ``run`` itself never synchronises (rr_gr4j_plan_status)."""
+        if self._ws is not None and getattr(self, "HAS_GR4J", False):
+            _lib.check(self.lib.rr_gr4j_plan_status(_ptr(self._ws),
+                                                    self._stream()),
+                       "rr_gr4j_plan_status")
+
+
+def _same_length(what, *arrays):
+    n = {int(a.shape[0]) for a in arrays}
+    if len(n) != 1:
+        raise RuntimeError("%s must be of the same size." % what)
 
 
 class HBVEduEnsemble(_Ensemble):
@@ -102,6 +187,11 @@ class HBVEduEnsemble(_Ensemble):
         self.inits = tuple(float(v) for v in (snow_init, soil_init, s1_init,
                                               s2_init))
         self.num_timesteps = int(self.prec.numel())
+        _same_length("The arrays of the temperature, precipitation and month",
+                     self.temp.reshape(-1), self.prec.reshape(-1),
+                     self.month0.reshape(-1))
+        if self.PE_m.numel() != 12 or self.T_m.numel() != 12:
+            raise RuntimeError("The monthly arrays must be of length 12.")
 
     def run(self, params, qsim=None, storages=None, qobs=None, sse=None):
         """Enqueue one sweep on the current stream (asynchronous).
@@ -114,9 +204,8 @@ class HBVEduEnsemble(_Ensemble):
         t = self.num_timesteps
         wsb = self.lib.rr_hbvedu_workspace_bytes(t, n)
         ws = self._workspace(wsb)
-        st = storages or (None,) * 4
-        ld = qsim.stride(0) if qsim is not None else (
-            st[0].stride(0) if st[0] is not None else n)
+        st = tuple(storages) if storages else (None,) * 4
+        ld = self._check_outputs(n, (qsim,) + st)
         rc = self.lib.rr_hbvedu_simulate_dev(
             _ptr(self.temp), _ptr(self.prec), _ptr(self.month0),
             _ptr(self.PE_m), _ptr(self.T_m), t, *self.inits, _ptr(params), n,
@@ -143,8 +232,7 @@ class ABCEnsemble(_Ensemble):
         t = self.num_timesteps
         wsb = self.lib.rr_abc_workspace_bytes(t, n)
         ws = self._workspace(wsb)
-        ld = qsim.stride(0) if qsim is not None else (
-            storage.stride(0) if storage is not None else n)
+        ld = self._check_outputs(n, (qsim, storage))
         rc = self.lib.rr_abc_simulate_dev(
             _ptr(self.prec), t, self.initial_state, _ptr(params), n,
             _ptr(qsim), _ptr(storage), ld, _ptr(qobs),
@@ -158,6 +246,7 @@ class GR4JEnsemble(_Ensemble):
     """GR4J over N parameter sets (rr_gr4j_simulate_dev)."""
 
     NUM_PARAMS = 4
+    HAS_GR4J = True
 
     def __init__(self, prec, etp, s_init=0., r_init=0., device="cuda:0"):
         super().__init__(device)
@@ -165,15 +254,20 @@ class GR4JEnsemble(_Ensemble):
         self.etp = _dev_tensor(etp, self.device)
         self.inits = (float(s_init), float(r_init))
         self.num_timesteps = int(self.prec.numel())
+        _same_length("The arrays of precipitation and evapotranspiration",
+                     self.prec.reshape(-1), self.etp.reshape(-1))
 
     def run(self, params, qsim=None, storages=None, qobs=None, sse=None):
+        """Enqueue one sweep on the current stream; never synchronises.  The
+        unit-hydrograph storage (registers for ceil(x4) <= 3 / 5 / 10, LDS up
+        to x4 = 20) is chosen on the GPU; a block with an unusable x4 leaves
+        the outputs untouched -- ``check()`` reports it."""
         n, sse = self._common(params, qobs, sse)
         t = self.num_timesteps
         wsb = self.lib.rr_gr4j_workspace_bytes(t, n)
         ws = self._workspace(wsb)
-        st = storages or (None,) * 2
-        ld = qsim.stride(0) if qsim is not None else (
-            st[0].stride(0) if st[0] is not None else n)
+        st = tuple(storages) if storages else (None,) * 2
+        ld = self._check_outputs(n, (qsim,) + st)
         rc = self.lib.rr_gr4j_simulate_dev(
             _ptr(self.prec), _ptr(self.etp), t, *self.inits, _ptr(params), n,
             _ptr(qsim), *[_ptr(x) for x in st], ld, _ptr(qobs),
@@ -197,17 +291,15 @@ class CemaneigeEnsemble(_Ensemble):
         self.temp = _dev_tensor(layer_mean_temp, self.device)
         self.frac = _dev_tensor(frac_solid_prec, self.device)
         self.inits = (float(snow_pack_init), float(thermal_state_init))
-        self.num_timesteps, self.num_layers = (int(x) for x in
-                                               self.prec.shape)
+        self._layer_shapes()
 
     def run(self, params, outflow=None, storages=None, qobs=None, sse=None):
         n, sse = self._common(params, qobs, sse)
         t, nl = self.num_timesteps, self.num_layers
         wsb = self.lib.rr_cemaneige_workspace_bytes(t, nl, n)
         ws = self._workspace(wsb)
-        st = storages or (None,) * 2
-        ld = outflow.stride(0) if outflow is not None else (
-            st[0].stride(1) if st[0] is not None else n)
+        st = tuple(storages) if storages else (None,) * 2
+        ld = self._check_outputs(n, (outflow,), st, nl)
         rc = self.lib.rr_cemaneige_simulate_dev(
             _ptr(self.prec), _ptr(self.temp), _ptr(self.frac), t, nl,
             *self.inits, _ptr(params), n, _ptr(outflow),
@@ -223,6 +315,7 @@ class CemaneigeGR4JEnsemble(_Ensemble):
     (rr_cemaneigegr4j_simulate_dev)."""
 
     NUM_PARAMS = 6
+    HAS_GR4J = True
 
     def __init__(self, layer_prec, layer_mean_temp, frac_solid_prec, etp,
                  snow_pack_init=0., thermal_state_init=0., s_init=0.,
@@ -235,18 +328,17 @@ class CemaneigeGR4JEnsemble(_Ensemble):
         self.inits = tuple(float(v) for v in (snow_pack_init,
                                               thermal_state_init, s_init,
                                               r_init))
-        self.num_timesteps, self.num_layers = (int(x) for x in
-                                               self.prec.shape)
+        self._layer_shapes(self.etp)
 
     def run(self, params, qsim=None, storages=None, qobs=None, sse=None):
-        """storages: optional (G, eTG, s_store, r_store)."""
+        """storages: optional (G, eTG, s_store, r_store).  Asynchronous; see
+        GR4JEnsemble.run for the x4 rule and ``check()``."""
         n, sse = self._common(params, qobs, sse)
         t, nl = self.num_timesteps, self.num_layers
         wsb = self.lib.rr_cemaneigegr4j_workspace_bytes(t, nl, n)
         ws = self._workspace(wsb)
-        st = storages or (None,) * 4
-        ld = qsim.stride(0) if qsim is not None else (
-            st[2].stride(0) if st[2] is not None else n)
+        st = tuple(storages) if storages else (None,) * 4
+        ld = self._check_outputs(n, (qsim, st[2], st[3]), st[:2], nl)
         rc = self.lib.rr_cemaneigegr4j_simulate_dev(
             _ptr(self.prec), _ptr(self.temp), _ptr(self.etp), _ptr(self.frac),
             t, nl, *self.inits, _ptr(params), n, _ptr(qsim),
@@ -300,8 +392,24 @@ class HBVEduCatchments(_Ensemble):
         if params.dim() != 3 or params.shape[0] != c or params.shape[2] != 11:
             raise ValueError("params must be [C, N, 11]")
         n = params.shape[1]
-        if qobs is not None and sse is None:
-            sse = torch.empty((c, n), dtype=torch.float64, device=self.device)
+        self._check_tensor(params, (c, n, 11), "params")
+        if not params.is_contiguous():
+            raise ValueError("params must be contiguous (double[C][N][11])")
+        if qobs is not None:
+            self._check_tensor(qobs, (c, t), "qobs")
+            if not qobs.is_contiguous():
+                raise ValueError("qobs must be contiguous")
+            if sse is None:
+                sse = torch.empty((c, n), dtype=torch.float64,
+                                  device=self.device)
+            else:
+                self._check_tensor(sse, (c, n), "sse")
+        for k, o in enumerate((qsim,) + (tuple(storages) if storages
+                                         else ())):
+            self._check_tensor(o, (c, t, n), "output %d" % k)
+            if o is not None and not o.is_contiguous():
+                raise ValueError("multi-catchment outputs must be contiguous "
+                                 "[C, T, N]")
         wsb = self.lib.rr_hbvedu_catchments_workspace_bytes(t, c, n)
         ws = self._workspace(wsb)
         st = storages or (None,) * 4
@@ -322,6 +430,8 @@ class SnowGR4JEnsemble(_Ensemble):
     hyst=True, ice=True  -> CemaneigeHystGR4JIce
     (rr_cemaneigehystgr4j_simulate_dev & co.)."""
 
+    HAS_GR4J = True
+
     def __init__(self, hyst, ice, layer_prec, layer_mean_temp, frac_solid_prec,
                  etp, frac_ice=None, snow_pack_init=0., thermal_state_init=0.,
                  sca_init=0., s_init=0., r_init=0., device="cuda:0"):
@@ -338,8 +448,10 @@ class SnowGR4JEnsemble(_Ensemble):
         self.inits = tuple(float(v) for v in (snow_pack_init,
                                               thermal_state_init, sca_init,
                                               s_init, r_init))
-        self.num_timesteps, self.num_layers = (int(x) for x in
-                                               self.prec.shape)
+        self._layer_shapes(self.etp)
+        if ice and self.frac_ice.numel() != self.num_layers:
+            raise ValueError("frac_ice must hold one value per elevation "
+                             "layer.")
 
     def run(self, params, qsim=None, qobs=None, sse=None):
         """Discharge and/or fused per-set squared error (storages are served
@@ -348,7 +460,7 @@ class SnowGR4JEnsemble(_Ensemble):
         t, nl = self.num_timesteps, self.num_layers
         wsb = self.lib.rr_snowgr4j_workspace_bytes(t, nl, n)
         ws = self._workspace(wsb)
-        ld = qsim.stride(0) if qsim is not None else n
+        ld = self._check_outputs(n, (qsim,))
         sse_p = _ptr(sse) if qobs is not None else None
         i = self.inits
         tail = (ld, _ptr(qobs), sse_p, _ptr(ws), wsb, self._stream())

@@ -1,0 +1,175 @@
+"""The *_simulate_dev family is enqueue-and-return: no call synchronises its
+stream (the GR4J family chooses its unit-hydrograph storage on the GPU and
+reports unusable x4 values through rr_gr4j_plan_status), sweeps on two
+streams overlap, and the resident ensembles reject tensors whose dtype /
+device / shape / layout the raw-pointer kernels could not survive."""
+
+import time
+
+import numpy as np
+import pytest
+
+from .conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from rrmpg_amd import _lib, device, models
+    from rrmpg_amd.utils import synthetic as syn
+    _lib.load()
+    _lib.require_gpu()
+    return torch, device, models, syn, syn.make_forcing(syn.T_30YR)
+
+
+def _ensembles(env, which):
+    torch, dev, models, syn, f = env
+    if which == "gr4j":
+        return (dev.GR4JEnsemble(f["prec"], f["etp"], **syn.GR4J_INITS),
+                models.GR4J)
+    from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+    layers, _ = prepare_snow_inputs(f["prec"], f["temp"], f["tmin"],
+                                    f["tmax"], syn.STATION_HEIGHT, 0, 0,
+                                    list(syn.ALTITUDES), etp=f["etp"])
+    if which == "cemaneigegr4j":
+        return (dev.CemaneigeGR4JEnsemble(layers[0], layers[1], layers[2],
+                                          layers[3], 0., 0., .6, .7),
+                models.CemaneigeGR4J)
+    return (dev.SnowGR4JEnsemble(True, False, layers[0], layers[1], layers[2],
+                                 layers[3], s_init=.6, r_init=.7),
+            models.CemaneigeHystGR4J)
+
+
+@pytest.mark.parametrize("which", ["gr4j", "cemaneigegr4j", "hystgr4j"])
+def test_gr4j_family_run_does_not_block(env, which):
+    """Second call on a stream that is still busy with the first returns long
+    before the first finishes (the old plan read the x4 scan back and waited
+    for the stream)."""
+    torch = env[0]
+    ens, cls = _ensembles(env, which)
+    n = 400_000
+    params = env[1].sample_params(cls(), n, 99)
+    qobs = torch.rand(ens.num_timesteps, dtype=torch.float64, device="cuda")
+    sse = ens.run(params, None, qobs=qobs)            # warm-up / sizing
+    torch.cuda.synchronize()
+    e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+    e0.record()
+    ens.run(params, None, qobs=qobs, sse=sse)
+    e1.record()
+    torch.cuda.synchronize()
+    kernel_ms = e0.elapsed_time(e1)
+    assert kernel_ms > 5.0
+    ens.run(params, None, qobs=qobs, sse=sse)
+    t0 = time.perf_counter()
+    ens.run(params, None, qobs=qobs, sse=sse)         # stream busy
+    host_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    assert host_ms < 0.25 * kernel_ms, (host_ms, kernel_ms)
+    ens.check()                                       # no complaint
+
+
+def test_two_streams_overlap(env):
+    """Two quarter-chip GR4J sweeps on two streams take about as long as one,
+    not twice as long."""
+    torch, dev, models, syn, f = env
+    n = 16_384                       # 256 waves: a quarter of the SIMDs
+    a = dev.GR4JEnsemble(f["prec"], f["etp"], **syn.GR4J_INITS)
+    b = dev.GR4JEnsemble(f["prec"], f["etp"], **syn.GR4J_INITS)
+    pa = dev.sample_params(models.GR4J(), n, 1)
+    pb = dev.sample_params(models.GR4J(), n, 2)
+    qa, qb = a.new_output(n), b.new_output(n)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def both(stream_b):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(sa):
+            a.run(pa, qa)
+        with torch.cuda.stream(stream_b):
+            b.run(pb, qb)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    both(sb), both(sa)                                # warm-up
+    serial = min(both(sa) for _ in range(3))
+    overlapped = min(both(sb) for _ in range(3))
+    assert overlapped < 0.75 * serial, (overlapped, serial)
+    # and the results are those of a plain single-stream run
+    q1 = a.new_output(n)
+    a.run(pa, q1)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, qa)
+
+
+def test_unusable_x4_is_reported_by_check(env, oracle):
+    torch, dev, models, syn, f = env
+    t = 400
+    ens = dev.GR4JEnsemble(f["prec"][:t], f["etp"][:t], **syn.GR4J_INITS)
+    flat = np.array([[300., .5, 80., 1.7], [250., -1., 60., 2.4],
+                     [400., 1., 90., 0.9]])
+    good = ens.upload_params(flat)
+    q = torch.full((t, 3), -7.0, dtype=torch.float64, device="cuda")
+    ens.run(good, q)
+    ens.check()
+    ref = oracle.simulate_gr4j(f["prec"][:t], f["etp"][:t], (.6, .7), flat)
+    assert rel_err(q.cpu().numpy(), ref) < 1e-10
+    for bad_x4, msg in ((-0.5, "ceil"), (float("nan"), "ceil"),
+                        (25.0, "exceeds")):
+        bad = flat.copy()
+        bad[1, 3] = bad_x4
+        q.fill_(-7.0)
+        ens.run(ens.upload_params(bad), q)            # returns, no error yet
+        with pytest.raises(RuntimeError, match="RR_E_PARAM") as ei:
+            ens.check()
+        assert msg in str(ei.value)
+        assert bool((q == -7.0).all())                # nothing was written
+    ens.run(good, q)                                  # and it recovers
+    ens.check()
+    assert rel_err(q.cpu().numpy(), ref) < 1e-10
+
+
+def test_resident_ensembles_validate_their_tensors(env):
+    torch, dev, models, syn, f = env
+    t = 300
+    ens = dev.HBVEduEnsemble(f["temp"][:t], f["prec"][:t], f["month"][:t],
+                             f["PE_m"], f["T_m"], **syn.HBV_INITS)
+    p = dev.sample_params(models.HBVEdu(), 100, 5)
+    q = ens.new_output(100)
+    ens.run(p, q)
+    with pytest.raises(TypeError, match="float64"):
+        ens.run(p.float(), q)
+    with pytest.raises(TypeError, match="float64"):
+        ens.run(p, q.float())
+    with pytest.raises(ValueError, match="shape"):
+        ens.run(p, ens.new_output(99))
+    with pytest.raises(ValueError, match="shape"):
+        ens.run(p, q[:-1])
+    with pytest.raises(ValueError, match="contiguous"):
+        ens.run(p, torch.empty((100, t), dtype=torch.float64,
+                               device="cuda").t())
+    with pytest.raises(ValueError, match="contiguous"):
+        ens.run(torch.empty((11, 100), dtype=torch.float64,
+                            device="cuda").t(), q)
+    with pytest.raises(ValueError, match="lives on"):
+        ens.run(p, q.cpu())
+    with pytest.raises(ValueError, match="shape"):
+        ens.run(p, q, qobs=torch.zeros(t - 1, dtype=torch.float64,
+                                       device="cuda"))
+    with pytest.raises(ValueError, match="row stride"):
+        wide = torch.empty((t, 228), dtype=torch.float64, device="cuda")
+        ens.run(p, q, (wide[:, :100], q.clone(), q.clone(), q.clone()))
+    with pytest.raises(RuntimeError, match="same size"):
+        dev.HBVEduEnsemble(f["temp"][:t], f["prec"][:t - 1], f["month"][:t],
+                           f["PE_m"], f["T_m"])
+    with pytest.raises(RuntimeError, match="length 12"):
+        dev.HBVEduEnsemble(f["temp"][:t], f["prec"][:t], f["month"][:t],
+                           f["PE_m"][:11], f["T_m"])
+    with pytest.raises(RuntimeError, match="same size"):
+        dev.GR4JEnsemble(f["prec"][:t], f["etp"][:t + 1])
+    # a column block of a wider array is fine (ld > N)
+    wide = torch.zeros((t, 228), dtype=torch.float64, device="cuda")
+    ens.run(p, wide[:, 28:128])
+    torch.cuda.synchronize()
+    assert torch.equal(wide[:, 28:128], q) and float(wide[:, :28].sum()) == 0
