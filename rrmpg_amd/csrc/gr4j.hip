@@ -20,7 +20,11 @@ struct __attribute__((aligned(32))) GrDay {
     double net;      // prec - etp if wet else etp - prec (:90, :102)
     double qobs;     // the day's observation (0 when no metric is fused)
     int wet;         // prec >= etp (:89)
-    int pad[3];
+    int net_ok;      // net is +0 or in [2^-900, 2^196): a numerator the
+                     // 3-FMA quotient net/x1 serves (gr4j_core.h
+                     // gr4j_num_mask, decided here once per day instead of
+                     // by six vector instructions in every wave)
+    int pad[2];
 };
 
 __global__ void gr4j_pack_forcing(const double *__restrict__ prec,
@@ -35,7 +39,9 @@ __global__ void gr4j_pack_forcing(const double *__restrict__ prec,
     d.wet = p >= e;
     d.net = d.wet ? p - e : e - p;
     d.qobs = qobs ? qobs[t] : 0.0;
-    d.pad[0] = d.pad[1] = d.pad[2] = 0;
+    d.net_ok = (d.net == 0.0 && !__builtin_signbit(d.net)) ||
+               (d.net >= 0x1p-900 && d.net < 0x1p196);
+    d.pad[0] = d.pad[1] = 0;
     days[t] = d;
 }
 
@@ -103,7 +109,8 @@ __global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
 
     for (int64_t k = 0; k < T; ++k) {
         const GrDay f = days[k];    // wave-uniform -> s_load_dwordx8
-        const double q = gr4j_step_net(P, s, r, uh, f.net, f.wet != 0);
+        const double q = gr4j_step_net(P, s, r, uh, f.net, f.wet != 0,
+                                       f.net_ok ? ~0ull : 0ull);
         if (Q) rr_store_row(qsim + row, row_bytes, lane_off, q);
         if (S) {
             rr_store_row(s_store + row, row_bytes, lane_off, s);

@@ -44,13 +44,26 @@ struct Gr4jPar {
 // the folded update of gr4j_step_net cannot overflow early.
 #define GR4J_NUM_HI 0x1p196
 
+// Lanes whose a is a numerator the 3-FMA quotient certainly serves: +0 or
+// 2^-900 <= a < 2^196.  Stores and fluxes are never negative in a sane run,
+// so the magnitude test is ONE unsigned range check on the high word (two
+// 32-bit instructions at 2 cycles each instead of two fp64 compares at 4;
+// profiles/ubench): everything else -- negatives, NaN, inf, subnormals --
+// falls outside it and sends the wave through the IEEE division, where every
+// lane is re-examined with the full test (div_by_invariant_m).
+__device__ __forceinline__ lanemask_t gr4j_num_mask(double a)
+{
+    const unsigned hi = (unsigned)__double2hiint(a);
+    return RR_LANES((hi - 0x07B00000u) < (0x4C300000u - 0x07B00000u)) |
+           lanes_plus_zero(a);
+}
+
 // a / x for the per-lane invariant x (bit-identical to `/`, see common.h);
 // stores run dry, so exact zeros stay on the fast form
 __device__ __forceinline__ double gr4j_div(double a, const InvDivisor &d,
                                            lanemask_t d_ok)
 {
-    return div_by_invariant_m(a, inv_div_numerator_mask0(a, GR4J_NUM_HI), d,
-                              d_ok, GR4J_NUM_HI);
+    return div_by_invariant_m(a, gr4j_num_mask(a), d, d_ok, GR4J_NUM_HI);
 }
 
 // _s_curve1 (gr4j_model.py:159-173); t is the integer ordinate index
@@ -83,6 +96,14 @@ __device__ __forceinline__ int gr4j_num_uh2(double x4)
 {
     const double c = ceil(2 * x4 + 1);
     return (c >= 1.0) ? ((c > 2e6) ? 2000000 : (int)c) : 0;
+}
+
+// a * b + c as a three-address v_fma_f64 (see UhRegs::route)
+__device__ __forceinline__ double uh_fma(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
 
 // ---- register tier ---------------------------------------------------------
@@ -137,22 +158,31 @@ struct UhRegs {
     __device__ __forceinline__ void route(double p1, double p2, double &head1,
                                           double &head2)
     {
+        // (uh_fma: a three-address v_fma_f64 written out, because hipcc
+        // turns __builtin_fma into the two-address v_fmac on the NEXT slot's
+        // register and then shifts the whole array back with one v_mov_b64
+        // per slot at the end of every day)
 #pragma unroll
         for (int j = 0; j < N1MAX; ++j)
-            u1[j] = __builtin_fma(
-                o1[j], p1,
-                (j + 1 < N1MAX) ? u1[(j + 1 < N1MAX) ? j + 1 : j] : 0.0);
+            u1[j] = (j + 1 < N1MAX)
+                ? uh_fma(o1[j], p1, u1[(j + 1 < N1MAX) ? j + 1 : j])
+                : o1[j] * p1;
 #pragma unroll
         for (int j = 0; j < N2MAX; ++j)
-            u2[j] = __builtin_fma(
-                o2[j], p2,
-                (j + 1 < N2MAX) ? u2[(j + 1 < N2MAX) ? j + 1 : j] : 0.0);
+            u2[j] = (j + 1 < N2MAX)
+                ? uh_fma(o2[j], p2, u2[(j + 1 < N2MAX) ? j + 1 : j])
+                : o2[j] * p2;
         const lanemask_t finite = lanes_finite(p1) & lanes_finite(p2);
         if (rr_exec() & ~finite) {
+            // (lengths made opaque: hipcc otherwise hoists the 3 * N1MAX + 1
+            // slot masks `j < n` of this never-taken path out of the time
+            // loop and parks them in that many SGPR pairs)
+            int m1 = n1, m2 = n2;
+            asm volatile("" : "+v"(m1), "+v"(m2));
 #pragma unroll
-            for (int j = 0; j < N1MAX; ++j) u1[j] = (j < n1) ? u1[j] : 0.0;
+            for (int j = 0; j < N1MAX; ++j) u1[j] = (j < m1) ? u1[j] : 0.0;
 #pragma unroll
-            for (int j = 0; j < N2MAX; ++j) u2[j] = (j < n2) ? u2[j] : 0.0;
+            for (int j = 0; j < N2MAX; ++j) u2[j] = (j < m2) ? u2[j] : 0.0;
         }
         head1 = u1[0];
         head2 = u2[0];
@@ -329,7 +359,7 @@ template <bool GUARD_BY_VOTE = true>
 __device__ __forceinline__ double gr4j_inv_fourth_root(double b)
 {
     if constexpr (!GUARD_BY_VOTE) return inv_fourth_root(b);
-    double y = inv_fourth_root_core(b);
+    double y = inv_fourth_root_core3(b);
     if (rr_exec() & ~lanes_of_class(b, 0x100)) {
         asm volatile("");                   // keep this a branch
         y = (b < __builtin_inf()) ? y : ((b != b) ? b : 0.0);
@@ -346,7 +376,12 @@ __device__ __forceinline__ double pow_3_5(double x)
     if constexpr (!FAST_ROOT) return x * x * x * sqrt(x);
     // +0, positive subnormal or positive normal: one class test
     const lanemask_t ok = lanes_of_class(x, 0x1c0);
-    double root = fast_sqrt_core(nb_max(0x1p-500, x));
+    // (v_max_f64 written out: from C++ hipcc quiets the operand first with a
+    // v_max x, x of its own; a NaN x gives 2^-500 here, the slow path below
+    // replaces the root for it anyway)
+    double xr;
+    asm("v_max_f64 %0, %1, %2" : "=v"(xr) : "v"(x), "s"(0x1p-500));
+    double root = fast_sqrt_core(xr);
     if (rr_exec() & ~ok) {
         // (the empty asm keeps this a branch: hipcc would otherwise evaluate
         // the IEEE sqrt for every wave and select)
@@ -391,31 +426,39 @@ __device__ __attribute__((noinline)) double gr4j_store_change_reference(
 // one shape: a tanh of the net amount over x1, one quotient; only the branch
 // that applies is evaluated.  (The plain GR4J kernel gets wet/net from its
 // pre-pass, wave-uniform; the coupled kernels compute them per lane.)
+// `net_m`: lanes whose net is a valid numerator of the 3-FMA quotient
+// (gr4j_num_mask; the plain GR4J kernel's pre-pass knows it per day).
 // JIT_CONST: see fastmath.h fast_tanh_parts (set by the fused snow kernels).
 template <class UH, bool JIT_CONST = false>
 __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
                                                 double &r, UH &uh, double net,
-                                                bool wet)
+                                                bool wet, lanemask_t net_m)
 {
     // tanh(net/x1) = E / D (fastmath.h: E = expm1(2a)/2, D = E + 1); its
     // quotient is folded into the store update's own:
     //     c*th / (1 + k*th) == c*E / (D + k*E),
     // one division per day instead of two.
     double E, D;
-    fast_tanh_parts<JIT_CONST>(gr4j_div(net, P.inv_x1, P.x1_m), E, D);
+    fast_tanh_parts<JIT_CONST>(
+        div_by_invariant_m(net, net_m, P.inv_x1, P.x1_m, GR4J_NUM_HI), E, D);
     // One vote covers the 3-FMA quotient s/x1 and the folded form: with
-    // |s| in {0} u [2^-900, 2^196] and |x1| in [2^-100, 2^100] (invdiv.h) the
+    // s in {0} u [2^-900, 2^196) and |x1| in [2^-100, 2^100] (invdiv.h) the
     // quotient is exact and |s/x1| <= 2^296, so c*E and k*E (E <= 1.2e17,
     // |c| <= 2^692) stay finite
     // -- they are D times the reference's own c*th, k*th and would otherwise
-    // overflow before those do.  Any other lane sends the wave through the
-    // reference's own sequence (IEEE quotient, two divisions).
-    const lanemask_t fast =
-        inv_div_numerator_mask0(s, GR4J_NUM_HI) & P.x1_m;
+    // overflow before those do.  The folded quotient itself is taken with
+    // fastmath.h's 6-instruction division (the IEEE sequence is 11, and the
+    // form is a few-ulp restatement already), which needs a denominator
+    // away from zero: D + k*E >= 1 whenever 0 <= s <= x1, anything else is
+    // voted out.  Any other lane sends the wave through the reference's own
+    // sequence (IEEE quotient, two divisions).
     const double sx = inv_div_core(s, P.inv_x1);
     double c, k;
     gr4j_store_coefficients(wet, s, P.x1, sx, c, k);
-    double frac = c * E / (D + k * E);
+    const double den = D + k * E;
+    const lanemask_t fast = gr4j_num_mask(s) & P.x1_m &
+                            RR_LANES(fabs(den) >= 0x1p-100);
+    double frac = fast_div_core(c * E, den);
     if (rr_exec() & ~fast) {
         double exact;
         if constexpr (std::is_same<UH, UhRegs<10>>::value) {
@@ -430,7 +473,7 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
             exact = ce * th / (1 + ke * th);
         }
         const bool ok = inv_div_numerator_ok0(s) && fabs(s) <= GR4J_NUM_HI &&
-                        P.inv_x1.ok;
+                        P.inv_x1.ok && fabs(den) >= 0x1p-100;
         frac = ok ? frac : exact;
     }
     // s - e_s + p_s (:114) and p_n - p_s (:123) with the branch's zeros
@@ -478,5 +521,6 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
 {
     const bool wet = prec >= etp;                               // :89
     const double net = wet ? prec - etp : etp - prec;           // :90, :102
-    return gr4j_step_net<UH, JIT_CONST>(P, s, r, uh, net, wet);
+    return gr4j_step_net<UH, JIT_CONST>(P, s, r, uh, net, wet,
+                                        gr4j_num_mask(net));
 }

@@ -137,5 +137,35 @@ int main(int argc, char **argv) {
                      inv_fourth_root(INFINITY) < 1e-70 && inv_fourth_root(1e308) < 1e-70 &&
                      std::isnan(inv_fourth_root(NAN));
     printf("r4_special_ok %d\n", r4_special);
+
+    // the one-step third-order variant the GR4J kernels use (finite b >= 1)
+    double wr3 = 0, wr3x = 0;
+    for (long i = 0; i < n; ++i) {
+        double v = (i & 1) ? 3.0 * u01() : exp2(-30 + 60 * u01());
+        double b = 1 + (v * v) * (v * v);
+        double err = ulp_err(inv_fourth_root_core3(b),
+                             powl((long double)b, -0.25L));
+        if (err > wr3) { wr3 = err; wr3x = b; }
+    }
+    printf("worst_ulp_inv_fourth_root3 %.4f at b=%.17g\n", wr3, wr3x);
+    printf("r4_3_exact_ok %d\n", inv_fourth_root_core3(1.0) == 1.0 &&
+                                  inv_fourth_root_core3(16.0) == 0.5);
+
+    // fast_div_core: denominators as the folded store update produces them
+    // (D + k E in [1, 1e18]) and wide, numerators of either sign
+    double wd = 0, wdn = 0, wdd = 0;
+    for (long i = 0; i < n; ++i) {
+        double d = (i & 1) ? 1.0 + 3.0 * u01() : exp2(200 * u01());
+        if (i % 7 == 0) d = -d;
+        double nn = exp2(-300 + 900 * u01()) * (u01() < 0.5 ? -1 : 1);
+        if (i % 5 == 0) nn = 1500.0 * u01();
+        double err = ulp_err(fast_div_core(nn, d),
+                             (long double)nn / (long double)d);
+        if (err > wd) { wd = err; wdn = nn; wdd = d; }
+    }
+    printf("worst_ulp_fast_div %.4f at n=%.17g d=%.17g\n", wd, wdn, wdd);
+    printf("fast_div_exact_ok %d\n", fast_div_core(0.0, 3.0) == 0.0 &&
+           fast_div_core(6.0, 3.0) == 2.0 && fast_div_core(-1.0, 4.0) == -0.25 &&
+           std::isnan(fast_div_core(NAN, 2.0)));
     return 0;
 }

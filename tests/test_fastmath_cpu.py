@@ -44,6 +44,10 @@ def test_fastpow_accuracy(tmp_path):
     assert float(vals["worst_ulp_fast_sqrt"]) < 0.75, out
     assert float(vals["worst_ulp_inv_fourth_root"]) < 2.0, out
     assert int(vals["r4_special_ok"]) == 1, out
+    assert float(vals["worst_ulp_inv_fourth_root3"]) < 1.5, out
+    assert int(vals["r4_3_exact_ok"]) == 1, out
+    assert float(vals["worst_ulp_fast_div"]) < 1.0, out
+    assert int(vals["fast_div_exact_ok"]) == 1, out
 
 
 def test_invariant_division_is_bit_exact(tmp_path):
