@@ -72,6 +72,22 @@ __global__ __launch_bounds__(256) void cema_gtresh(
     }
 }
 
+// The CemaGt table {G_tresh, RN(1 / G_tresh)} of the register kernels
+// (snow_core.h) and the flag "every threshold suits the 3-FMA quotient",
+// behind G_tresh[L] and Psolannual[L].
+__global__ void cema_gt_table(double *__restrict__ gtresh, int L, int nreg)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool all_ok = true;
+    for (int l = 0; l < nreg; ++l) {
+        const InvDivisor d = make_inv_divisor(gtresh[l]);
+        gtresh[2 * L + 2 * l] = d.b;
+        gtresh[2 * L + 2 * l + 1] = d.rb;
+        all_ok = all_ok && d.ok;
+    }
+    gtresh[4 * L] = all_ok ? 1.0 : 0.0;
+}
+
 template <int L>
 __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const double *__restrict__ days, const double *__restrict__ gtresh,
@@ -87,27 +103,25 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const double CTG = p[0], Kf = p[1];
     const double omc = 1 - CTG;
     double G[L], eTG[L];
-    InvDivisor inv_gt[L];
-    lanemask_t gt_m[L];          // lanes whose threshold suits the 3-FMA quotient
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        G[l] = 0.0; eTG[l] = 0.0;
-        inv_gt[l] = make_inv_divisor(gtresh[l]);
-        gt_m[l] = RR_LANES(inv_gt[l].ok);
-    }
+    for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
+    const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
+    const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
     double acc = 0.0;
     const bool wq = outflow != nullptr, ws = G_out != nullptr,
                we = sse != nullptr;
-    for (int64_t t = 0; t < T; ++t) {
+    // one day; `first` (a std::bool_constant) marks day 0, which is peeled
+    // off the time loop
+    auto one_day = [&](auto first, int64_t t) {
         // the whole day record by value, up front: one wide scalar load and
         // one wait per day (read through the pointer, hipcc fetches every
         // field at its use site with its own s_load + wait)
         double rec[3 * L];
 #pragma unroll
         for (int k = 0; k < 3 * L; ++k) rec[k] = days[t * (3 * L) + k];
-        const double q = cema_day<L>(rec, inv_gt, gt_m, t == 0,
-                                     snow_pack_init, thermal_state_init, CTG,
-                                     omc, Kf, G, eTG);
+        const double q = cema_day<L, decltype(first)::value>(
+            rec, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG, omc,
+            Kf, G, eTG);
         if (active) {
             if (wq) outflow[t * ld + i] = q;
             if (ws) {
@@ -122,7 +136,9 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
             const double d = qobs[t] - q;
             acc = __builtin_fma(d, d, acc);
         }
-    }
+    };
+    one_day(std::true_type{}, 0);
+    for (int64_t t = 1; t < T; ++t) one_day(std::false_type{}, t);
     if (we && active) sse[i] = acc;
 }
 
@@ -169,14 +185,10 @@ cemaneigegr4j_kernel(
     P.set(p[2], p[3], p[4], p[5]);
     const double omc = 1 - CTG;
     double G[L], eTG[L];
-    InvDivisor inv_gt[L];
-    lanemask_t gt_m[L];          // lanes whose threshold suits the 3-FMA quotient
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        G[l] = 0.0; eTG[l] = 0.0;
-        inv_gt[l] = make_inv_divisor(gtresh[l]);
-        gt_m[l] = RR_LANES(inv_gt[l].ok);
-    }
+    for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
+    const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
+    const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
     UH uh;
     if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
     else uh.init(P.x4);
@@ -184,13 +196,15 @@ cemaneigegr4j_kernel(
     double acc = 0.0;
     const bool we = sse != nullptr;
     constexpr int D = 3 * L + 1;
-    for (int64_t t = 0; t < T; ++t) {
+    // one day; `first` (a std::bool_constant) marks day 0, which is peeled
+    // off the time loop
+    auto one_day = [&](auto first, int64_t t) {
         double day[D];          // by value: one wide scalar load per day
 #pragma unroll
         for (int k = 0; k < D; ++k) day[k] = days[t * D + k];
-        const double liquid = cema_day<L>(day, inv_gt, gt_m, t == 0, snow_pack_init,
-                                          thermal_state_init, CTG, omc, Kf, G,
-                                          eTG);
+        const double liquid = cema_day<L, decltype(first)::value>(
+            day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG, omc,
+            Kf, G, eTG);
         const double q = gr4j_step<UH, true>(P, s, r, uh, liquid, day[3 * L]);
         if (active && (wq | ws)) {
             coupled_out_ptr_t po =
@@ -215,7 +229,9 @@ cemaneigegr4j_kernel(
             const double d = qobs[t] - q;
             acc = __builtin_fma(d, d, acc);
         }
-    }
+    };
+    one_day(std::true_type{}, 0);
+    for (int64_t t = 1; t < T; ++t) one_day(std::false_type{}, t);
     if (we && active) sse[i] = acc;
 }
 
@@ -349,13 +365,14 @@ int rr_cema_prepass(const double *prec, const double *mean_temp,
 {
     const int D = 3 * L + (etp ? 1 : 0);
     double *gt = (double *)((char *)workspace + 512);
-    double *days = (double *)((char *)workspace + 512 +
-                              rr_align256((size_t)L * 16));
+    double *days = (double *)((char *)workspace + 512 + cema_gt_bytes(L));
     hipLaunchKernelGGL(cema_pack, dim3((unsigned)rr_ceil_div(T * L, 256)),
                        dim3(256), 0, st, prec, mean_temp, frac, etp, T, L, D,
                        days);
     hipLaunchKernelGGL(cema_gtresh, dim3((unsigned)L), dim3(256), 0, st, days,
                        T, D, gt);
+    hipLaunchKernelGGL(cema_gt_table, dim3(1), dim3(1), 0, st, gt, L,
+                       L <= RR_CEMANEIGE_MAX_LAYERS ? L : 0);
     *days_out = days;
     *gt_out = gt;
     *state_out = (double *)((char *)days + cema_days_bytes(T, L, etp != nullptr));

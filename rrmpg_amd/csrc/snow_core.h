@@ -25,25 +25,58 @@ static inline size_t cema_days_bytes(int64_t T, int64_t L, bool with_etp)
     return rr_align256((size_t)T * (size_t)(3 * L + (with_etp ? 1 : 0)) * 8);
 }
 
+// per-layer constants: G_tresh[L], Psolannual[L], the CemaGt table [L] the
+// register kernels read (below), and one flag: every threshold suits the
+// 3-FMA quotient
+static inline size_t cema_gt_bytes(int64_t L)
+{
+    if (L < 1) L = 1;
+    return rr_align256((size_t)(4 * L + 1) * 8);
+}
+
 // + the [nstate][L][N] snow-state scratch when the layers do not fit in
 // registers (nstate = 2: G, eTG; 4 with the hysteresis' sca and SWE maximum)
 static inline size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp,
                                    int64_t N, int nstate = 2)
 {
-    size_t b = 512 + rr_align256((size_t)(L > 0 ? L : 1) * 16) +
-               cema_days_bytes(T, L, with_etp);
+    size_t b = 512 + cema_gt_bytes(L) + cema_days_bytes(T, L, with_etp);
     if (L > RR_CEMANEIGE_MAX_LAYERS && N > 0)
         b += rr_align256((size_t)nstate * (size_t)L * (size_t)N * 8);
     return b;
 }
 
 
+// Per-layer melt threshold as the kernels read it: {G_tresh, RN(1/G_tresh)}
+// per layer, written by the pre-pass (cema_gtresh) behind the thresholds
+// themselves.  Parameter independent, so it is fetched with a scalar load at
+// its point of use (the days on which a layer melts) instead of occupying
+// 4 SGPRs per layer for the whole time loop -- the fused kernels are short of
+// SGPRs, and every one that overflows into a VGPR lane costs a v_readlane
+// (a VALU slot) per use.
+struct CemaGt { double gt, rgt; };
+typedef const CemaGt __attribute__((address_space(4))) *cema_gt_ptr_t;
+
+// c / L (the layer mean, np.mean's division by the size): L is a constant,
+// so the correctly rounded 3-FMA quotient of invdiv.h applies; c is a sum of
+// non-negative fluxes, anything else takes the IEEE division.
+template <int L>
+__device__ __forceinline__ double cema_layer_mean(double c)
+{
+    const InvDivisor inv_L = {(double)L, 1.0 / (double)L, true};
+    return div_by_invariant_m(c, gr4j_num_mask(c), inv_L, ~0ull);
+}
+
 // One day of the snow routine for all L layers of one parameter set
 // (cemaneige_model.py:83-125).  Returns the layer-mean liquid outflow.
-template <int L>
+// FIRST: day 0, whose states are the initial values (:85-96) -- a template
+// argument because the kernels peel that day off their time loop (as a
+// run-time flag it costs two selects per state and layer on EVERY day).
+// gt_tab: the CemaGt table; gt_ok: lanes (all or none) for which every
+// threshold suits the 3-FMA quotient.
+template <int L, bool FIRST>
 __device__ __forceinline__ double cema_day(
-    const double *__restrict__ day, const InvDivisor (&inv_gt)[L],
-    const lanemask_t (&gt_m)[L], bool first, double snow_pack_init, double thermal_state_init, double CTG,
+    const double *__restrict__ day, cema_gt_ptr_t gt_tab, lanemask_t gt_ok,
+    double snow_pack_init, double thermal_state_init, double CTG,
     double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L])
 {
     double c = 0.0;
@@ -51,7 +84,7 @@ __device__ __forceinline__ double cema_day(
     for (int l = 0; l < L; ++l) {
         const double snow = day[l], rain = day[L + l], temp = day[2 * L + l];
         double g, e;
-        if (first) {                                       // :85-96
+        if (FIRST) {                                       // :85-96
             g = snow_pack_init;
             e = thermal_state_init;
         } else {
@@ -76,19 +109,27 @@ __device__ __forceinline__ double cema_day(
             // G / G_tresh: the threshold is fixed for the whole run, so the
             // quotient is the 3-instruction correctly rounded form of
             // common.h
-            const double gt = inv_gt[l].b;
+            cema_gt_ptr_t pg = gt_tab + l;
+            asm volatile("" : "+s"(pg));     // keeps the load inside the branch
+            InvDivisor inv_gt;
+            inv_gt.b = pg->gt;
+            inv_gt.rb = pg->rgt;
+            inv_gt.ok = gt_ok != 0;
+            // (both fields now: one s_load_dwordx4 and one wait, not a
+            // second load + wait where the reciprocal is first used)
+            asm volatile("" : : "s"(inv_gt.b), "s"(inv_gt.rb));
             const double ratio =                           // :109-112
-                (g < gt) ? div_by_invariant_m(g, inv_div_numerator_mask0(g),
-                                              inv_gt[l], gt_m[l])
-                         : 1.0;
+                (g < inv_gt.b)
+                    ? div_by_invariant_m(g, gr4j_num_mask(g), inv_gt, gt_ok)
+                    : 1.0;
             melt = (0.9 * ratio + 0.1) * pot_melt;         // :115
         }
         g = g - melt;                                      // :118
         G[l] = g;
         eTG[l] = e;
-        c += rain + melt;                                  // :121, :125
+        c = (l == 0) ? rain + melt : c + (rain + melt);    // :121, :125
     }
-    return c / (double)L;
+    return cema_layer_mean<L>(c);
 }
 
 

@@ -17,10 +17,11 @@
 // maximum SWE before melt.  Returns the layer-mean liquid outflow.
 // sca_prev0: what the reference reads as sca[t-1] at t = 0 -- row -1, i.e. 0
 // (or sca_init when T == 1); sca_init itself never survives (quirk Q8).
-template <int L>
+// FIRST: day 0 (peeled off the kernels' time loops, see snow_core.h cema_day).
+template <int L, bool FIRST>
 __device__ __forceinline__ double cema_hyst_day(
     const double *__restrict__ day, const double *__restrict__ psol,
-    bool first, double snow_pack_init, double thermal_state_init,
+    double snow_pack_init, double thermal_state_init,
     double sca_prev0, double CTG, double one_minus_CTG, double Kf,
     const InvDivisor &inv_Thacc, lanemask_t thacc_m, double Rsp,
     double (&G)[L], double (&eTG)[L],
@@ -31,7 +32,7 @@ __device__ __forceinline__ double cema_hyst_day(
     for (int l = 0; l < L; ++l) {
         const double snow = day[l], rain = day[L + l], temp = day[2 * L + l];
         double g, e;
-        if (first) {                                       // :98-110
+        if (FIRST) {                                       // :98-110
             g = snow_pack_init;
             e = thermal_state_init;
         } else {
@@ -47,7 +48,7 @@ __device__ __forceinline__ double cema_hyst_day(
         const double snow_balance = snow - pot_melt;       // :123
         double sc;
         if (snow_balance >= 0) {                           // :126-129
-            const double prev = first ? sca_prev0 : sca[l];
+            const double prev = FIRST ? sca_prev0 : sca[l];
             // (a day without snowfall or melt has snow_balance == 0)
             sc = prev + div_by_invariant_m(
                             snow_balance, inv_div_numerator_mask0(snow_balance),
@@ -66,9 +67,9 @@ __device__ __forceinline__ double cema_hyst_day(
         G[l] = g;
         eTG[l] = e;
         sca[l] = sc;
-        c += rain + melt;                                  // :162, :166
+        c = (l == 0) ? rain + melt : c + (rain + melt);    // :162, :166
     }
-    return c / (double)L;
+    return cema_layer_mean<L>(c);
 }
 
 // Where the optional parameters sit in a record of `npar` doubles:
@@ -128,14 +129,12 @@ snow_gr4j_kernel(
     P.set(p[lay.i_x1], p[lay.i_x1 + 1], p[lay.i_x1 + 2], p[lay.i_x1 + 3]);
     const double omc = 1 - CTG;
     double G[L], eTG[L], sca[L], swe_max[L];
-    InvDivisor inv_gt[L];
-    lanemask_t gt_m[L];          // lanes whose threshold suits the 3-FMA quotient
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         G[l] = 0.0; eTG[l] = 0.0; sca[l] = 0.0; swe_max[l] = 0.0;
-        inv_gt[l] = make_inv_divisor(gtresh[l]);
-        gt_m[l] = RR_LANES(inv_gt[l].ok);
     }
+    const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
+    const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
     const double *psol = gtresh + L;
     const double sca_prev0 = (T == 1) ? sca_init : 0.0;
     UH uh;
@@ -145,19 +144,22 @@ snow_gr4j_kernel(
     double acc = 0.0;
     const bool we = sse != nullptr;
     constexpr int D = 3 * L + 1;
-    for (int64_t t = 0; t < T; ++t) {
+    // one day; `first` (a std::bool_constant) marks day 0, which is peeled
+    // off the time loop
+    auto one_day = [&](auto first, int64_t t) {
+        constexpr bool FIRST = decltype(first)::value;
         double day[D];          // by value: one wide scalar load per day
 #pragma unroll
         for (int k = 0; k < D; ++k) day[k] = days[t * D + k];
         double snowmelt;
         if constexpr (HYST)
-            snowmelt = cema_hyst_day<L>(day, psol, t == 0, snow_pack_init,
-                                        thermal_state_init, sca_prev0, CTG,
-                                        omc, Kf, inv_Thacc, thacc_m, Rsp, G,
-                                        eTG, sca, swe_max);
+            snowmelt = cema_hyst_day<L, FIRST>(
+                day, psol, snow_pack_init, thermal_state_init, sca_prev0, CTG,
+                omc, Kf, inv_Thacc, thacc_m, Rsp, G, eTG, sca, swe_max);
         else
-            snowmelt = cema_day<L>(day, inv_gt, gt_m, t == 0, snow_pack_init,
-                                   thermal_state_init, CTG, omc, Kf, G, eTG);
+            snowmelt = cema_day<L, FIRST>(day, gt_tab, gt_ok, snow_pack_init,
+                                          thermal_state_init, CTG, omc, Kf, G,
+                                          eTG);
         double liquid = snowmelt;
         double ice_total = 0.0;
         if constexpr (ICE) {
@@ -203,7 +205,9 @@ snow_gr4j_kernel(
             const double d = qobs[t] - q;
             acc = __builtin_fma(d, d, acc);
         }
-    }
+    };
+    one_day(std::true_type{}, 0);
+    for (int64_t t = 1; t < T; ++t) one_day(std::false_type{}, t);
     if (we && active) sse[i] = acc;
 }
 
