@@ -79,6 +79,14 @@ const char *rr_last_error(void);
 int rr_set_device(int device);
 int rr_get_device(void);
 
+/* The host-pointer family keeps, per device, its streams and its small device
+ * buffers (inputs, parameter block, workspace, output slabs up to 64 MiB
+ * each) between calls, and does not upload an input again whose bytes have
+ * not changed since the previous call -- Model.fit() makes thousands of
+ * one-set calls with the same forcing.  This returns that memory to the
+ * device (the next call allocates again). */
+int rr_release_cached_memory(void);
+
 /* Measurement / test hooks.  Process-wide integer options that select a
  * specific kernel variant for A/B measurements and for parity tests that
  * must reach a variant the size heuristics would not pick.  The launch paths
@@ -93,7 +101,10 @@ int rr_get_device(void);
                                   * even where a register tier would do      */
 #define RR_OPT_MAX_BLOCK_COLS  3 /* 0 (default) = sized to free HBM; > 0 caps
                                   * the host-pointer family's column blocks  */
-#define RR_OPT_COUNT_          4
+#define RR_OPT_GATHER_THREADS  4 /* 0 (default) = 12 (or fewer cores); > 0:
+                                  * host threads scattering the staging ring
+                                  * of a large gather into the caller's array */
+#define RR_OPT_COUNT_          5
 int rr_debug_set_option(int option, int64_t value);
 int64_t rr_debug_get_option(int option);
 

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "rr_last_error": (ctypes.c_char_p, []),
     "rr_set_device": (ctypes.c_int, [ctypes.c_int]),
     "rr_get_device": (ctypes.c_int, []),
+    "rr_release_cached_memory": (ctypes.c_int, []),
     "rr_debug_set_option": (ctypes.c_int, [ctypes.c_int, _i64]),
     "rr_debug_get_option": (_i64, [ctypes.c_int]),
     "rr_column_sums_dev": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp,
@@ -179,7 +180,8 @@ def set_device(index):
 
 
 # include/rrhip.h RR_OPT_*
-OPTIONS = {"hbv_variant": 1, "gr4j_force_lds": 2, "max_block_cols": 3}
+OPTIONS = {"hbv_variant": 1, "gr4j_force_lds": 2, "max_block_cols": 3,
+           "gather_threads": 4}
 
 
 class debug_option:

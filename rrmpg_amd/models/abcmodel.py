@@ -89,15 +89,16 @@ class ABCModel(BaseModel):
             return qsim, storage
         return qsim
 
-    def fit(self, qobs, prec, initial_state=0, batched=False):
+    def fit(self, qobs, prec, initial_state=0, batched=True):
         """Fit the model to a timeseries of discharge.
 
         Uses scipy's differential evolution, as the reference does
         (abcmodel.py:188-232); every candidate is one GPU call that returns
         only its squared-error sum.
 
-        batched=True (extension): one GPU sweep per generation, see
-        BaseModel._differential_evolution.
+        batched (default True): one GPU sweep per generation;
+        batched=False: one candidate per call, the reference's own optimiser
+        trajectory (BaseModel._differential_evolution).
 
         Returns:
             res: A scipy OptimizeResult class object.

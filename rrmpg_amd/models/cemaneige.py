@@ -83,7 +83,7 @@ class Cemaneige(BaseModel):
 
     def fit(self, obs, prec, mean_temp, min_temp, max_temp,
             met_station_height, snow_pack_init=0, thermal_state_init=0,
-            altitudes=[], batched=False):
+            altitudes=[], batched=True):
         """Fit the Cemaneige model to an observed timeseries.
 
         scipy differential evolution over the default bounds, as in the

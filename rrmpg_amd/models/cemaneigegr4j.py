@@ -82,7 +82,7 @@ class CemaneigeGR4J(BaseModel):
 
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp,
             met_station_height, snow_pack_init=0, thermal_state_init=0,
-            s_init=0, r_init=0, altitudes=[], batched=False):
+            s_init=0, r_init=0, altitudes=[], batched=True):
         """Fit the Cemaneige + GR4J coupled model to an observed timeseries.
 
         scipy differential evolution over the default bounds, as in the

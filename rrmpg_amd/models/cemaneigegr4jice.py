@@ -91,7 +91,7 @@ class CemaneigeGR4JIce(BaseModel):
 
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
             met_station_height, snow_pack_init=0, thermal_state_init=0,
-            s_init=0, r_init=0, altitudes=[], batched=False):
+            s_init=0, r_init=0, altitudes=[], batched=True):
         """Fit the model to an observed discharge series (scipy differential
         evolution on the MSE; reference: cemaneigegr4jice.py:290-417).
 

@@ -100,7 +100,7 @@ class CemaneigeHystGR4J(BaseModel):
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp,
             met_station_height, loss_metric="mse", snow_pack_init=0,
             thermal_state_init=0, sca_init=0, s_init=0, r_init=0,
-            altitudes=[], batched=False):
+            altitudes=[], batched=True):
         """Fit the model to an observed discharge series (scipy differential
         evolution; loss_metric 'mse' or 'kge'; reference:
         cemaneigehystgr4j.py:292-424).
@@ -121,7 +121,7 @@ class CemaneigeHystGR4J(BaseModel):
                   NDSI2, NDSI3, NDSI4, NDSI5, met_station_height,
                   loss_metric="mse", snow_pack_init=0, thermal_state_init=0,
                   sca_init=0, s_init=0, r_init=0, altitudes=[],
-                  batched=False):
+                  batched=True):
         """Fit to discharge AND the snow-covered area of five elevation bands
         (NDSI1..NDSI5, in percent); 75 % / 5 x 5 % weighting (reference:
         cemaneigehystgr4j.py:427-570).

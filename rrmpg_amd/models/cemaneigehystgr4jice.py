@@ -87,7 +87,7 @@ class CemaneigeHystGR4JIce(BaseModel):
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
             met_station_height, loss_metric="mse", snow_pack_init=0,
             thermal_state_init=0, sca_init=0, s_init=0, r_init=0,
-            altitudes=[], batched=False):
+            altitudes=[], batched=True):
         """Fit the model to an observed discharge series (scipy differential
         evolution; loss_metric 'mse' or 'kge'; reference:
         cemaneigehystgr4jice.py:308-445).
@@ -108,7 +108,7 @@ class CemaneigeHystGR4JIce(BaseModel):
                   frac_ice, NDSI1, NDSI2, NDSI3, NDSI4, NDSI5,
                   met_station_height, loss_metric="mse", snow_pack_init=0,
                   thermal_state_init=0, sca_init=0, s_init=0, r_init=0,
-                  altitudes=[], batched=False):
+                  altitudes=[], batched=True):
         """Fit to discharge AND the snow-covered area of five elevation bands
         (reference: cemaneigehystgr4jice.py:447-593).
 

@@ -82,7 +82,7 @@ class GR4J(BaseModel):
             return tuple(out)
         return out[0]
 
-    def fit(self, qobs, prec, etp, s_init=0., r_init=0., batched=False):
+    def fit(self, qobs, prec, etp, s_init=0., r_init=0., batched=True):
         """Fit the GR4J model to a timeseries of discharge.
 
         scipy differential evolution over the default bounds, as in the

@@ -80,7 +80,7 @@ class HBVEdu(BaseModel):
         return out[0]
 
     def fit(self, qobs, temp, prec, month, PE_m, T_m, snow_init=0.,
-            soil_init=0., s1_init=0., s2_init=0., batched=False):
+            soil_init=0., s1_init=0., s2_init=0., batched=True):
         """Fit the HBVEdu model to a timeseries of discharge.
 
         scipy differential evolution over the default bounds, as in the

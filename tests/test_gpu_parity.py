@@ -503,6 +503,11 @@ def test_fit_recovers_known_parameters(models):
     res = models.ABCModel().fit(qobs, prec, initial_state=1.0)
     assert res.fun < 1e-6
     assert np.allclose(res.x, [0.35, 0.15, 0.4], atol=1e-2)
+    # the reference's call shape: one candidate per loss evaluation
+    np.random.seed(0)
+    res = models.ABCModel().fit(qobs, prec, initial_state=1.0, batched=False)
+    assert res.fun < 1e-6
+    assert np.allclose(res.x, [0.35, 0.15, 0.4], atol=1e-2)
 
 
 def test_device_division_by_invariant_is_bit_exact():
