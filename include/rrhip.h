@@ -222,6 +222,25 @@ int rr_cemaneige_simulate(const double *prec, const double *mean_temp,
                           double *outflow, double *G, double *eTG,
                           const double *qobs, double *sse);
 
+/* Forcing preprocessing of the Cemaneige family on the device -- replaces
+ * extrapolate_precipitation, extrapolate_temperature and
+ * calculate_solid_fraction (reference: rrmpg/models/cemaneige_utils.py:
+ * 100-158, 160-207, 15-98): station series [T] (device) -> the [T][L] layer
+ * arrays the *_simulate_dev entries take (device), same fp64 operations.
+ * altitudes: host, [L].  prec_factor: host, [L], or NULL = computed here as
+ * exp((z - z_station) * 0.0004) with the C library's exp (what numba calls;
+ * pass numpy's values to match a numpy caller bit for bit).  A model without
+ * elevation layers is L = 1 with altitudes[0] = met_station_height. */
+size_t rr_cemaneige_layers_workspace_bytes(int64_t L);
+int rr_cemaneige_layers_dev(const double *prec, const double *mean_temp,
+                            const double *min_temp, const double *max_temp,
+                            int64_t T, const double *altitudes, int64_t L,
+                            double met_station_height,
+                            const double *prec_factor, double *layer_prec,
+                            double *layer_mean_temp, double *frac_solid_prec,
+                            void *workspace, size_t workspace_bytes,
+                            void *stream);
+
 /* ---- Cemaneige + GR4J coupled ------------------------------------------
  * replaces run_cemaneigegr4j(prec, mean_temp, etp, frac_solid_prec,
  *                            snow_pack_init, thermal_state_init, s_init,

@@ -75,6 +75,10 @@ _SIGNATURES = {
     "rr_cemaneige_simulate": (ctypes.c_int,
                               [_f64p] * 3 + [_i64, _i64, _dbl, _dbl, _f64p,
                                              _i64] + [_f64p] * 5),
+    "rr_cemaneige_layers_workspace_bytes": (_sz, [_i64]),
+    "rr_cemaneige_layers_dev": (ctypes.c_int,
+                                [_vp] * 4 + [_i64, _f64p, _i64, _dbl, _f64p]
+                                + [_vp] * 4 + [_sz, _vp]),
     "rr_cemaneigegr4j_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "rr_cemaneigegr4j_simulate_dev": (ctypes.c_int,
                                       [_vp] * 4 + [_i64, _i64] + [_dbl] * 4

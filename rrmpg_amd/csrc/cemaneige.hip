@@ -21,6 +21,10 @@
 // In the coupled kernel the layer-mean outflow of the snow routine feeds
 // GR4J's precipitation in registers the same day; the [T] liquid-water
 // intermediate of the reference (cemaneigegr4j_model.py:57-62) never exists.
+#include <math.h>
+
+#include <vector>
+
 #include "snow_core.h"
 
 // days: [T][D] doubles, D = 3*L + (with_etp ? 1 : 0):
@@ -376,6 +380,107 @@ int rr_cema_prepass(const double *prec, const double *mean_temp,
     *days_out = days;
     *gt_out = gt;
     *state_out = (double *)((char *)days + cema_days_bytes(T, L, etp != nullptr));
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---- forcing preprocessing on the device -------------------------------------
+// rrmpg/models/cemaneige_utils.py of the reference: extrapolate_precipitation
+// (:100-158), extrapolate_temperature (:160-207), calculate_solid_fraction
+// (:15-98) -- one thread per (day, layer), the same fp64 operations in the
+// same order; the per-layer constants (precipitation factor, temperature
+// offset, which solid-fraction rule) come from the host.
+struct CemaLayerConst {
+    double prec_factor;    // exp(...) of :143/:151, or 1 (:156)
+    double temp_delta;     // (z - z_station) * -0.0065 (:200-205)
+    int low;               // z < 1500 m: min/max rule (:52-96)
+    int pad;
+};
+
+__global__ void cema_layers_kernel(const double *__restrict__ prec,
+                                   const double *__restrict__ mean_temp,
+                                   const double *__restrict__ min_temp,
+                                   const double *__restrict__ max_temp,
+                                   int64_t T, int L,
+                                   const CemaLayerConst *__restrict__ lc,
+                                   double *__restrict__ layer_prec,
+                                   double *__restrict__ layer_mean,
+                                   double *__restrict__ frac)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= T * L) return;
+    const int64_t t = g / L;
+    const int l = (int)(g - t * L);
+    const CemaLayerConst c = lc[l];
+    const double tmean = mean_temp[t] + c.temp_delta;
+    const double tmin = min_temp[t] + c.temp_delta;
+    const double tmax = max_temp[t] + c.temp_delta;
+    double f;
+    if (c.low) {
+        if (tmax <= 0) f = 1.0;
+        else if (tmin >= 0) f = 0.0;
+        else f = 1 - (tmax / (tmax - tmin));
+    } else {
+        if (tmean >= 3) f = 0.0;
+        else if (tmean <= 0) f = 1.0;
+        else f = 1 - (tmean + 1) / 4;
+    }
+    layer_prec[g] = prec[t] * c.prec_factor;
+    layer_mean[g] = tmean;
+    frac[g] = f;
+}
+
+extern "C" size_t rr_cemaneige_layers_workspace_bytes(int64_t L)
+{
+    if (L < 1) L = 1;
+    return rr_align256((size_t)L * sizeof(CemaLayerConst));
+}
+
+extern "C" int rr_cemaneige_layers_dev(
+    const double *prec, const double *mean_temp, const double *min_temp,
+    const double *max_temp, int64_t T, const double *altitudes, int64_t L,
+    double met_station_height, const double *prec_factor, double *layer_prec,
+    double *layer_mean_temp, double *frac_solid_prec, void *workspace,
+    size_t workspace_bytes, void *stream)
+{
+    const char *who = "rr_cemaneige_layers_dev";
+    if (T < 0 || L < 1 || L > 4096) {
+        rr_set_error("%s: T=%lld, L=%lld", who, (long long)T, (long long)L);
+        return RR_E_SIZE;
+    }
+    if (T == 0) return RR_OK;
+    if (!prec || !mean_temp || !min_temp || !max_temp || !altitudes ||
+        !layer_prec || !layer_mean_temp || !frac_solid_prec) {
+        rr_set_error("%s: NULL pointer", who);
+        return RR_E_NULL;
+    }
+    if (!workspace || workspace_bytes < rr_cemaneige_layers_workspace_bytes(L)) {
+        rr_set_error("%s: workspace too small", who);
+        return RR_E_WORKSPACE;
+    }
+    std::vector<CemaLayerConst> lc((size_t)L);
+    for (int64_t l = 0; l < L; ++l) {
+        const double z = altitudes[l];
+        double factor;                               // cemaneige_utils.py:139-156
+        if (prec_factor) factor = prec_factor[l];
+        else if (z <= 4000) factor = exp((z - met_station_height) * 0.0004);
+        else if (met_station_height <= 4000)
+            factor = exp((4000 - met_station_height) * 0.0004);
+        else factor = 1.0;
+        lc[(size_t)l].prec_factor = factor;
+        lc[(size_t)l].temp_delta = (z - met_station_height) * -0.0065;
+        lc[(size_t)l].low = z < 1500;
+        lc[(size_t)l].pad = 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // (pageable source: the runtime stages the L records before returning)
+    RR_HIP(hipMemcpyAsync(workspace, lc.data(), (size_t)L * sizeof(CemaLayerConst),
+                          hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(cema_layers_kernel,
+                       dim3((unsigned)rr_ceil_div(T * L, 256)), dim3(256), 0,
+                       st, prec, mean_temp, min_temp, max_temp, T, (int)L,
+                       (const CemaLayerConst *)workspace, layer_prec,
+                       layer_mean_temp, frac_solid_prec);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -453,34 +453,111 @@ class SnowGR4JEnsemble(_Ensemble):
             raise ValueError("frac_ice must hold one value per elevation "
                              "layer.")
 
-    def run(self, params, qsim=None, qobs=None, sse=None):
-        """Discharge and/or fused per-set squared error (storages are served
-        by the model classes' host path)."""
+    def storage_names(self):
+        """The state series this variant can materialise, in the order of the
+        reference's return tuple."""
+        names = ["G", "eTG", "s_store", "r_store"]
+        if self.hyst:
+            names.append("sca")
+        if self.ice:
+            names.append("icemelt")
+        if self.hyst and self.ice:
+            names.append("snowmelt")
+        return names
+
+    def new_storages(self, num_sets):
+        """Device tensors for every state series of ``storage_names()``:
+        G, eTG, sca are [T, L, N], the others [T, N]."""
+        return {k: self.new_output(num_sets, self.num_layers
+                                   if k in ("G", "eTG", "sca") else 1)
+                for k in self.storage_names()}
+
+    def run(self, params, qsim=None, qobs=None, sse=None, storages=None):
+        """Discharge, fused per-set squared error and/or (storages: the dict
+        of ``new_storages``, all of them or none) every state series.
+        Asynchronous; see GR4JEnsemble.run for the x4 rule and ``check()``."""
         n, sse = self._common(params, qobs, sse)
         t, nl = self.num_timesteps, self.num_layers
         wsb = self.lib.rr_snowgr4j_workspace_bytes(t, nl, n)
         ws = self._workspace(wsb)
-        ld = self._check_outputs(n, (qsim,))
+        st = storages or {}
+        if st and sorted(st) != sorted(self.storage_names()):
+            raise ValueError("pass all of %s or none" % self.storage_names())
+        two = [qsim] + [st.get(k) for k in ("s_store", "r_store", "icemelt",
+                                            "snowmelt")]
+        three = [st.get(k) for k in ("G", "eTG", "sca")]
+        ld = self._check_outputs(n, two, three, nl)
         sse_p = _ptr(sse) if qobs is not None else None
         i = self.inits
         tail = (ld, _ptr(qobs), sse_p, _ptr(ws), wsb, self._stream())
+        g = lambda k: _ptr(st.get(k))               # noqa: E731
         if self.hyst and self.ice:
             rc = self.lib.rr_cemaneigehystgr4jice_simulate_dev(
                 _ptr(self.prec), _ptr(self.temp), _ptr(self.etp),
                 _ptr(self.frac_ice), _ptr(self.frac), t, nl, *i, _ptr(params),
-                n, _ptr(qsim), *([None] * 7), *tail)
+                n, _ptr(qsim), g("G"), g("eTG"), g("s_store"), g("r_store"),
+                g("sca"), g("icemelt"), g("snowmelt"), *tail)
         elif self.hyst:
             rc = self.lib.rr_cemaneigehystgr4j_simulate_dev(
                 _ptr(self.prec), _ptr(self.temp), _ptr(self.etp),
                 _ptr(self.frac), t, nl, *i, _ptr(params), n, _ptr(qsim),
-                *([None] * 5), *tail)
+                g("G"), g("eTG"), g("s_store"), g("r_store"), g("sca"), *tail)
         else:
             rc = self.lib.rr_cemaneigegr4jice_simulate_dev(
                 _ptr(self.prec), _ptr(self.temp), _ptr(self.etp),
                 _ptr(self.frac_ice), _ptr(self.frac), t, nl, i[0], i[1], i[3],
-                i[4], _ptr(params), n, _ptr(qsim), *([None] * 5), *tail)
+                i[4], _ptr(params), n, _ptr(qsim), g("G"), g("eTG"),
+                g("s_store"), g("r_store"), g("icemelt"), *tail)
         _lib.check(rc, "rr_snowgr4j_simulate_dev")
         return sse if qobs is not None else None
+
+
+def snow_layers(prec, mean_temp, min_temp, max_temp, met_station_height,
+                altitudes=(), device="cuda:0", numpy_exp=True):
+    """Station series -> the [T, L] layer forcing of the Cemaneige family,
+    computed on the GPU (rr_cemaneige_layers_dev): the resident counterpart of
+    the host preprocessing in rrmpg_amd.models.cemaneige_utils (reference:
+    rrmpg/models/cemaneige_utils.py).  Inputs: numpy arrays or device
+    tensors [T].  Returns device tensors (layer_prec, layer_mean_temp,
+    frac_solid_prec), ready for CemaneigeEnsemble & co.
+
+    numpy_exp=True hands the L precipitation factors over as numpy computes
+    them, so the result equals the host preprocessing bit for bit; False
+    lets the library use the C library's exp (as numba does).
+    """
+    lib = _lib.load()
+    _lib.require_gpu()
+    dev = torch.device(device)
+    series = [_dev_tensor(a, dev).reshape(-1) for a in (prec, mean_temp,
+                                                         min_temp, max_temp)]
+    t = int(series[0].numel())
+    if any(int(a.numel()) != t for a in series):
+        raise RuntimeError("All meteorological input arrays must have the "
+                           "same length.")
+    alts = np.asarray(altitudes if len(altitudes) else [met_station_height],
+                      dtype=np.float64)
+    nl = int(alts.size)
+    factor = None
+    if numpy_exp:
+        factor = np.where(
+            alts <= 4000, np.exp((alts - met_station_height) * 0.0004),
+            np.exp((4000 - met_station_height) * 0.0004)
+            if met_station_height <= 4000 else 1.0).astype(np.float64)
+    outs = [torch.empty((t, nl), dtype=torch.float64, device=dev)
+            for _ in range(3)]
+    wsb = lib.rr_cemaneige_layers_workspace_bytes(nl)
+    ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rr_cemaneige_layers_dev(
+            *[_ptr(a) for a in series], t, _lib.f64(alts)[1], nl,
+            float(met_station_height),
+            None if factor is None else _lib.f64(factor)[1],
+            *[_ptr(o) for o in outs], _ptr(ws), wsb,
+            torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "rr_cemaneige_layers_dev")
+    if t:
+        torch.cuda.current_stream(dev).synchronize()   # ws, factors go away
+    return tuple(outs)
 
 
 def column_sums(qsim, obs):

@@ -139,12 +139,68 @@ def loss_q(cls, hyst, ice, kge_as_is, X, obs, layers, frac_ice, inits,
     return loss if np.ndim(X) == 2 else loss[0]
 
 
-def loss_q_sca(cls, ice, X, obs, layers, frac_ice, ndsi, inits, loss_metric):
+class QScaScorer:
+    """The discharge + snow-covered-area loss of fit_Q_SCA evaluated where the
+    series are: forcing, observed discharge and the five NDSI series are
+    uploaded once, every candidate population is simulated with all state
+    series left in HBM, and the six squared-error / KGE ingredients per
+    candidate come from one column-sum pass each (rr_column_sums_dev) -- no
+    [T, L, N] array crosses PCIe and no Python loop runs over candidates
+    (the reference: one run + six metric calls per candidate,
+    cemaneigehystgr4j.py:615-691)."""
+
+    def __init__(self, ice, layers, frac_ice, inits, obs, ndsi):
+        import torch
+        from .. import device as rrdev
+        self.torch, self.rrdev = torch, rrdev
+        self.ens = rrdev.SnowGR4JEnsemble(
+            True, ice, layers[0], layers[1], layers[2], layers[3],
+            frac_ice=frac_ice if ice else None, snow_pack_init=inits[0],
+            thermal_state_init=inits[1], sca_init=inits[2], s_init=inits[3],
+            r_init=inits[4])
+        self.obs = np.ascontiguousarray(obs, dtype=np.float64)
+        # the model's sca is a fraction, the NDSI series are in percent:
+        # compare sca with NDSI / 100 (MSE scales by 1e4, KGE not at all)
+        self.ndsi = [np.ascontiguousarray(nd, dtype=np.float64).ravel() / 100
+                     for nd in ndsi]
+        dev = self.ens.device
+        self.obs_d = torch.from_numpy(self.obs).to(dev)
+        self.ndsi_d = [torch.from_numpy(nd).to(dev) for nd in self.ndsi]
+
+    def losses(self, params, loss_metric):
+        from ..utils.metrics import scores_from_sums
+        ens = self.ens
+        block = ens.upload_params(params)
+        n = block.shape[0]
+        qsim = ens.new_output(n)
+        st = ens.new_storages(n)
+        ens.run(block, qsim, storages=st)
+        ens.check()
+        key = "mse" if loss_metric == "mse" else "kge"
+        sums = self.rrdev.column_sums(qsim, self.obs_d).cpu().numpy()
+        part = scores_from_sums(sums, self.obs)[key]
+        total = 0.75 * (part if key == "mse" else 1 - part)
+        for b in range(5):
+            sums = self.rrdev.column_sums(st["sca"][:, b, :],
+                                          self.ndsi_d[b]).cpu().numpy()
+            part = scores_from_sums(sums, self.ndsi[b])[key]
+            total = total + 0.05 * (part * 1e4 if key == "mse" else 1 - part)
+        return total
+
+
+def loss_q_sca(cls, ice, X, obs, layers, frac_ice, ndsi, inits, loss_metric,
+               scorer=None):
     """Multi-objective loss on discharge (75 %) and the snow-covered area of
     the five elevation bands (5 % each, in percent against the NDSI series);
-    reference: cemaneigehystgr4j.py:615-691."""
+    reference: cemaneigehystgr4j.py:615-691.  With a QScaScorer (what
+    fit_Q_SCA builds) everything is scored in HBM; without one the series
+    are brought to the host and scored with calc_mse / calc_kge one candidate
+    at a time, as the reference does."""
     check_loss_metric(loss_metric)
     params = cls._params_from_population(X)
+    if scorer is not None:
+        losses = scorer.losses(params, loss_metric)
+        return losses if np.ndim(X) == 2 else losses[0]
     out, _ = run(True, ice, layers, frac_ice, inits, params, True, True, None)
     losses = np.zeros(params.size)
     for j in range(params.size):

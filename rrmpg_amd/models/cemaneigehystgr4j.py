@@ -136,7 +136,10 @@ class CemaneigeHystGR4J(BaseModel):
             met_station_height, snow_pack_init, thermal_state_init, sca_init,
             s_init, r_init, altitudes)
         ndsi = (NDSI1, NDSI2, NDSI3, NDSI4, NDSI5)
-        args = (obs, layers, ndsi, inits, loss_metric)
+        # forcing, observations and NDSI series resident in HBM for the
+        # whole optimisation; candidates are scored there
+        scorer = core.QScaScorer(False, layers, None, inits, obs, ndsi)
+        args = (obs, layers, ndsi, inits, loss_metric, scorer)
         return self._differential_evolution(_loss_Q_SCA, args, batched)
 
 
@@ -149,6 +152,7 @@ def _loss(X, *args):
 
 def _loss_Q_SCA(X, *args):
     """Return the discharge + SCA loss for the current parameter set(s)."""
-    obs, layers, ndsi, inits, loss_metric = args
+    obs, layers, ndsi, inits, loss_metric = args[:5]
     return core.loss_q_sca(CemaneigeHystGR4J, False, X, obs, layers, None,
-                           ndsi, inits, loss_metric)
+                           ndsi, inits, loss_metric,
+                           scorer=args[5] if len(args) > 5 else None)

@@ -122,7 +122,10 @@ class CemaneigeHystGR4JIce(BaseModel):
             met_station_height, snow_pack_init, thermal_state_init, sca_init,
             s_init, r_init, altitudes)
         ndsi = (NDSI1, NDSI2, NDSI3, NDSI4, NDSI5)
-        args = (obs, layers, fice, ndsi, inits, loss_metric)
+        # forcing, observations and NDSI series resident in HBM for the
+        # whole optimisation; candidates are scored there
+        scorer = core.QScaScorer(True, layers, fice, inits, obs, ndsi)
+        args = (obs, layers, fice, ndsi, inits, loss_metric, scorer)
         return self._differential_evolution(_loss_Q_SCA, args, batched)
 
 
@@ -135,6 +138,7 @@ def _loss(X, *args):
 
 def _loss_Q_SCA(X, *args):
     """Return the discharge + SCA loss for the current parameter set(s)."""
-    obs, layers, fice, ndsi, inits, loss_metric = args
+    obs, layers, fice, ndsi, inits, loss_metric = args[:6]
     return core.loss_q_sca(CemaneigeHystGR4JIce, True, X, obs, layers, fice,
-                           ndsi, inits, loss_metric)
+                           ndsi, inits, loss_metric,
+                           scorer=args[6] if len(args) > 6 else None)

@@ -173,3 +173,51 @@ def test_resident_ensembles_validate_their_tensors(env):
     ens.run(p, wide[:, 28:128])
     torch.cuda.synchronize()
     assert torch.equal(wide[:, 28:128], q) and float(wide[:, :28].sum()) == 0
+
+
+def test_device_snow_layers_match_reference_preprocessing(env):
+    """rr_cemaneige_layers_dev (forcing preprocessing on the GPU) against the
+    reference's own cemaneige_utils outputs (golden, generated by the
+    reference), including the >= 1500 m solid-fraction rule and the 4000 m
+    precipitation cap -- bit for bit."""
+    from .conftest import golden
+    torch, dev = env[0], env[1]
+    g = golden("syn_cemaneige_prep")
+    series = (g["prec"], g["temp"], g["tmin"], g["tmax"])
+    lp, lm, fr = dev.snow_layers(*series, float(g["station"]),
+                                 list(g["altitudes"]))
+    assert np.array_equal(lp.cpu().numpy(), g["layer_prec"])
+    assert np.array_equal(lm.cpu().numpy(), g["layer_mean"])
+    assert np.array_equal(fr.cpu().numpy(), g["frac_solid"])
+    lp, lm, fr = dev.snow_layers(*series, float(g["station_hi"]),
+                                 list(g["altitudes_hi"]))
+    assert np.array_equal(lp.cpu().numpy(), g["layer_prec_hi"])
+    assert np.array_equal(lm.cpu().numpy(), g["layer_mean_hi"])
+    assert np.array_equal(fr.cpu().numpy(), g["frac_solid_hi"])
+    lp, _, _ = dev.snow_layers(*(s[:64] for s in series),
+                               float(g["station_vhi"]),
+                               list(g["altitudes_hi"]))
+    assert np.array_equal(lp.cpu().numpy(), g["layer_prec_vhi"])
+    # the C library's exp instead of numpy's: the factor may differ in its
+    # last bit, the product by two
+    lp2, _, _ = dev.snow_layers(*series, float(g["station"]),
+                                list(g["altitudes"]), numpy_exp=False)
+    a, b = lp2.cpu().numpy(), g["layer_prec"]
+    assert np.all(np.abs(a - b) <= 2 * np.spacing(np.abs(b)))
+    # no elevation layers: one layer at station height; feeds an ensemble
+    lp1, lm1, fr1 = dev.snow_layers(*series, 500.0)
+    assert lp1.shape == (series[0].size, 1)
+    assert np.array_equal(lp1[:, 0].cpu().numpy(), g["prec"])
+    ens = dev.CemaneigeEnsemble(lp1, lm1, fr1)
+    from rrmpg_amd import models
+    p = dev.sample_params(models.Cemaneige(), 64, 3)
+    q = ens.new_output(64)
+    ens.run(p, q)
+    rec = np.zeros(64, dtype=models.Cemaneige._dtype)
+    for k, name in enumerate(models.Cemaneige._param_list):
+        rec[name] = p[:, k].cpu().numpy()
+    host = models.Cemaneige().simulate(
+        g["prec"], g["temp"], g["tmin"], g["tmax"], met_station_height=500,
+        params=rec)
+    torch.cuda.synchronize()
+    assert np.array_equal(q.cpu().numpy(), host)

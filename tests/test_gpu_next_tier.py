@@ -256,6 +256,27 @@ def test_next_tier_fit_losses(models):
         0.05 * calc_mse(ndsi[b], out["sca"][:, b, 0] * 100) for b in range(5))
     got = hmod._loss_Q_SCA(X, obs, layers, ndsi, inits, "mse")
     assert abs(got - want) <= 1e-10 * want
+    # what fit_Q_SCA really runs: the whole population scored in HBM
+    # (QScaScorer) -- equal to the host scoring, both metrics, and for the
+    # ice variant
+    Xpop = np.stack([X, h["params"][3], h["params"][5]], 1)
+    scorer = core.QScaScorer(False, layers, None, inits, obs, ndsi)
+    for metric in ("mse", "kge"):
+        host = hmod._loss_Q_SCA(Xpop, obs, layers, ndsi, inits, metric)
+        dev = hmod._loss_Q_SCA(Xpop, obs, layers, ndsi, inits, metric, scorer)
+        assert host.shape == dev.shape == (3,)
+        assert np.max(np.abs(dev - host) / np.abs(host)) < 1e-9, metric
+        one = hmod._loss_Q_SCA(Xpop[:, 1], obs, layers, ndsi, inits, metric,
+                               scorer)
+        assert abs(one - dev[1]) <= 1e-12 * abs(dev[1])
+    gi = golden("syn_cemaneigehystgr4jice")
+    Xi2 = np.stack([gi["params"][1], gi["params"][4]], 1)
+    sc_i = core.QScaScorer(True, layers, gi["frac_ice"], inits, obs, ndsi)
+    host = himod._loss_Q_SCA(Xi2, obs, layers, gi["frac_ice"], ndsi, inits,
+                             "mse")
+    dev = himod._loss_Q_SCA(Xi2, obs, layers, gi["frac_ice"], ndsi, inits,
+                            "mse", sc_i)
+    assert np.max(np.abs(dev - host) / np.abs(host)) < 1e-9
     # population form
     pop = hmod._loss(np.stack([X, h["params"][3]], 1), obs, layers, inits,
                      "mse")
