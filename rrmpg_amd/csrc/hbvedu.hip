@@ -357,13 +357,17 @@ static int hbv_launch(const double *temp, const double *prec,
                        (qobs && sse) ? qobs : nullptr, T, days);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK), (unsigned)C);
     const bool any_s = snow != nullptr;
-    // forcing variant: 0 scalar load per day (default), 1 LDS staging
-    // (measurement only), 2 scalar load with the next day prefetched: sweeps
-    // of at most one wave per SIMD (<= 65,536 sets, down to fit()'s single
-    // candidate), where nothing else hides the load -- measured 3.72 vs
-    // 4.10 ms at 20k sets, but 4.52 vs 4.21 at 100k and 29.5 vs 28.4 at 1M.
-    // rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one (tests, A/B runs).
-    int variant = (rr_ceil_div(N, RR_BLOCK) * C <= 1024) ? 2 : 0;
+    // forcing variant: 0 one scalar load at the top of each day; 1 LDS
+    // staging (measurement only); 2 the next day's record requested in the
+    // middle of the day, two records alternating (125 instead of 87 VGPRs).
+    // Measured (profiles/README.md, round 2, kernel ms for 0 / 2): 65k sets
+    // 4.03 / 3.35, 125k 3.98 / 4.07, 250k 8.09 / 7.75, 375k 12.85 / 11.21,
+    // 500k 14.76 / 14.63, 1M 28.07 / 28.07 -- the prefetch wins wherever a
+    // SIMD holds one or three to eight waves, loses 2 % at exactly two and
+    // ties from about twelve on, where the plain loop (one wave per SIMD
+    // more) is kept.  rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one.
+    const int64_t waves = rr_ceil_div(N, RR_BLOCK) * C;
+    int variant = ((waves > 1024 && waves <= 2048) || waves > 10240) ? 0 : 2;
     const int64_t pinned = rr_option(RR_OPT_HBV_VARIANT);
     if (pinned >= 0) variant = (int)pinned;
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,

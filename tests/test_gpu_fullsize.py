@@ -175,6 +175,15 @@ def test_metric_config_hbv_1m(env, oracle):
         sse2 = ens.run(params, q2, qobs=qobs)
         torch.cuda.synchronize()
         assert torch.equal(q2, qsim) and torch.equal(sse2, sse)
+        del q2
+    # one GPU's shard of the million-set sweep on eight GPUs, and the sizes
+    # either side of the kernel-variant thresholds: same columns, bit for bit
+    for m in (124_999, 65_536, 65_537, 131_073, 655_361):
+        qs = ens.new_output(m)
+        ss = ens.run(params[:m].contiguous(), qs, qobs=qobs)
+        torch.cuda.synchronize()
+        assert torch.equal(qs, qsim[:, :m]) and torch.equal(ss, sse[:m]), m
+        del qs
 
 
 def test_config2_gr4j_1m_scores(env, oracle):
