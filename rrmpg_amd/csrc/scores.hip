@@ -4,13 +4,17 @@
 // a Python loop over calc_mse (reference: rrmpg/tools/monte_carlo.py:66-71),
 // and its metrics module offers NSE, RMSE, KGE, alpha/beta and Pearson r
 // (reference: rrmpg/utils/metrics.py:29-299), each re-validating and copying
-// both series.  All of those scores are functions of five per-column sums, so
-// one pass over qsim[T][ld] produces them for every parameter set at once:
-//     sums[i] = { sum q, sum q^2, sum q*obs, sum (obs - q)^2, #finite pairs }
+// both series.  All of those scores are functions of four per-column sums
+// (and of sums over the observations alone, taken on the host), so one pass
+// over qsim[T][ld] produces them for every parameter set at once:
+//     sums[i] = { sum q, sum q^2, sum q*obs, sum (obs - q)^2 }
 // One lane per column, rows streamed top to bottom: each wave reads 512
 // contiguous bytes per row -- a pure HBM-bandwidth kernel (8 B per
-// model-timestep read, nothing written but 40 B per set).  Accumulation is
-// in time order (numpy's pairwise sums differ by ~1e-16 relative).
+// model-timestep read, nothing written but 32 B per set).  Accumulation is
+// in time order (numpy's pairwise sums differ by ~1e-16 relative).  As in the
+// reference's metric functions, a NaN in either series makes that column's
+// scores NaN: there is no pairwise-finite filtering (callers with gaps in the
+// observations mask them before, as they would for rrmpg.utils.metrics).
 #include "common.h"
 
 __global__ __launch_bounds__(256) void column_sums_kernel(

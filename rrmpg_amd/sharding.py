@@ -29,17 +29,20 @@ def shard_bounds(num_sets, world_size, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def allgather_scores(local_scores, num_sets=None, group=None):
+def allgather_scores(local_scores, num_sets=None, group=None,
+                     always_collective=False):
     """All-gather the per-set scores of every rank's block, in set order.
 
     local_scores: 1-D tensor (this rank's block; blocks may differ in length
     by one).  Returns the concatenated [num_sets] tensor on every rank.
-    Without an initialised process group (single process) it is the identity.
+    Without an initialised process group (single process) it is the identity;
+    so it is for a group of one rank unless always_collective is set (tests:
+    the RCCL call itself on a single-GPU box).
     """
     if not (dist.is_available() and dist.is_initialized()):
         return local_scores
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not always_collective:
         return local_scores
     rank = dist.get_rank(group)
     if num_sets is None:

@@ -108,3 +108,34 @@ def test_self_launched_ranks_over_rccl():
              env={"WORLD_SIZE": None, "RANK": None, "LOCAL_RANK": None})
     assert d["n_gpus"] == 2 and d["scores_finite"] is True
     assert 0 <= d["parity_spot"] < 1e-10
+
+
+def test_rccl_collectives_on_one_rank(tmp_path):
+    """backend "nccl" (= RCCL) initialises and runs the sweep's collectives
+    (barrier, max-reduce of the timings, all-gather of the scores) on this
+    software stack -- with the one rank a single-GPU box can host."""
+    script = tmp_path / "one_rank.py"
+    script.write_text(
+        "import os, sys, torch\n"
+        "import torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from rrmpg_amd.sharding import allgather_scores\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29611',\n"
+        "                  RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "dist.barrier()\n"
+        "x = torch.arange(1001, dtype=torch.float64, device=dev) * 0.5\n"
+        "y = allgather_scores(x, 1001, always_collective=True)\n"
+        "t = torch.tensor([3.0, 1.0], dtype=torch.float64, device=dev)\n"
+        "dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(x, y) and y.data_ptr() != x.data_ptr()\n"
+        "assert t.tolist() == [3.0, 1.0]\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n"
+        % REPO)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True,
+                         text=True, timeout=300,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
