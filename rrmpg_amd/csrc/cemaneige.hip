@@ -27,8 +27,9 @@
 
 #include "snow_core.h"
 
-// days: [T][D] doubles, D = 3*L + (with_etp ? 1 : 0):
-//   [0,L) snow, [L,2L) rain, [2L,3L) mean_temp, [3L] etp
+// days: [T][D] doubles, D = cema_record_len(L, with_etp) (snow_core.h):
+//   [0,L) snow, [L,2L) rain, [2L,3L) mean_temp, [3L] etp, then the day's
+//   observation (cema_day_meta)
 __global__ void cema_pack(const double *__restrict__ prec,
                           const double *__restrict__ mean_temp,
                           const double *__restrict__ frac,
@@ -47,6 +48,16 @@ __global__ void cema_pack(const double *__restrict__ prec,
     d[L + l] = rain;
     d[2 * L + l] = mean_temp[g];
     if (etp && l == 0) d[3 * L] = etp[t];
+}
+
+// The trailing slot of every record: the day's observed discharge
+// (snow_core.h).  One thread per day.
+__global__ void cema_day_meta(double *__restrict__ days, int64_t T, int D,
+                              const double *__restrict__ qobs)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    days[t * D + D - 1] = qobs ? qobs[t] : 0.0;
 }
 
 // One workgroup per layer: the wave stages 256 days of snow in LDS, lane 0
@@ -120,9 +131,10 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
         // the whole day record by value, up front: one wide scalar load and
         // one wait per day (read through the pointer, hipcc fetches every
         // field at its use site with its own s_load + wait)
-        double rec[3 * L];
+        constexpr int D = cema_record_len(L, false);
+        double rec[D];
 #pragma unroll
-        for (int k = 0; k < 3 * L; ++k) rec[k] = days[t * (3 * L) + k];
+        for (int k = 0; k < D; ++k) rec[k] = days[t * D + k];
         const double q = cema_day<L, decltype(first)::value>(
             rec, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG, omc,
             Kf, G, eTG);
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
             }
         }
         if (we) {
-            const double d = qobs[t] - q;
+            const double d = rec[D - 1] - q;     // the day's observation
             acc = __builtin_fma(d, d, acc);
         }
     };
@@ -199,7 +211,7 @@ cemaneigegr4j_kernel(
     double s = s_init * P.x1, r = r_init * P.x3;
     double acc = 0.0;
     const bool we = sse != nullptr;
-    constexpr int D = 3 * L + 1;
+    constexpr int D = cema_record_len(L, true);
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
     auto one_day = [&](auto first, int64_t t) {
@@ -230,7 +242,7 @@ cemaneigegr4j_kernel(
             }
         }
         if (we) {
-            const double d = qobs[t] - q;
+            const double d = day[D - 1] - q;   // the day's observation
             acc = __builtin_fma(d, d, acc);
         }
     };
@@ -362,17 +374,19 @@ extern "C" size_t rr_cemaneigegr4j_workspace_bytes(int64_t T, int64_t L,
 }
 
 int rr_cema_prepass(const double *prec, const double *mean_temp,
-                        const double *frac, const double *etp, int64_t T,
-                        int L, void *workspace, hipStream_t st,
-                        double **days_out, double **gt_out,
+                        const double *frac, const double *etp,
+                        const double *qobs, int64_t T, int L, void *workspace,
+                        hipStream_t st, double **days_out, double **gt_out,
                         double **state_out)
 {
-    const int D = 3 * L + (etp ? 1 : 0);
+    const int D = cema_record_len(L, etp != nullptr);
     double *gt = (double *)((char *)workspace + 512);
     double *days = (double *)((char *)workspace + 512 + cema_gt_bytes(L));
     hipLaunchKernelGGL(cema_pack, dim3((unsigned)rr_ceil_div(T * L, 256)),
                        dim3(256), 0, st, prec, mean_temp, frac, etp, T, L, D,
                        days);
+    hipLaunchKernelGGL(cema_day_meta, dim3((unsigned)rr_ceil_div(T, 256)),
+                       dim3(256), 0, st, days, T, D, qobs);
     hipLaunchKernelGGL(cema_gtresh, dim3((unsigned)L), dim3(256), 0, st, days,
                        T, D, gt);
     hipLaunchKernelGGL(cema_gt_table, dim3(1), dim3(1), 0, st, gt, L,
@@ -522,14 +536,15 @@ extern "C" int rr_cemaneige_simulate_dev(
     }
     hipStream_t st = (hipStream_t)stream;
     double *days, *gt, *state;
-    rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, nullptr, T, (int)L,
-                      workspace, st, &days, &gt, &state);
+    rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, nullptr,
+                         (qobs && sse) ? qobs : nullptr, T, (int)L, workspace,
+                         st, &days, &gt, &state);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
     if (L > RR_CEMANEIGE_MAX_LAYERS) {
         cemaneige_dyn_kernel<void><<<grid, block, 0, st>>>(
-            days, gt, T, (int)L, 3 * (int)L, snow_pack_init,
+            days, gt, T, (int)L, cema_record_len((int)L, false), snow_pack_init,
             thermal_state_init, 0., 0., params, 2, N, nullptr, 0, state,
             outflow, G, eTG, nullptr, nullptr, ld, qo, sse);
         RR_HIP(hipGetLastError());
@@ -580,8 +595,9 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
     if (rc != RR_OK) return rc;
     const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     double *days, *gt, *state;
-    rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp, T, (int)L,
-                      workspace, st, &days, &gt, &state);
+    rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp,
+                         (qobs && sse) ? qobs : nullptr, T, (int)L, workspace,
+                         st, &days, &gt, &state);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
@@ -593,7 +609,8 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
             using UH = decltype(uh);
             cemaneige_dyn_kernel<UH>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
-                   st>>>(days, gt, T, (int)L, 3 * (int)L + 1, snow_pack_init,
+                   st>>>(days, gt, T, (int)L, cema_record_len((int)L, true),
+                         snow_pack_init,
                          thermal_state_init, s_init, r_init, params, 6, N,
                          d_plan, force_lds, state, qsim, G, eTG, s_store,
                          r_store, ld, qo, sse);

@@ -49,6 +49,11 @@ __device__ __forceinline__ double nb_min(double a, double b) {
 typedef unsigned long long lanemask_t;
 #define RR_LANES(cmp) ((lanemask_t)__builtin_amdgcn_ballot_w64(cmp))
 __device__ __forceinline__ lanemask_t rr_exec() { return RR_LANES(true); }
+// "some lane of the wave is outside mask m" for the votes whose answer is no
+// in any sane run: marked unlikely so that hipcc lays the slow block out of
+// line and the fast path falls through (a taken branch per vote per day
+// otherwise: the wave's instruction buffer is refilled every time).
+#define RR_ANY_OUTSIDE(m) __builtin_expect((rr_exec() & ~(m)) != 0, 0)
 
 // Class tests written directly into an SGPR pair with one v_cmp_class_f64
 // (spelled as an integer or class test in C++ they go through the VGPR round
@@ -114,7 +119,7 @@ __device__ __forceinline__ double div_by_invariant_m(double a, lanemask_t a_ok,
                                                      lanemask_t d_ok,
                                                      double hi = 0x1p900) {
     double q = inv_div_core(a, d);
-    if (rr_exec() & ~(a_ok & d_ok)) {
+    if (RR_ANY_OUTSIDE(a_ok & d_ok)) {
         const bool ok = inv_div_numerator_ok0(a) && fabs(a) <= hi && d.ok;
         const double exact = a / d.b;
         q = ok ? q : exact;        // ok lanes: both values are RN(a / b)

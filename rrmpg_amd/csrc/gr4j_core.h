@@ -173,7 +173,7 @@ struct UhRegs {
                 ? uh_fma(o2[j], p2, u2[(j + 1 < N2MAX) ? j + 1 : j])
                 : o2[j] * p2;
         const lanemask_t finite = lanes_finite(p1) & lanes_finite(p2);
-        if (rr_exec() & ~finite) {
+        if (RR_ANY_OUTSIDE(finite)) {
             // (lengths made opaque: hipcc otherwise hoists the 3 * N1MAX + 1
             // slot masks `j < n` of this never-taken path out of the time
             // loop and parks them in that many SGPR pairs)
@@ -272,7 +272,7 @@ struct UhLds {
             if (j == 0) head2 = nv;
         }
         const lanemask_t finite = lanes_finite(p1) & lanes_finite(p2);
-        if (rr_exec() & ~finite) {
+        if (RR_ANY_OUTSIDE(finite)) {
             for (int j = 0; j < n1w; ++j)
                 if (j >= n1) U1(j) = 0.0;
             for (int j = 0; j < n2w; ++j)
@@ -360,7 +360,7 @@ __device__ __forceinline__ double gr4j_inv_fourth_root(double b)
 {
     if constexpr (!GUARD_BY_VOTE) return inv_fourth_root(b);
     double y = inv_fourth_root_core3(b);
-    if (rr_exec() & ~lanes_of_class(b, 0x100)) {
+    if (RR_ANY_OUTSIDE(lanes_of_class(b, 0x100))) {
         asm volatile("");                   // keep this a branch
         y = (b < __builtin_inf()) ? y : ((b != b) ? b : 0.0);
     }
@@ -382,7 +382,7 @@ __device__ __forceinline__ double pow_3_5(double x)
     double xr;
     asm("v_max_f64 %0, %1, %2" : "=v"(xr) : "v"(x), "s"(0x1p-500));
     double root = fast_sqrt_core(xr);
-    if (rr_exec() & ~ok) {
+    if (RR_ANY_OUTSIDE(ok)) {
         // (the empty asm keeps this a branch: hipcc would otherwise evaluate
         // the IEEE sqrt for every wave and select)
         asm volatile("");
@@ -459,7 +459,7 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     const lanemask_t fast = gr4j_num_mask(s) & P.x1_m &
                             RR_LANES(fabs(den) >= 0x1p-100);
     double frac = fast_div_core(c * E, den);
-    if (rr_exec() & ~fast) {
+    if (RR_ANY_OUTSIDE(fast)) {
         double exact;
         if constexpr (std::is_same<UH, UhRegs<10>>::value) {
             // measured: out of line is 2 % faster in these kernels, 1-2 %

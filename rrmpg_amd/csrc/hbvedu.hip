@@ -223,7 +223,7 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
             // the box mask is the vote, and no compare is spent on it.  If any lane
             // is outside the box the wave also evaluates the general pow and
             // every lane fastpow cannot serve takes it.
-            if (rr_exec() & ~soil_m) {
+            if (RR_ANY_OUTSIDE(soil_m)) {
                 const double general = pow_general(wetness, Beta);
                 pw = fastpow_tab_ok(wetness, z) ? pw : general;
             }

@@ -10,19 +10,35 @@
 int rr_gr4j_plan_async(const double *params, int64_t N, int stride,
                        int x4_index, int *d_plan, hipStream_t st);
 
-// defined in cemaneige.hip: packs the per-day records {snow[L], rain[L],
-// temp[L] (, etp)} and the per-layer G_tresh[L] / Psolannual[L] into the
-// workspace (layout below); returns device pointers into it
+// Day record of the snow kernels, D = cema_record_len(L, with_etp) doubles:
+//   [0, L) snow   [L, 2L) rain   [2L, 3L) mean temperature   [3L] etp (if any)
+//   [D - 1] the day's observed discharge (0 when no score is fused): rides
+//           along so that the score needs no second scalar load + wait at the
+//           end of every day
+// One record is wave-uniform and arrives with one burst of scalar loads.
+// (Measured and dropped, round 2: a flag word per day -- temp[l] > 0, snow[l]
+// == +0 -- with wave-uniform shortcuts for frost days and bare ground, which
+// cut the snow routine from ~17 to 6-8 vector instructions on most
+// layer-days, bit for bit: the two scalar branches per layer and day they
+// need made every snow kernel 10-19 % SLOWER; profiles/README.md.)
+static __host__ __device__ constexpr int cema_record_len(int L, bool with_etp)
+{
+    return 3 * L + (with_etp ? 1 : 0) + 1;
+}
+
+// defined in cemaneige.hip: packs the day records and the per-layer
+// G_tresh[L] / Psolannual[L] / CemaGt table into the workspace (layout
+// below); returns device pointers into it.  qobs: device, [T], or NULL.
 int rr_cema_prepass(const double *prec, const double *mean_temp,
-                    const double *frac, const double *etp, int64_t T, int L,
-                    void *workspace, hipStream_t st, double **days_out,
-                    double **gt_out, double **state_out);
+                    const double *frac, const double *etp, const double *qobs,
+                    int64_t T, int L, void *workspace, hipStream_t st,
+                    double **days_out, double **gt_out, double **state_out);
 
 static inline size_t cema_days_bytes(int64_t T, int64_t L, bool with_etp)
 {
     if (T < 1) T = 1;
     if (L < 1) L = 1;
-    return rr_align256((size_t)T * (size_t)(3 * L + (with_etp ? 1 : 0)) * 8);
+    return rr_align256((size_t)T * (size_t)cema_record_len((int)L, with_etp) * 8);
 }
 
 // per-layer constants: G_tresh[L], Psolannual[L], the CemaGt table [L] the

@@ -143,7 +143,7 @@ snow_gr4j_kernel(
     double s = s_init * P.x1, r = r_init * P.x3;
     double acc = 0.0;
     const bool we = sse != nullptr;
-    constexpr int D = 3 * L + 1;
+    constexpr int D = cema_record_len(L, true);
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
     auto one_day = [&](auto first, int64_t t) {
@@ -202,7 +202,7 @@ snow_gr4j_kernel(
             }
         }
         if (we) {
-            const double d = qobs[t] - q;
+            const double d = day[D - 1] - q;   // the day's observation
             acc = __builtin_fma(d, d, acc);
         }
     };
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
     double s = s_init * P.x1, r = r_init * P.x3;
     double acc = 0.0;
     const bool we = sse != nullptr;
-    const int D = 3 * L + 1;
+    const int D = cema_record_len(L, true);
     for (int64_t t = 0; t < T; ++t) {
         const double *day = days + t * D;
         const bool first = t == 0;
@@ -400,8 +400,9 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     if (rc != RR_OK) return rc;
     const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     double *days, *gt, *state;
-    rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp, T, (int)L,
-                      workspace, st, &days, &gt, &state);
+    rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp,
+                         (qobs && sse) ? qobs : nullptr, T, (int)L, workspace,
+                         st, &days, &gt, &state);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
