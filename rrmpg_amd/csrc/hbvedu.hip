@@ -318,8 +318,18 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         }
         if (t < Ti) day_step(a, t, [] {});
     } else {
-        for (int t = 1; t < Ti; ++t) {
-            const HbvDay f = days[t];      // wave-uniform -> s_load_dwordx8
+        // (two days per trip, written out -- the votes are convergent
+        // operations, which keeps hipcc from unrolling a loop with a
+        // remainder on its own: one taken branch per two days)
+        int t = 1;
+        for (; t + 1 < Ti; t += 2) {
+            const HbvDay f0 = days[t];     // wave-uniform -> s_load_dwordx8
+            day_step(f0, t, [] {});
+            const HbvDay f1 = days[t + 1];
+            day_step(f1, t + 1, [] {});
+        }
+        if (t < Ti) {
+            const HbvDay f = days[t];
             day_step(f, t, [] {});
         }
     }
