@@ -17,10 +17,11 @@ int rr_gr4j_plan_async(const double *params, int64_t N, int stride,
 //           end of every day
 // One record is wave-uniform and arrives with one burst of scalar loads.
 // (Measured and dropped, round 2: a flag word per day -- temp[l] > 0, snow[l]
-// == +0 -- with wave-uniform shortcuts for frost days and bare ground, which
-// cut the snow routine from ~17 to 6-8 vector instructions on most
-// layer-days, bit for bit: the two scalar branches per layer and day they
-// need made every snow kernel 10-19 % SLOWER; profiles/README.md.)
+// == +0 -- with wave-uniform shortcuts for frost and bare ground that cut the
+// snow routine from ~17 to 6-8 vector instructions per layer-day, bit for
+// bit.  Decided per layer (two scalar branches per layer and day) every snow
+// kernel got 10-19 % SLOWER; decided once per day (all layers frost / all
+// bare) nothing was gained either.  profiles/README.md.)
 static __host__ __device__ constexpr int cema_record_len(int L, bool with_etp)
 {
     return 3 * L + (with_etp ? 1 : 0) + 1;

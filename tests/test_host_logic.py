@@ -351,3 +351,47 @@ def test_array_checks():
     src = np.ones((2, 3))
     out = validate_array_input(src, np.float64, 'arr')
     assert out.shape == (6,) and out is not src
+
+
+def test_debug_options_and_cache_release_need_no_gpu():
+    """The measurement / test hooks are plain process-wide ints behind
+    rr_debug_set_option (nothing in the library reads the environment), with
+    range checks; releasing cached memory is a no-op without a device."""
+    lib = _lib.load()
+    opt = _lib.OPTIONS
+    assert lib.rr_debug_get_option(opt["hbv_variant"]) == -1
+    assert lib.rr_debug_get_option(opt["gr4j_force_lds"]) == 0
+    assert lib.rr_debug_get_option(opt["max_block_cols"]) == 0
+    with _lib.debug_option("hbv_variant", 2):
+        assert lib.rr_debug_get_option(opt["hbv_variant"]) == 2
+        with _lib.debug_option("max_block_cols", 512):
+            assert lib.rr_debug_get_option(opt["max_block_cols"]) == 512
+        assert lib.rr_debug_get_option(opt["max_block_cols"]) == 0
+    assert lib.rr_debug_get_option(opt["hbv_variant"]) == -1
+    assert lib.rr_debug_set_option(opt["hbv_variant"], 7) == -4    # RR_E_PARAM
+    assert b"does not take" in lib.rr_last_error()
+    assert lib.rr_debug_set_option(99, 0) == -4
+    assert lib.rr_debug_get_option(99) == -2 ** 63
+    assert lib.rr_release_cached_memory() == 0
+    # no getenv anywhere in the library's sources
+    csrc = os.path.join(REPO, "rrmpg_amd", "csrc")
+    for name in os.listdir(csrc):
+        if name.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, name)).read(), name
+
+
+def test_layer_preprocessing_argument_errors_without_gpu():
+    lib = _lib.load()
+    alt = np.array([600., 900.])
+    pa = alt.ctypes.data_as(_lib._f64p)
+    assert lib.rr_cemaneige_layers_workspace_bytes(5) >= 5 * 24
+    rc = lib.rr_cemaneige_layers_dev(None, None, None, None, 10, pa, 2, 500.,
+                                     None, None, None, None, None, 0, None)
+    assert rc == -1 and b"NULL pointer" in lib.rr_last_error()
+    rc = lib.rr_cemaneige_layers_dev(None, None, None, None, 10, pa, 0, 500.,
+                                     None, None, None, None, None, 0, None)
+    assert rc == -2
+    assert lib.rr_cemaneige_layers_dev(None, None, None, None, 0, pa, 2, 500.,
+                                       None, None, None, None, None, 0,
+                                       None) == 0
+    assert lib.rr_gr4j_plan_status(None, None) == -1
