@@ -83,8 +83,9 @@ int rr_get_device(void);
  * buffers (inputs, parameter block, workspace, output slabs up to 64 MiB
  * each) between calls, and does not upload an input again whose bytes have
  * not changed since the previous call -- Model.fit() makes thousands of
- * one-set calls with the same forcing.  This returns that memory to the
- * device (the next call allocates again). */
+ * one-set calls with the same forcing.  Large results additionally leave a
+ * 256-MiB pinned staging ring behind.  This returns all of that memory (the
+ * next call allocates again). */
 int rr_release_cached_memory(void);
 
 /* Measurement / test hooks.  Process-wide integer options that select a

@@ -557,6 +557,14 @@ extern "C" int rr_release_cached_memory(void)
         slot_free(c.ws[k]); slot_free(c.sse[k]);
         for (Slot &s : c.slab[k]) slot_free(s);
     }
+    if (c.ring) {                       // the 256-MiB pinned staging ring
+        (void)hipHostFree(c.ring);
+        c.ring = nullptr;
+        for (int k = 0; k < RING_SLOTS; ++k) {
+            if (c.ring_ev[k]) (void)hipEventDestroy(c.ring_ev[k]);
+            c.ring_ev[k] = nullptr;
+        }
+    }
     return RR_OK;
 }
 

@@ -221,3 +221,41 @@ def test_device_snow_layers_match_reference_preprocessing(env):
         params=rec)
     torch.cuda.synchronize()
     assert np.array_equal(q.cpu().numpy(), host)
+
+
+def test_host_family_context_and_staged_gather(env, oracle):
+    """The host-pointer family's per-device context: an input whose bytes
+    changed IN PLACE is uploaded again (the hash, not the pointer, decides);
+    a result above 64 MiB goes through the pinned staging ring in several
+    double-buffered column blocks and equals the small-block result; the
+    cache can be released and is rebuilt on demand."""
+    torch, dev, models, syn, f = env
+    from rrmpg_amd import _lib
+    t = 2000
+    temp, prec = f["temp"][:t].copy(), f["prec"][:t].copy()
+    kw = dict(month=f["month"][:t], PE_m=f["PE_m"], T_m=f["T_m"],
+              soil_init=100., s1_init=3., s2_init=10.)
+    np.random.seed(2)
+    m = models.HBVEdu()
+    p = m.get_random_params(6000)                # 2000 x 6000 x 8 B = 96 MB
+    q1 = m.simulate(temp, prec, params=p, **kw)
+    flat = np.stack([p[k] for k in m.get_parameter_names()], 1)
+    cols = np.array([0, 17, 2999, 3000, 5999])
+    ref = oracle.simulate_hbvedu(temp, prec, f["month"][:t] - 1, f["PE_m"],
+                                 f["T_m"], (0., 100., 3., 10.), flat[cols])
+    assert rel_err(q1[:, cols], ref) < 1e-10
+    with _lib.debug_option("max_block_cols", 640):       # ten ragged blocks
+        q2 = m.simulate(temp, prec, params=p, **kw)
+    assert np.array_equal(q1, q2)
+    # same buffer, new content: must not be served from the cached copy
+    prec *= 1.5
+    q3 = m.simulate(temp, prec, params=p[:64], **kw)
+    ref3 = oracle.simulate_hbvedu(temp, prec, f["month"][:t] - 1, f["PE_m"],
+                                  f["T_m"], (0., 100., 3., 10.), flat[:64])
+    assert rel_err(q3, ref3) < 1e-10
+    assert not np.array_equal(q3, q1[:, :64])
+    assert _lib.load().rr_release_cached_memory() == 0
+    q4 = m.simulate(temp, prec, params=p[:64], **kw)
+    assert np.array_equal(q3, q4)
+    q5 = m.simulate(temp, prec.copy(), params=p, **kw)        # ring again
+    assert np.array_equal(q5[:, :64], q3)
