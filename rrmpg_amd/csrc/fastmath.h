@@ -289,18 +289,20 @@ FP_FN double fastpow_tab_core(double x, double y2hi, double y2lo,
     // 2^(z_hi + z_lo), as in fastpow_core
     const double n = FP_RINT(z_hi);
     const double q0 = (z_hi - n) + z_lo;              // |.| <= 0.5 (+ tiny)
-    double q = 1.3691488853904128e-12;                // ln2^13 / 13!
-    q = FP_FMA_K(q, q0, 2.5678435993488206e-11);
-    q = FP_FMA_K(q, q0, 4.4455382718708116e-10);
-    q = FP_FMA_K(q, q0, 7.054911620801123e-09);
-    q = FP_FMA_K(q, q0, 1.01780860092397e-07);
-    q = FP_FMA_K(q, q0, 1.321548679014431e-06);
-    q = FP_FMA_K(q, q0, 1.5252733804059841e-05);
-    q = FP_FMA_K(q, q0, 0.0001540353039338161);
-    q = FP_FMA_K(q, q0, 0.0013333558146428443);
-    q = FP_FMA_K(q, q0, 0.009618129107628477);
-    q = FP_FMA_K(q, q0, 0.05550410866482158);
-    q = FP_FMA_K(q, q0, 0.24022650695910072);
+    // 2^q0 = 1 + q0 Q(q0), Q of degree 10 through the Chebyshev nodes of
+    // [-1/2, 1/2] (csrc/tools/gen_exp_poly.py; 0.18 x 2^-53, the same as the
+    // degree-12 Taylor polynomial this replaces: both are at the rounding of
+    // their coefficients)
+    double q = 4.4549605981865186e-10;
+    q = FP_FMA_K(q, q0, 7.072585949269223e-09);
+    q = FP_FMA_K(q, q0, 1.0178062445845774e-07);
+    q = FP_FMA_K(q, q0, 1.321544258792169e-06);
+    q = FP_FMA_K(q, q0, 1.525273382983612e-05);
+    q = FP_FMA_K(q, q0, 0.0001540353044173605);
+    q = FP_FMA_K(q, q0, 0.0013333558146416936);
+    q = FP_FMA_K(q, q0, 0.009618129107606888);
+    q = FP_FMA_K(q, q0, 0.0555041086648216);
+    q = FP_FMA_K(q, q0, 0.24022650695910097);
     q = FP_FMA_K(q, q0, 0.6931471805599453);
     q = FP_FMA(q, q0, 1.0);                           // inline constant
     return FP_LDEXP(q, (int)n);
@@ -317,7 +319,9 @@ FP_FN bool fastpow_tab_ok(double x, double z)
 // ---------------------------------------------------------------------------
 // tanh(a), any a.  tanh(a) = E / (E + 2) with E = expm1(2|a|), sign restored.
 //   2|a| = n ln2 + r, |r| <= ln2/2 (ln2 split hi/lo so n*ln2_hi is exact);
-//   expm1(r) = r + r^2 (1/2 + r/6 + ... + r^11/13!) (truncation 1e-17 rel.);
+//   expm1(r) = r + r^2 q(r), q of degree 10 through the Chebyshev nodes of
+//   the interval (csrc/tools/gen_exp_poly.py, 0.008 x 2^-53; the Taylor
+//   polynomial of that accuracy has degree 11);
 //   E = 2^n expm1(r) + (2^n - 1) in one FMA (2^n - 1 is exact for n <= 53).
 // |a| is clamped to 20 first (tanh(20) rounds to 1.0; keeps 2^n finite and
 // makes +-inf give +-1); NaN propagates; tanh(+-0) = +-0.  Error <= ~2.5 ulp
@@ -326,7 +330,7 @@ FP_FN bool fastpow_tab_ok(double x, double z)
 // fast_tanh_parts gives numerator and denominator (tanh(a) = num / den,
 // den >= 1) so that a caller can fold the quotient into one of its own.
 //
-// JIT_CONST (device only): the 15 constants are fetched from constant memory
+// JIT_CONST (device only): the 14 constants are fetched from constant memory
 // with scalar loads at the point of use instead of living in SGPRs for the
 // whole time loop.  The big fused kernels (snow routine + GR4J) run out of
 // SGPRs otherwise and hipcc parks the overflow in VGPR lanes, paying a
@@ -334,12 +338,12 @@ FP_FN bool fastpow_tab_ok(double x, double z)
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const double __attribute__((address_space(4))) *fp_cptr_t;
 static __device__ __constant__ const double FP_TANH_TABLE[16] = {
-    1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08,
-    2.755731922398589e-07, 2.7557319223985893e-06, 2.48015873015873e-05,
-    0.0001984126984126984, 0.001388888888888889, 0.008333333333333333,
-    0.041666666666666664, 0.16666666666666666, 0.5,
+    2.0914679376583935e-09, 2.510520637395701e-08, 2.7557273661348637e-07,
+    2.7557255425746435e-06, 2.4801587325533363e-05, 0.00019841269874800493,
+    0.0013888888888883752, 0.008333333333326141, 0.04166666666666667,
+    0.1666666666666667, 0.5,
     1.4426950408889634, 6.93147180369123816490e-01,
-    1.90821492927058770002e-10, 0.0};
+    1.90821492927058770002e-10, 0.0, 0.0};
 #endif
 
 template <bool JIT_CONST = false>
@@ -353,11 +357,11 @@ FP_FN void fast_tanh_parts(double a, double &num, double &den)
     if constexpr (JIT_CONST) {
         fp_cptr_t c = (fp_cptr_t)FP_TANH_TABLE;
         asm volatile("" : "+s"(c));   // keeps the loads inside the time loop
-        n = FP_RINT(y * c[12]);
-        const double r = FP_FMA(-n, c[14], FP_FMA(-n, c[13], y));
+        n = FP_RINT(y * c[11]);
+        const double r = FP_FMA(-n, c[13], FP_FMA(-n, c[12], y));
         double q = c[0];
 #pragma unroll
-        for (int j = 1; j < 12; ++j) q = FP_FMA_C(q, r, c[j]);
+        for (int j = 1; j < 11; ++j) q = FP_FMA_C(q, r, c[j]);
         p = FP_FMA(r * r, q, r);
     } else
 #endif
@@ -365,17 +369,16 @@ FP_FN void fast_tanh_parts(double a, double &num, double &den)
         n = FP_RINT(y * 1.4426950408889634);
         const double r = FP_FMA(-n, 1.90821492927058770002e-10,
                                 FP_FMA(-n, 6.93147180369123816490e-01, y));
-        double q = 1.6059043836821613e-10;           // 1/13!
-        q = FP_FMA_C(q, r, 2.08767569878681e-09);    // 1/12!
-        q = FP_FMA_C(q, r, 2.505210838544172e-08);   // 1/11!
-        q = FP_FMA_C(q, r, 2.755731922398589e-07);   // 1/10!
-        q = FP_FMA_C(q, r, 2.7557319223985893e-06);  // 1/9!
-        q = FP_FMA_C(q, r, 2.48015873015873e-05);    // 1/8!
-        q = FP_FMA_C(q, r, 0.0001984126984126984);   // 1/7!
-        q = FP_FMA_C(q, r, 0.001388888888888889);    // 1/6!
-        q = FP_FMA_C(q, r, 0.008333333333333333);    // 1/5!
-        q = FP_FMA_C(q, r, 0.041666666666666664);    // 1/4!
-        q = FP_FMA_C(q, r, 0.16666666666666666);     // 1/3!
+        double q = 2.0914679376583935e-09;           // see FP_TANH_TABLE
+        q = FP_FMA_C(q, r, 2.510520637395701e-08);
+        q = FP_FMA_C(q, r, 2.7557273661348637e-07);
+        q = FP_FMA_C(q, r, 2.7557255425746435e-06);
+        q = FP_FMA_C(q, r, 2.4801587325533363e-05);
+        q = FP_FMA_C(q, r, 0.00019841269874800493);
+        q = FP_FMA_C(q, r, 0.0013888888888883752);
+        q = FP_FMA_C(q, r, 0.008333333333326141);
+        q = FP_FMA_C(q, r, 0.04166666666666667);
+        q = FP_FMA_C(q, r, 0.1666666666666667);
         q = FP_FMA_C(q, r, 0.5);
         p = FP_FMA(r * r, q, r);                     // expm1(r)
     }
@@ -449,6 +452,67 @@ FP_FN double inv_fourth_root_core3(double bb)
     // constant of the ISA, 0.25 is not
     const double p = FP_FMA_HALF(e, 0.3125);
     return FP_FMA(y * e * 0.5, p, y);
+}
+
+// (1 + u)**(-1/4) for 0 <= u <= FP_R4_UMAX as 1 + u P(u), P of degree 7
+// (csrc/tools/gen_root_poly.py; approximation error 0.009 x 2^-53): eight
+// full-rate FMAs and no hardware estimate -- the Newton form above costs two
+// quarter-rate instructions (16 cycles each) + 8, i.e. about twice as much.
+// The result is the rounding of 1 + u P(u) with u P(u) exact to ~2^-60: error
+// <= 0.51 ulp against the exact root of 1 + u, <= 0.76 ulp against the
+// reference's own expression, which rounds 1 + u first.  GR4J's percolation
+// (gr4j_model.py:117) has u = (4/9 S/x1)**4 <= 0.0391 whenever the production
+// store is not above its capacity, which the model's equations maintain.
+// CONSTS: 0 coefficients in SGPR pairs, 1 in VGPR pairs, 2 fetched from
+// constant memory at the point of use (see fast_tanh_parts' JIT_CONST).
+#define FP_R4_UMAX 0.0416
+#define FP_R4_C0 -0.25
+#define FP_R4_C1 0.15624999999996197
+#define FP_R4_C2 -0.11718749998077582
+#define FP_R4_C3 0.0952148400420375
+#define FP_R4_C4 -0.08093226527063785
+#define FP_R4_C5 0.0707978435375625
+#define FP_R4_C6 -0.06270408403556514
+#define FP_R4_C7 0.04930569258051168
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __constant__ const double FP_R4_TABLE[8] = {
+    FP_R4_C7, FP_R4_C6, FP_R4_C5, FP_R4_C4,
+    FP_R4_C3, FP_R4_C2, FP_R4_C1, FP_R4_C0};
+#endif
+
+template <int CONSTS = 0>
+FP_FN double inv_fourth_root_1p_small(double u)
+{
+    double p;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (CONSTS == 2) {
+        fp_cptr_t c = (fp_cptr_t)FP_R4_TABLE;
+        asm volatile("" : "+s"(c));   // keeps the load inside the time loop
+        p = c[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) p = FP_FMA_C(p, u, c[j]);
+    } else if constexpr (CONSTS == 1) {
+        p = FP_R4_C7;
+        p = FP_FMA_CV(p, u, FP_R4_C6);
+        p = FP_FMA_CV(p, u, FP_R4_C5);
+        p = FP_FMA_CV(p, u, FP_R4_C4);
+        p = FP_FMA_CV(p, u, FP_R4_C3);
+        p = FP_FMA_CV(p, u, FP_R4_C2);
+        p = FP_FMA_CV(p, u, FP_R4_C1);
+        p = FP_FMA_CV(p, u, FP_R4_C0);
+    } else
+#endif
+    {
+        p = FP_R4_C7;
+        p = FP_FMA_C(p, u, FP_R4_C6);
+        p = FP_FMA_C(p, u, FP_R4_C5);
+        p = FP_FMA_C(p, u, FP_R4_C4);
+        p = FP_FMA_C(p, u, FP_R4_C3);
+        p = FP_FMA_C(p, u, FP_R4_C2);
+        p = FP_FMA_C(p, u, FP_R4_C1);
+        p = FP_FMA_C(p, u, FP_R4_C0);
+    }
+    return FP_FMA(u, p, 1.0);
 }
 
 // n / d for a finite normal d in [1, 2^200] and finite n with |n| < 2^800:

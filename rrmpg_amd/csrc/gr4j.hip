@@ -69,11 +69,15 @@ __global__ void gr4j_scan_x4(const double *__restrict__ params, int64_t N,
     }
 }
 
+// Minimum waves per SIMD the register allocation is held to: 5 (<= 96 VGPRs)
+// for the 3+7-register tier -- the polynomial's coefficients sit in VGPR pairs
+// there (gr4j_core.h), and above four waves the fp64 issue rate no longer
+// depends on the count (profiles/r02_valu_cost.txt) --, 6 for the LDS tier.
 template <class UH>
 constexpr int gr4j_min_waves()
 {
-    return (std::is_same<UH, UhRegs<3>>::value ||
-            std::is_same<UH, UhLds>::value) ? 6 : 2;
+    return std::is_same<UH, UhRegs<3>>::value ? 5
+           : std::is_same<UH, UhLds>::value   ? 6 : 2;
 }
 
 template <class UH, bool Q, bool S, bool E>

@@ -355,6 +355,26 @@ static inline void gr4j_for_each_tier(F &&f)
 // 1 - result), NaN propagates.
 // GUARD_BY_VOTE = false: the branch-free clamped form (UhRegs<10> kernels, see
 // pow_3_5 below).
+// Percolation root as a polynomial (fastmath.h inv_fourth_root_1p_small):
+// where its eight coefficients live.  Plain GR4J kernels with the hydrographs
+// in 3+7 or 5+11 registers have VGPRs to spare (and no SGPRs: 104 of 106
+// taken): VGPR pairs; everything else -- the LDS tier, held to 80 VGPRs, and
+// the fused snow kernels, short of both -- fetches them from constant memory
+// at the point of use.  UhRegs<10> kernels keep the Newton form (measured: no
+// difference at two waves per SIMD).  A/B in profiles/README.md.
+#ifndef RR_R4_POLY
+#define RR_R4_POLY 1        // measurement switch: 0 = Newton form everywhere
+#endif
+template <class UH>
+constexpr bool RR_R4_POLY_ENABLED =
+    RR_R4_POLY != 0 && !std::is_same<UH, UhRegs<10>>::value;
+template <class UH, bool JIT_CONST>
+constexpr int gr4j_r4_consts()
+{
+    return (!JIT_CONST && (std::is_same<UH, UhRegs<3>>::value ||
+                           std::is_same<UH, UhRegs<5>>::value)) ? 1 : 2;
+}
+
 template <bool GUARD_BY_VOTE = true>
 __device__ __forceinline__ double gr4j_inv_fourth_root(double b)
 {
@@ -490,8 +510,23 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1, P.x1_m);
     const double v2 = v * v;
     constexpr bool votes = !std::is_same<UH, UhRegs<10>>::value;
-    const double perc =
-        sn * (1 - gr4j_inv_fourth_root<votes>(1 + v2 * v2));
+    // v <= 4/9 while the store is within its capacity: the root of 1 + v**4
+    // is then a degree-7 polynomial in v**4 (fastmath.h); a wave with a lane
+    // beyond that takes the general form for those lanes
+    const double u = v2 * v2;
+    double root;
+    if constexpr (RR_R4_POLY_ENABLED<UH>) {
+        root = inv_fourth_root_1p_small<gr4j_r4_consts<UH, JIT_CONST>()>(u);
+        const lanemask_t small = RR_LANES(u <= FP_R4_UMAX);
+        if (RR_ANY_OUTSIDE(small)) {
+            asm volatile("");                       // keep this a branch
+            const double general = gr4j_inv_fourth_root<votes>(1 + u);
+            root = (u <= FP_R4_UMAX) ? root : general;
+        }
+    } else {
+        root = gr4j_inv_fourth_root<votes>(1 + u);
+    }
+    const double perc = sn * (1 - root);
     sn = sn - perc;                                             // :120
     const double p_r = perc + excess;                           // :123
     const double p_r_uh1 = 0.9 * p_r;                           // :126-127

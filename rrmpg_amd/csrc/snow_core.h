@@ -21,7 +21,11 @@ int rr_gr4j_plan_async(const double *params, int64_t N, int stride,
 // snow routine from ~17 to 6-8 vector instructions per layer-day, bit for
 // bit.  Decided per layer (two scalar branches per layer and day) every snow
 // kernel got 10-19 % SLOWER; decided once per day (all layers frost / all
-// bare) nothing was gained either.  profiles/README.md.)
+// bare) nothing was gained either.  Nor does it pay to take the wave-uniform
+// `temp > 0` off the vector unit: as w = (temp > 0) ? 0.0 : NaN formed by four
+// scalar integer instructions, with `e == w` as the whole melt condition, one
+// vector compare per layer and day is saved and every snow kernel is 1-2 %
+// slower.  profiles/README.md.)
 static __host__ __device__ constexpr int cema_record_len(int L, bool with_etp)
 {
     return 3 * L + (with_etp ? 1 : 0) + 1;
