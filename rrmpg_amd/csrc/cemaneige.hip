@@ -180,6 +180,7 @@ struct CoupledOut {
 };
 typedef const CoupledOut __attribute__((address_space(4))) *coupled_out_ptr_t;
 
+typedef const double __attribute__((address_space(4))) *cema_rec_ptr_t;
 template <int L, class UH>
 __global__ __launch_bounds__(RR_BLOCK, (coupled_min_waves<L, UH>())) void
 cemaneigegr4j_kernel(
@@ -212,16 +213,36 @@ cemaneigegr4j_kernel(
     double acc = 0.0;
     const bool we = sse != nullptr;
     constexpr int D = cema_record_len(L, true);
+    // The day's record (wave-uniform, SGPRs).  The snow routine is its only
+    // reader apart from the two trailing slots, so the NEXT day's record is
+    // requested into the registers that fall free after it -- in the middle
+    // of the GR4J day, once that step's constant tables are through (they
+    // need the SGPRs) -- and arrives while the rest of the day runs.
+    // Requested at the top of the day, every wave would sit out the
+    // scalar-load latency once per day, which a sweep of one or two waves per
+    // SIMD cannot hide (measured: 65k sets 16.2 -> 14.0 ms, 125k 18.3 -> 17.9,
+    // a million unchanged; the hysteresis / ice kernels of snownext.hip,
+    // shorter of SGPRs still, lose with it and keep the load at the top).
+    const cema_rec_ptr_t drec = (cema_rec_ptr_t)days;
+    double day[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) day[k] = drec[k];
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
     auto one_day = [&](auto first, int64_t t) {
-        double day[D];          // by value: one wide scalar load per day
-#pragma unroll
-        for (int k = 0; k < D; ++k) day[k] = days[t * D + k];
         const double liquid = cema_day<L, decltype(first)::value>(
             day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG, omc,
             Kf, G, eTG);
-        const double q = gr4j_step<UH, true>(P, s, r, uh, liquid, day[3 * L]);
+        const double etp_t = day[3 * L], qobs_t = day[D - 1];
+        auto fetch_next = [&]() {
+            // (day T-1 requests the spare record behind the last one)
+            cema_rec_ptr_t nx = drec + (t + 1) * D;
+            asm volatile("" : "+s"(nx));     // keeps the loads at this spot
+#pragma unroll
+            for (int k = 0; k < D; ++k) day[k] = nx[k];
+        };
+        const double q =
+            gr4j_step<UH, true>(P, s, r, uh, liquid, etp_t, fetch_next);
         if (active && (wq | ws)) {
             coupled_out_ptr_t po =
                 (coupled_out_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -242,7 +263,7 @@ cemaneigegr4j_kernel(
             }
         }
         if (we) {
-            const double d = day[D - 1] - q;   // the day's observation
+            const double d = qobs_t - q;   // the day's observation
             acc = __builtin_fma(d, d, acc);
         }
     };

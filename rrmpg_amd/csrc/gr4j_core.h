@@ -449,10 +449,17 @@ __device__ __attribute__((noinline)) double gr4j_store_change_reference(
 // `net_m`: lanes whose net is a valid numerator of the 3-FMA quotient
 // (gr4j_num_mask; the plain GR4J kernel's pre-pass knows it per day).
 // JIT_CONST: see fastmath.h fast_tanh_parts (set by the fused snow kernels).
-template <class UH, bool JIT_CONST = false>
+// MID: called once in the middle of the day, after the last of the step's
+// constant-table loads (tanh, percolation polynomial) -- where the fused snow
+// kernels request the next day's forcing record (cemaneige.hip).
+struct Gr4jNoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <class UH, bool JIT_CONST = false, class MID = Gr4jNoHook>
 __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
                                                 double &r, UH &uh, double net,
-                                                bool wet, lanemask_t net_m)
+                                                bool wet, lanemask_t net_m,
+                                                MID &&mid = MID())
 {
     // tanh(net/x1) = E / D (fastmath.h: E = expm1(2a)/2, D = E + 1); its
     // quotient is folded into the store update's own:
@@ -527,6 +534,7 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
         root = gr4j_inv_fourth_root<votes>(1 + u);
     }
     const double perc = sn * (1 - root);
+    mid();
     sn = sn - perc;                                             // :120
     const double p_r = perc + excess;                           // :123
     const double p_r_uh1 = 0.9 * p_r;                           // :126-127
@@ -549,13 +557,14 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     return q_r + q_d;                                           // :154
 }
 
-template <class UH, bool JIT_CONST = false>
+template <class UH, bool JIT_CONST = false, class MID = Gr4jNoHook>
 __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
                                             double &r, UH &uh, double prec,
-                                            double etp)
+                                            double etp, MID &&mid = MID())
 {
     const bool wet = prec >= etp;                               // :89
     const double net = wet ? prec - etp : etp - prec;           // :90, :102
     return gr4j_step_net<UH, JIT_CONST>(P, s, r, uh, net, wet,
-                                        gr4j_num_mask(net));
+                                        gr4j_num_mask(net),
+                                        static_cast<MID &&>(mid));
 }

@@ -43,7 +43,10 @@ static inline size_t cema_days_bytes(int64_t T, int64_t L, bool with_etp)
 {
     if (T < 1) T = 1;
     if (L < 1) L = 1;
-    return rr_align256((size_t)T * (size_t)cema_record_len((int)L, with_etp) * 8);
+    // + one spare record: the fused kernels request the next day's record in
+    // the middle of a day, the last day included
+    return rr_align256((size_t)(T + 1) *
+                       (size_t)cema_record_len((int)L, with_etp) * 8);
 }
 
 // per-layer constants: G_tresh[L], Psolannual[L], the CemaGt table [L] the
