@@ -85,6 +85,10 @@ def parse_args():
     ap.add_argument("--hbv-variant", type=int, default=-1,
                     help="measurement hook: pin the HBV-Edu kernel variant "
                          "(rr_debug_set_option RR_OPT_HBV_VARIANT)")
+    ap.add_argument("--fused-variant", type=int, default=0,
+                    help="measurement hook: pin the CemaneigeGR4J kernel "
+                         "variant (RR_OPT_FUSED_VARIANT: 1 many-waves, "
+                         "2 small-sweep)")
     ap.add_argument("--no-parity-spot", action="store_true")
     return ap.parse_args()
 
@@ -372,6 +376,10 @@ def main():
     if args.hbv_variant >= 0:
         _lib.check(_lib.load().rr_debug_set_option(
             _lib.OPTIONS["hbv_variant"], args.hbv_variant),
+            "rr_debug_set_option")
+    if args.fused_variant > 0:
+        _lib.check(_lib.load().rr_debug_set_option(
+            _lib.OPTIONS["fused_variant"], args.fused_variant),
             "rr_debug_set_option")
 
     # this rank's block of the parameter-set axis

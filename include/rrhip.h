@@ -105,7 +105,11 @@ int rr_release_cached_memory(void);
 #define RR_OPT_GATHER_THREADS  4 /* 0 (default) = 12 (or fewer cores); > 0:
                                   * host threads scattering the staging ring
                                   * of a large gather into the caller's array */
-#define RR_OPT_COUNT_          5
+#define RR_OPT_FUSED_VARIANT   5 /* CemaneigeGR4J kernel: 0 by sweep size
+                                  * (default); 1 the many-waves kernel; 2 the
+                                  * small-sweep kernel (constants and melt
+                                  * thresholds in VGPRs) wherever it exists  */
+#define RR_OPT_COUNT_          6
 int rr_debug_set_option(int option, int64_t value);
 int64_t rr_debug_get_option(int option);
 

@@ -161,11 +161,24 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
 // Small configurations (<= 5 layers, unit hydrographs in 3+7 registers or in
 // LDS) are held at 128 registers = 4 waves per SIMD: a handful of spills cost
 // less than the lost wave (137 -> 130 ms at L = 5).
-template <int L, class UH>
+template <int L, class UH, bool SMALL = false>
 constexpr int coupled_min_waves()
 {
-    return (L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
-                       std::is_same<UH, UhLds>::value)) ? 4 : 2;
+    return (!SMALL && L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
+                                 std::is_same<UH, UhLds>::value)) ? 4 : 2;
+}
+
+// SMALL variant of the fused kernel, for sweeps of at most two waves per SIMD
+// (<= 131,072 sets: one GPU's shard of BASELINE configs[3], and every `fit`
+// population): occupancy is not a concern there and exposed latencies are,
+// so the polynomial constants and the melt thresholds sit in VGPRs and the
+// only scalar load left in the time loop is the prefetched day record.
+// Instantiated where the register file allows it.
+template <int L, class UH>
+constexpr bool coupled_has_small()
+{
+    return L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
+                      std::is_same<UH, UhRegs<5>>::value);
 }
 
 // Output pointers.  Passed as the FIRST kernel argument and never touched by
@@ -181,8 +194,8 @@ struct CoupledOut {
 typedef const CoupledOut __attribute__((address_space(4))) *coupled_out_ptr_t;
 
 typedef const double __attribute__((address_space(4))) *cema_rec_ptr_t;
-template <int L, class UH>
-__global__ __launch_bounds__(RR_BLOCK, (coupled_min_waves<L, UH>())) void
+template <int L, class UH, bool SMALL = false>
+__global__ __launch_bounds__(RR_BLOCK, (coupled_min_waves<L, UH, SMALL>())) void
 cemaneigegr4j_kernel(
     CoupledOut /* read through the kernarg segment, see above */,
     const double *__restrict__ days, const double *__restrict__ gtresh,
@@ -223,6 +236,9 @@ cemaneigegr4j_kernel(
     // SIMD cannot hide (measured: 65k sets 16.2 -> 14.0 ms, 125k 18.3 -> 17.9,
     // a million unchanged; the hysteresis / ice kernels of snownext.hip,
     // shorter of SGPRs still, lose with it and keep the load at the top).
+    CemaGtRegs<L> gt_regs;
+    if constexpr (SMALL) cema_gt_to_regs<L>(gt_tab, gt_regs);
+    constexpr int CONSTS = SMALL ? GR4J_CONSTS_VGPR : GR4J_CONSTS_JIT;
     const cema_rec_ptr_t drec = (cema_rec_ptr_t)days;
     double day[D];
 #pragma unroll
@@ -230,9 +246,9 @@ cemaneigegr4j_kernel(
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
     auto one_day = [&](auto first, int64_t t) {
-        const double liquid = cema_day<L, decltype(first)::value>(
+        const double liquid = cema_day<L, decltype(first)::value, SMALL>(
             day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG, omc,
-            Kf, G, eTG);
+            Kf, G, eTG, &gt_regs);
         const double etp_t = day[3 * L], qobs_t = day[D - 1];
         auto fetch_next = [&]() {
             // (day T-1 requests the spare record behind the last one)
@@ -242,7 +258,7 @@ cemaneigegr4j_kernel(
             for (int k = 0; k < D; ++k) day[k] = nx[k];
         };
         const double q =
-            gr4j_step<UH, true>(P, s, r, uh, liquid, etp_t, fetch_next);
+            gr4j_step<UH, CONSTS>(P, s, r, uh, liquid, etp_t, fetch_next);
         if (active && (wq | ws)) {
             coupled_out_ptr_t po =
                 (coupled_out_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -365,7 +381,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
                                 ws ? G_out + (t * L) * ld + i : nullptr,
                                 ws ? eTG_out + (t * L) * ld + i : nullptr, ld,
                                 ws && active);
-        if constexpr (coupled) q = gr4j_step<UH, true>(P, s, r, uh, q, day[3 * L]);
+        if constexpr (coupled) q = gr4j_step<UH, GR4J_CONSTS_JIT>(P, s, r, uh, q, day[3 * L]);
         if (active) {
             if (wq) qsim[t * ld + i] = q;
             if (coupled && ws) {
@@ -640,14 +656,30 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
         return RR_OK;
     }
     const CoupledOut out = {qsim, G, eTG, s_store, r_store, ld};
+    // at most two waves per SIMD: the small-sweep variant where there is one
+    // (1024 SIMDs on an MI355X)
+    const bool small = (int64_t)grid.x <= 2048 &&
+                       rr_option(RR_OPT_FUSED_VARIANT) != 1;
     dispatch_layers((int)L, [&](auto LL) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
-            cemaneigegr4j_kernel<LL.value, UH>
-                <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
-                   st>>>(out, days, gt, T, snow_pack_init, thermal_state_init,
-                         s_init, r_init, params, N, d_plan, force_lds,
-                         qsim != nullptr, G != nullptr, qo, sse);
+            const size_t lds = std::is_same<UH, UhLds>::value ? lds_bytes : 0;
+            if constexpr (coupled_has_small<LL.value, UH>()) {
+                if (small || rr_option(RR_OPT_FUSED_VARIANT) == 2) {
+                    cemaneigegr4j_kernel<LL.value, UH, true>
+                        <<<grid, block, lds, st>>>(
+                            out, days, gt, T, snow_pack_init,
+                            thermal_state_init, s_init, r_init, params, N,
+                            d_plan, force_lds, qsim != nullptr, G != nullptr,
+                            qo, sse);
+                    return;
+                }
+            }
+            cemaneigegr4j_kernel<LL.value, UH, false>
+                <<<grid, block, lds, st>>>(
+                    out, days, gt, T, snow_pack_init, thermal_state_init,
+                    s_init, r_init, params, N, d_plan, force_lds,
+                    qsim != nullptr, G != nullptr, qo, sse);
         });
     });
     RR_HIP(hipGetLastError());

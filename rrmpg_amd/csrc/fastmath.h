@@ -346,7 +346,10 @@ static __device__ __constant__ const double FP_TANH_TABLE[16] = {
     1.90821492927058770002e-10, 0.0, 0.0};
 #endif
 
-template <bool JIT_CONST = false>
+// CONSTS: where the 14 constants live -- 0 SGPR pairs, 1 VGPR pairs (sweeps of
+// at most two waves per SIMD: registers to spare, and no scalar load whose
+// latency nobody hides), 2 constant memory at the point of use (JIT_CONST).
+template <int CONSTS = 0>
 FP_FN void fast_tanh_parts(double a, double &num, double &den)
 {
     const double ax = __builtin_fabs(a);
@@ -354,7 +357,7 @@ FP_FN void fast_tanh_parts(double a, double &num, double &den)
     const double y = 2.0 * x;
     double p, n;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (JIT_CONST) {
+    if constexpr (CONSTS == 2) {
         fp_cptr_t c = (fp_cptr_t)FP_TANH_TABLE;
         asm volatile("" : "+s"(c));   // keeps the loads inside the time loop
         n = FP_RINT(y * c[11]);
@@ -370,16 +373,19 @@ FP_FN void fast_tanh_parts(double a, double &num, double &den)
         const double r = FP_FMA(-n, 1.90821492927058770002e-10,
                                 FP_FMA(-n, 6.93147180369123816490e-01, y));
         double q = 2.0914679376583935e-09;           // see FP_TANH_TABLE
-        q = FP_FMA_C(q, r, 2.510520637395701e-08);
-        q = FP_FMA_C(q, r, 2.7557273661348637e-07);
-        q = FP_FMA_C(q, r, 2.7557255425746435e-06);
-        q = FP_FMA_C(q, r, 2.4801587325533363e-05);
-        q = FP_FMA_C(q, r, 0.00019841269874800493);
-        q = FP_FMA_C(q, r, 0.0013888888888883752);
-        q = FP_FMA_C(q, r, 0.008333333333326141);
-        q = FP_FMA_C(q, r, 0.04166666666666667);
-        q = FP_FMA_C(q, r, 0.1666666666666667);
-        q = FP_FMA_C(q, r, 0.5);
+#define FP_TANH_STEP(c) \
+    q = (CONSTS == 1) ? FP_FMA_CV(q, r, (c)) : FP_FMA_C(q, r, (c))
+        FP_TANH_STEP(2.510520637395701e-08);
+        FP_TANH_STEP(2.7557273661348637e-07);
+        FP_TANH_STEP(2.7557255425746435e-06);
+        FP_TANH_STEP(2.4801587325533363e-05);
+        FP_TANH_STEP(0.00019841269874800493);
+        FP_TANH_STEP(0.0013888888888883752);
+        FP_TANH_STEP(0.008333333333326141);
+        FP_TANH_STEP(0.04166666666666667);
+        FP_TANH_STEP(0.1666666666666667);
+        FP_TANH_STEP(0.5);
+#undef FP_TANH_STEP
         p = FP_FMA(r * r, q, r);                     // expm1(r)
     }
     // H = expm1(2|a|) / 2 and H + 1: tanh = H / (H + 1).  (Halved so that a

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
             f.net = nx->net; f.qobs = nx->qobs; f.wet = nx->wet;
             f.net_ok = nx->net_ok;
         };
-        const double q = gr4j_step_net<UH, false>(P, s, r, uh, net, wet, net_m,
-                                                  fetch_next);
+        const double q = gr4j_step_net<UH, GR4J_CONSTS_SGPR>(
+            P, s, r, uh, net, wet, net_m, fetch_next);
         if (Q) rr_store_row(qsim + row, row_bytes, lane_off, q);
         if (S) {
             rr_store_row(s_store + row, row_bytes, lane_off, s);

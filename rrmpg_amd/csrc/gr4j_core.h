@@ -362,17 +362,25 @@ static inline void gr4j_for_each_tier(F &&f)
 // the fused snow kernels, short of both -- fetches them from constant memory
 // at the point of use.  UhRegs<10> kernels keep the Newton form (measured: no
 // difference at two waves per SIMD).  A/B in profiles/README.md.
+// Where a step's polynomial constants live (fastmath.h fast_tanh_parts):
+// the plain GR4J kernels keep the tanh's in SGPRs; the fused snow kernels are
+// short of SGPRs and fetch them from constant memory at the point of use;
+// their small-sweep variants (at most two waves per SIMD) hold them in VGPRs.
+enum { GR4J_CONSTS_SGPR = 0, GR4J_CONSTS_VGPR = 1, GR4J_CONSTS_JIT = 2 };
+
 #ifndef RR_R4_POLY
 #define RR_R4_POLY 1        // measurement switch: 0 = Newton form everywhere
 #endif
 template <class UH>
 constexpr bool RR_R4_POLY_ENABLED =
     RR_R4_POLY != 0 && !std::is_same<UH, UhRegs<10>>::value;
-template <class UH, bool JIT_CONST>
+template <class UH, int CONSTS>
 constexpr int gr4j_r4_consts()
 {
-    return (!JIT_CONST && (std::is_same<UH, UhRegs<3>>::value ||
-                           std::is_same<UH, UhRegs<5>>::value)) ? 1 : 2;
+    return (CONSTS == GR4J_CONSTS_VGPR ||
+            (CONSTS == GR4J_CONSTS_SGPR &&
+             (std::is_same<UH, UhRegs<3>>::value ||
+              std::is_same<UH, UhRegs<5>>::value))) ? 1 : 2;
 }
 
 template <bool GUARD_BY_VOTE = true>
@@ -448,14 +456,14 @@ __device__ __attribute__((noinline)) double gr4j_store_change_reference(
 // pre-pass, wave-uniform; the coupled kernels compute them per lane.)
 // `net_m`: lanes whose net is a valid numerator of the 3-FMA quotient
 // (gr4j_num_mask; the plain GR4J kernel's pre-pass knows it per day).
-// JIT_CONST: see fastmath.h fast_tanh_parts (set by the fused snow kernels).
+// CONSTS: GR4J_CONSTS_* above.
 // MID: called once in the middle of the day, after the last of the step's
 // constant-table loads (tanh, percolation polynomial) -- where the fused snow
 // kernels request the next day's forcing record (cemaneige.hip).
 struct Gr4jNoHook {
     __device__ __forceinline__ void operator()() const {}
 };
-template <class UH, bool JIT_CONST = false, class MID = Gr4jNoHook>
+template <class UH, int CONSTS = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook>
 __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
                                                 double &r, UH &uh, double net,
                                                 bool wet, lanemask_t net_m,
@@ -466,7 +474,7 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     //     c*th / (1 + k*th) == c*E / (D + k*E),
     // one division per day instead of two.
     double E, D;
-    fast_tanh_parts<JIT_CONST>(
+    fast_tanh_parts<CONSTS>(
         div_by_invariant_m(net, net_m, P.inv_x1, P.x1_m, GR4J_NUM_HI), E, D);
     // One vote covers the 3-FMA quotient s/x1 and the folded form: with
     // s in {0} u [2^-900, 2^196) and |x1| in [2^-100, 2^100] (invdiv.h) the
@@ -523,7 +531,7 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     const double u = v2 * v2;
     double root;
     if constexpr (RR_R4_POLY_ENABLED<UH>) {
-        root = inv_fourth_root_1p_small<gr4j_r4_consts<UH, JIT_CONST>()>(u);
+        root = inv_fourth_root_1p_small<gr4j_r4_consts<UH, CONSTS>()>(u);
         const lanemask_t small = RR_LANES(u <= FP_R4_UMAX);
         if (RR_ANY_OUTSIDE(small)) {
             asm volatile("");                       // keep this a branch
@@ -557,14 +565,14 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     return q_r + q_d;                                           // :154
 }
 
-template <class UH, bool JIT_CONST = false, class MID = Gr4jNoHook>
+template <class UH, int CONSTS = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook>
 __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
                                             double &r, UH &uh, double prec,
                                             double etp, MID &&mid = MID())
 {
     const bool wet = prec >= etp;                               // :89
     const double net = wet ? prec - etp : etp - prec;           // :90, :102
-    return gr4j_step_net<UH, JIT_CONST>(P, s, r, uh, net, wet,
+    return gr4j_step_net<UH, CONSTS>(P, s, r, uh, net, wet,
                                         gr4j_num_mask(net),
                                         static_cast<MID &&>(mid));
 }

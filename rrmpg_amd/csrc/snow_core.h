@@ -97,11 +97,33 @@ __device__ __forceinline__ double cema_layer_mean(double c)
 // run-time flag it costs two selects per state and layer on EVERY day).
 // gt_tab: the CemaGt table; gt_ok: lanes (all or none) for which every
 // threshold suits the 3-FMA quotient.
-template <int L, bool FIRST>
+// GT_REGS: the thresholds come from `gt_regs` ({G_tresh, 1/G_tresh} per layer
+// in VGPR pairs, cema_gt_to_regs) instead of a scalar load from the table at
+// the point of use -- the small-sweep kernels, which have registers to spare
+// and nobody to hide a load's latency behind.
+template <int L>
+struct CemaGtRegs { double gt[L], rgt[L]; };
+
+template <int L>
+__device__ __forceinline__ void cema_gt_to_regs(cema_gt_ptr_t gt_tab,
+                                                CemaGtRegs<L> &g)
+{
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        g.gt[l] = gt_tab[l].gt;
+        g.rgt[l] = gt_tab[l].rgt;
+        // (pins them in VGPRs: as uniform values hipcc would hold them in
+        // SGPRs, which these kernels do not have)
+        asm volatile("" : "+v"(g.gt[l]), "+v"(g.rgt[l]));
+    }
+}
+
+template <int L, bool FIRST, bool GT_REGS = false>
 __device__ __forceinline__ double cema_day(
     const double *__restrict__ day, cema_gt_ptr_t gt_tab, lanemask_t gt_ok,
     double snow_pack_init, double thermal_state_init, double CTG,
-    double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L])
+    double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L],
+    const CemaGtRegs<L> *gt_regs = nullptr)
 {
     double c = 0.0;
 #pragma unroll
@@ -133,15 +155,20 @@ __device__ __forceinline__ double cema_day(
             // G / G_tresh: the threshold is fixed for the whole run, so the
             // quotient is the 3-instruction correctly rounded form of
             // common.h
-            cema_gt_ptr_t pg = gt_tab + l;
-            asm volatile("" : "+s"(pg));     // keeps the load inside the branch
             InvDivisor inv_gt;
-            inv_gt.b = pg->gt;
-            inv_gt.rb = pg->rgt;
             inv_gt.ok = gt_ok != 0;
-            // (both fields now: one s_load_dwordx4 and one wait, not a
-            // second load + wait where the reciprocal is first used)
-            asm volatile("" : : "s"(inv_gt.b), "s"(inv_gt.rb));
+            if constexpr (GT_REGS) {
+                inv_gt.b = gt_regs->gt[l];
+                inv_gt.rb = gt_regs->rgt[l];
+            } else {
+                cema_gt_ptr_t pg = gt_tab + l;
+                asm volatile("" : "+s"(pg)); // keeps the load inside the branch
+                inv_gt.b = pg->gt;
+                inv_gt.rb = pg->rgt;
+                // (both fields now: one s_load_dwordx4 and one wait, not a
+                // second load + wait where the reciprocal is first used)
+                asm volatile("" : : "s"(inv_gt.b), "s"(inv_gt.rb));
+            }
             const double ratio =                           // :109-112
                 (g < inv_gt.b)
                     ? div_by_invariant_m(g, gr4j_num_mask(g), inv_gt, gt_ok)

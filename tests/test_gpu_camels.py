@@ -40,7 +40,7 @@ def test_gr4j_on_camels_basin_vs_oracle(basin, oracle):
         assert rel_err(a, b, floor=1e-9) < RTOL
 
 
-def test_cemaneigegr4j_on_camels_basin_vs_oracle(basin, oracle):
+def test_cemaneigegr4j_on_camels_basin_vs_oracle(basin, oracle, fused_variant):
     from rrmpg_amd.models import CemaneigeGR4J
     from rrmpg_amd.models import cemaneige_utils as cu
     alts = [310., 420., 510., 640., 900.]

@@ -207,3 +207,29 @@ def test_snow_models_fuzz(models, oracle):
                        _records(models.Cemaneige, flat), True, True, None)
     for a, b, n in zip(out, ref, ["outflow", "G", "eTG"]):
         _same(a, b, "cemaneige " + n)
+
+
+def test_cemaneigegr4j_fuzz(models, oracle, fused_variant):
+    """The fused kernel -- both of its variants -- on wild parameter blocks
+    (special values, extreme ranges) with all storages, plus a ragged number
+    of sets so that the tail wave is exercised."""
+    from rrmpg_amd.models import cemaneigegr4j as fmod
+    h = golden("syn_cemaneigehystgr4j")
+    rng = np.random.default_rng(103 + 1000 * SEED)
+    t = 500
+    layers = tuple(h[k][:t] for k in ("layer_prec", "layer_mean",
+                                      "frac_solid", "etp"))
+    lo = np.array([0, 0, 10, -5, 20, 0.5])
+    hi = np.array([1, 10, 1200, 3, 5000, 2.9])
+    flat = _wild_params(rng, lo, hi, 331)
+    bad = ~((flat[:, 5] > 0) & (flat[:, 5] <= 20))
+    flat[bad, 5] = rng.uniform(0.2, 9.9, bad.sum())
+    inits = (3.0, -0.2, 0.4, 0.5)
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_cemaneigegr4j(layers[0], layers[1], layers[3],
+                                            layers[2], inits, flat,
+                                            return_storages=True, nthreads=8)
+    out, _ = fmod._run(layers, inits, _records(models.CemaneigeGR4J, flat),
+                       True, True, None)
+    for a, b, n in zip(out, ref, ["qsim", "G", "eTG", "s_store", "r_store"]):
+        _same(a, b, "cemaneigegr4j " + n)

@@ -336,7 +336,7 @@ def test_cemaneige_bit_exact_vs_oracle(models, oracle):
 
 
 # --------------------------------------------------------- CemaneigeGR4J
-def test_cemaneigegr4j_kat_excel(models):
+def test_cemaneigegr4j_kat_excel(models, fused_variant):
     g = golden("kat_cemaneigegr4j")
     m = models.CemaneigeGR4J(params=dict(zip(models.CemaneigeGR4J._param_list,
                                              g["params"].tolist())))
@@ -348,7 +348,7 @@ def test_cemaneigegr4j_kat_excel(models):
     assert rel_err(qsim, g["ref_qsim"]) < RTOL
 
 
-def test_cemaneigegr4j_golden_and_oracle(models, oracle):
+def test_cemaneigegr4j_golden_and_oracle(models, oracle, fused_variant):
     g = golden("syn_cemaneigegr4j")
     p = golden("syn_cemaneige_prep")
     from rrmpg_amd.utils import synthetic as syn

@@ -369,6 +369,8 @@ def test_debug_options_and_cache_release_need_no_gpu():
         assert lib.rr_debug_get_option(opt["max_block_cols"]) == 0
     assert lib.rr_debug_get_option(opt["hbv_variant"]) == -1
     assert lib.rr_debug_set_option(opt["hbv_variant"], 7) == -4    # RR_E_PARAM
+    assert lib.rr_debug_get_option(opt["fused_variant"]) == 0
+    assert lib.rr_debug_set_option(opt["fused_variant"], 3) == -4
     assert b"does not take" in lib.rr_last_error()
     assert lib.rr_debug_set_option(99, 0) == -4
     assert lib.rr_debug_get_option(99) == -2 ** 63
