@@ -125,9 +125,12 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     double acc = 0.0;
     const bool wq = outflow != nullptr, ws = G_out != nullptr,
                we = sse != nullptr;
-    // one day; `first` (a std::bool_constant) marks day 0, which is peeled
+    const int lane_off = threadIdx.x * 8;
+    const int64_t first = (int64_t)blockIdx.x * RR_BLOCK;
+    const unsigned row_bytes = rr_row_bytes(first, N);
+    // one day; `is_first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
-    auto one_day = [&](auto first, int64_t t) {
+    auto one_day = [&](auto is_first, int64_t t) {
         // the whole day record by value, up front: one wide scalar load and
         // one wait per day (read through the pointer, hipcc fetches every
         // field at its use site with its own s_load + wait)
@@ -135,23 +138,33 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
         double rec[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) rec[k] = days[t * D + k];
-        const double q = cema_day<L, decltype(first)::value>(
+        const double q = cema_day<L, decltype(is_first)::value>(
             rec, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG, omc,
             Kf, G, eTG);
-        if (active) {
-            if (wq) outflow[t * ld + i] = q;
-            if (ws) {
+        // output rows: wave-uniform base + lane offset (common.h
+        // rr_store_row): no per-lane address arithmetic, no exec masking of
+        // the tail wave, and -- unlike eleven strength-reduced row pointers --
+        // nothing to advance on the days and in the modes that store nothing
+        if (wq) rr_store_row(outflow + first + t * ld, row_bytes, lane_off, q);
+        if (ws) {
+            // (opaque day index: the addresses are formed here, on the days
+            // and in the mode that stores, instead of as eleven induction
+            // pointers advanced every day)
+            int64_t ts = t;
+            asm volatile("" : "+s"(ts));
 #pragma unroll
-                for (int l = 0; l < L; ++l) {
-                    G_out[(t * L + l) * ld + i] = G[l];
-                    eTG_out[(t * L + l) * ld + i] = eTG[l];
-                }
+            for (int l = 0; l < L; ++l) {
+                const int64_t at = first + (ts * L + l) * ld;
+                rr_store_row(G_out + at, row_bytes, lane_off, G[l]);
+                rr_store_row(eTG_out + at, row_bytes, lane_off, eTG[l]);
             }
         }
-        if (we) {
-            const double d = rec[D - 1] - q;     // the day's observation
-            acc = __builtin_fma(d, d, acc);
-        }
+        // (unconditional: as `if (we)` on the run-time flag hipcc computes it
+        // anyway and then selects, two VOP3 selects a day; the record's
+        // observation slot holds 0 when no score is asked for, and the sum
+        // is only stored when one is)
+        const double d = rec[D - 1] - q;         // the day's observation
+        acc = __builtin_fma(d, d, acc);
     };
     one_day(std::true_type{}, 0);
     for (int64_t t = 1; t < T; ++t) one_day(std::false_type{}, t);
@@ -259,6 +272,9 @@ cemaneigegr4j_kernel(
         };
         const double q =
             gr4j_step<UH, CONSTS>(P, s, r, uh, liquid, etp_t, fetch_next);
+        // (per-lane addresses here: row stores through a buffer descriptor,
+        // as in cemaneige_kernel, cost this kernel 1.5-2.5 % -- four more
+        // SGPRs it does not have)
         if (active && (wq | ws)) {
             coupled_out_ptr_t po =
                 (coupled_out_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -278,6 +294,8 @@ cemaneigegr4j_kernel(
                 o.r_store[t * ld + i] = r;
             }
         }
+        // (as a branch on the run-time flag; unconditional -- as in
+        // cemaneige_kernel -- measured 0.5 % slower here)
         if (we) {
             const double d = qobs_t - q;   // the day's observation
             acc = __builtin_fma(d, d, acc);
