@@ -30,11 +30,15 @@
 // days: [T][D] doubles, D = cema_record_len(L, with_etp) (snow_core.h):
 //   [0,L) snow, [L,2L) rain, [2L,3L) mean_temp, [3L] etp, then the day's
 //   observation (cema_day_meta)
+// `insane`: counts the values that rule out the SANE form of the snow routine
+// (snow_core.h cema_day): a snowfall below zero, a temperature that is not
+// finite (or beyond 1e300).  Zeroed by rr_cema_prepass before the launch.
 __global__ void cema_pack(const double *__restrict__ prec,
                           const double *__restrict__ mean_temp,
                           const double *__restrict__ frac,
                           const double *__restrict__ etp, int64_t T, int L,
-                          int D, double *__restrict__ days)
+                          int D, double *__restrict__ days,
+                          unsigned long long *__restrict__ insane)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= T * L) return;
@@ -43,11 +47,13 @@ __global__ void cema_pack(const double *__restrict__ prec,
     const double p = prec[g];
     const double snow = p * frac[g];            // cemaneige_model.py:76
     const double rain = p - snow;               // :77
+    const double temp = mean_temp[g];
     double *d = days + t * D;
     d[l] = snow;
     d[L + l] = rain;
-    d[2 * L + l] = mean_temp[g];
+    d[2 * L + l] = temp;
     if (etp && l == 0) d[3 * L] = etp[t];
+    if (snow < 0.0 || !(fabs(temp) <= 1e300)) atomicAdd(insane, 1ull);
 }
 
 // The trailing slot of every record: the day's observed discharge
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const unsigned row_bytes = rr_row_bytes(first, N);
     // one day; `is_first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
-    auto one_day = [&](auto is_first, int64_t t) {
+    auto one_day = [&](auto is_first, auto sane, int64_t t) {
         // the whole day record by value, up front: one wide scalar load and
         // one wait per day (read through the pointer, hipcc fetches every
         // field at its use site with its own s_load + wait)
@@ -138,9 +144,10 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
         double rec[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) rec[k] = days[t * D + k];
-        const double q = cema_day<L, decltype(is_first)::value>(
-            rec, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG, omc,
-            Kf, G, eTG);
+        const double q =
+            cema_day<L, decltype(is_first)::value, false, decltype(sane)::value>(
+                rec, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
+                omc, Kf, G, eTG);
         // output rows: wave-uniform base + lane offset (common.h
         // rr_store_row): no per-lane address arithmetic, no exec masking of
         // the tail wave, and -- unlike eleven strength-reduced row pointers --
@@ -166,8 +173,17 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
         const double d = rec[D - 1] - q;         // the day's observation
         acc = __builtin_fma(d, d, acc);
     };
-    one_day(std::true_type{}, 0);
-    for (int64_t t = 1; t < T; ++t) one_day(std::false_type{}, t);
+    // the time loop exists twice: for waves that may use the SANE form of
+    // the snow routine (any sane run) and for the rest
+    if (cema_wave_is_sane(gtresh, L, CTG, snow_pack_init, thermal_state_init)) {
+        one_day(std::true_type{}, std::true_type{}, 0);
+        for (int64_t t = 1; t < T; ++t)
+            one_day(std::false_type{}, std::true_type{}, t);
+    } else {
+        one_day(std::true_type{}, std::false_type{}, 0);
+        for (int64_t t = 1; t < T; ++t)
+            one_day(std::false_type{}, std::false_type{}, t);
+    }
     if (we && active) sse[i] = acc;
 }
 
@@ -258,10 +274,11 @@ cemaneigegr4j_kernel(
     for (int k = 0; k < D; ++k) day[k] = drec[k];
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
-    auto one_day = [&](auto first, int64_t t) {
-        const double liquid = cema_day<L, decltype(first)::value, SMALL>(
-            day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG, omc,
-            Kf, G, eTG, &gt_regs);
+    auto one_day = [&](auto first, auto sane, int64_t t) {
+        const double liquid =
+            cema_day<L, decltype(first)::value, SMALL, decltype(sane)::value>(
+                day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
+                omc, Kf, G, eTG, &gt_regs);
         const double etp_t = day[3 * L], qobs_t = day[D - 1];
         auto fetch_next = [&]() {
             // (day T-1 requests the spare record behind the last one)
@@ -301,8 +318,16 @@ cemaneigegr4j_kernel(
             acc = __builtin_fma(d, d, acc);
         }
     };
-    one_day(std::true_type{}, 0);
-    for (int64_t t = 1; t < T; ++t) one_day(std::false_type{}, t);
+    // (two copies of the time loop, see cemaneige_kernel)
+    if (cema_wave_is_sane(gtresh, L, CTG, snow_pack_init, thermal_state_init)) {
+        one_day(std::true_type{}, std::true_type{}, 0);
+        for (int64_t t = 1; t < T; ++t)
+            one_day(std::false_type{}, std::true_type{}, t);
+    } else {
+        one_day(std::true_type{}, std::false_type{}, 0);
+        for (int64_t t = 1; t < T; ++t)
+            one_day(std::false_type{}, std::false_type{}, t);
+    }
     if (we && active) sse[i] = acc;
 }
 
@@ -437,9 +462,11 @@ int rr_cema_prepass(const double *prec, const double *mean_temp,
     const int D = cema_record_len(L, etp != nullptr);
     double *gt = (double *)((char *)workspace + 512);
     double *days = (double *)((char *)workspace + 512 + cema_gt_bytes(L));
+    unsigned long long *insane = (unsigned long long *)(gt + 4 * L + 1);
+    RR_HIP(hipMemsetAsync(insane, 0, sizeof(*insane), st));
     hipLaunchKernelGGL(cema_pack, dim3((unsigned)rr_ceil_div(T * L, 256)),
                        dim3(256), 0, st, prec, mean_temp, frac, etp, T, L, D,
-                       days);
+                       days, insane);
     hipLaunchKernelGGL(cema_day_meta, dim3((unsigned)rr_ceil_div(T, 256)),
                        dim3(256), 0, st, days, T, D, qobs);
     hipLaunchKernelGGL(cema_gtresh, dim3((unsigned)L), dim3(256), 0, st, days,

@@ -50,12 +50,13 @@ static inline size_t cema_days_bytes(int64_t T, int64_t L, bool with_etp)
 }
 
 // per-layer constants: G_tresh[L], Psolannual[L], the CemaGt table [L] the
-// register kernels read (below), and one flag: every threshold suits the
-// 3-FMA quotient
+// register kernels read (below), one flag: every threshold suits the
+// 3-FMA quotient, and one counter (a 64-bit integer): forcing values that
+// rule out the SANE form of the snow routine (cema_day)
 static inline size_t cema_gt_bytes(int64_t L)
 {
     if (L < 1) L = 1;
-    return rr_align256((size_t)(4 * L + 1) * 8);
+    return rr_align256((size_t)(4 * L + 2) * 8);
 }
 
 // + the [nstate][L][N] snow-state scratch when the layers do not fit in
@@ -118,7 +119,18 @@ __device__ __forceinline__ void cema_gt_to_regs(cema_gt_ptr_t gt_tab,
     }
 }
 
-template <int L, bool FIRST, bool GT_REGS = false>
+// SANE: the wave has established (cema_wave_is_sane) that in every lane
+//   * the thermal state can never be NaN -- 0 <= CTG <= 1, a finite initial
+//     state and finite temperatures make it a convex combination of finite
+//     values --, so `if e > 0: e = 0` (:93-96) is one v_min_f64 (which would
+//     turn a NaN into 0) instead of a compare and a 64-bit select;
+//   * the snow pack can never be negative -- an initial pack and snowfall
+//     that are not negative, and melt <= pack --, so the factor
+//     0.9 ratio + 0.1 of a day without melt is finite and positive without
+//     asking (the idle vote's second compare).
+// Three vector instructions per layer and day; bit-identical by construction
+// (and checked: every snow fixture is bit-exact in both forms).
+template <int L, bool FIRST, bool GT_REGS = false, bool SANE = false>
 __device__ __forceinline__ double cema_day(
     const double *__restrict__ day, cema_gt_ptr_t gt_tab, lanemask_t gt_ok,
     double snow_pack_init, double thermal_state_init, double CTG,
@@ -137,7 +149,13 @@ __device__ __forceinline__ double cema_day(
             g = G[l] + snow;
             e = CTG * eTG[l] + one_minus_CTG * temp;
         }
-        if (e > 0) e = 0.0;
+        if (SANE && !FIRST) {
+            // (written out: from C++ hipcc quiets the operand with a
+            // v_max x, x of its own first)
+            asm("v_min_f64 %0, %1, 0" : "=v"(e) : "v"(e));
+        } else {
+            if (e > 0) e = 0.0;
+        }
         double pot_melt = 0.0;                             // :99-106
         if (e == 0 && temp > 0) {
             pot_melt = Kf * temp;
@@ -149,7 +167,9 @@ __device__ __forceinline__ double cema_day(
         // melt = (0.9*ratio + 0.1) * pot_melt is that same zero -- the factor
         // is finite and positive whenever G >= 0 (ratio in [0, 1]) -- and the
         // wave skips the quotient and the melt arithmetic.
-        const lanemask_t idle = RR_LANES(pot_melt == 0.0) & RR_LANES(g >= 0.0);
+        const lanemask_t idle =
+            SANE ? RR_LANES(pot_melt == 0.0)
+                 : (RR_LANES(pot_melt == 0.0) & RR_LANES(g >= 0.0));
         double melt = pot_melt;
         if (rr_exec() & ~idle) {
             // G / G_tresh: the threshold is fixed for the whole run, so the
@@ -183,6 +203,22 @@ __device__ __forceinline__ double cema_day(
     return cema_layer_mean<L>(c);
 }
 
+
+// Whether the wave may run the SANE form of cema_day: the conditions of its
+// comment, for every lane and for the whole forcing (`gtresh` + 4L + 1: the
+// pre-pass's count of temperatures that are not finite and snowfalls that are
+// negative, a 64-bit integer).
+__device__ __forceinline__ bool cema_wave_is_sane(const double *gtresh, int L,
+                                                  double CTG,
+                                                  double snow_pack_init,
+                                                  double thermal_state_init)
+{
+    const long long bad_forcing =
+        *(const long long *)(gtresh + 4 * L + 1);
+    const lanemask_t ctg_ok = RR_LANES(CTG >= 0.0) & RR_LANES(CTG <= 1.0);
+    return bad_forcing == 0 && !(snow_pack_init < 0.0) &&
+           fabs(thermal_state_init) <= 1e300 && (rr_exec() & ~ctg_ok) == 0;
+}
 
 // calls f(std::integral_constant<int, L>) for the runtime L in 1..8
 template <class F>

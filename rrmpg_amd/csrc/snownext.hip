@@ -18,7 +18,9 @@
 // sca_prev0: what the reference reads as sca[t-1] at t = 0 -- row -1, i.e. 0
 // (or sca_init when T == 1); sca_init itself never survives (quirk Q8).
 // FIRST: day 0 (peeled off the kernels' time loops, see snow_core.h cema_day).
-template <int L, bool FIRST>
+// SANE: as in snow_core.h cema_day -- the thermal state cannot be NaN, so its
+// clamp is one v_min_f64.
+template <int L, bool FIRST, bool SANE = false>
 __device__ __forceinline__ double cema_hyst_day(
     const double *__restrict__ day, const double *__restrict__ psol,
     double snow_pack_init, double thermal_state_init,
@@ -39,7 +41,11 @@ __device__ __forceinline__ double cema_hyst_day(
             g = G[l] + snow;
             e = CTG * eTG[l] + one_minus_CTG * temp;
         }
-        if (e > 0) e = 0.0;
+        if (SANE && !FIRST) {
+            asm("v_min_f64 %0, %1, 0" : "=v"(e) : "v"(e));
+        } else {
+            if (e > 0) e = 0.0;
+        }
         double pot_melt = 0.0;                             // :113-120
         if (e == 0 && temp > 0) {
             pot_melt = Kf * temp;
@@ -146,18 +152,19 @@ snow_gr4j_kernel(
     constexpr int D = cema_record_len(L, true);
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
-    auto one_day = [&](auto first, int64_t t) {
+    auto one_day = [&](auto first, auto sane, int64_t t) {
         constexpr bool FIRST = decltype(first)::value;
+        constexpr bool SANE = decltype(sane)::value;
         double day[D];          // by value: one wide scalar load per day
 #pragma unroll
         for (int k = 0; k < D; ++k) day[k] = days[t * D + k];
         double snowmelt;
         if constexpr (HYST)
-            snowmelt = cema_hyst_day<L, FIRST>(
+            snowmelt = cema_hyst_day<L, FIRST, SANE>(
                 day, psol, snow_pack_init, thermal_state_init, sca_prev0, CTG,
                 omc, Kf, inv_Thacc, thacc_m, Rsp, G, eTG, sca, swe_max);
         else
-            snowmelt = cema_day<L, FIRST>(day, gt_tab, gt_ok, snow_pack_init,
+            snowmelt = cema_day<L, FIRST, false, SANE>(day, gt_tab, gt_ok, snow_pack_init,
                                           thermal_state_init, CTG, omc, Kf, G,
                                           eTG);
         double liquid = snowmelt;
@@ -206,8 +213,16 @@ snow_gr4j_kernel(
             acc = __builtin_fma(d, d, acc);
         }
     };
-    one_day(std::true_type{}, 0);
-    for (int64_t t = 1; t < T; ++t) one_day(std::false_type{}, t);
+    // (two copies of the time loop, see cemaneige.hip cemaneige_kernel)
+    if (cema_wave_is_sane(gtresh, L, CTG, snow_pack_init, thermal_state_init)) {
+        one_day(std::true_type{}, std::true_type{}, 0);
+        for (int64_t t = 1; t < T; ++t)
+            one_day(std::false_type{}, std::true_type{}, t);
+    } else {
+        one_day(std::true_type{}, std::false_type{}, 0);
+        for (int64_t t = 1; t < T; ++t)
+            one_day(std::false_type{}, std::false_type{}, t);
+    }
     if (we && active) sse[i] = acc;
 }
 

@@ -233,3 +233,68 @@ def test_cemaneigegr4j_fuzz(models, oracle, fused_variant):
                        True, True, None)
     for a, b, n in zip(out, ref, ["qsim", "G", "eTG", "s_store", "r_store"]):
         _same(a, b, "cemaneigegr4j " + n)
+
+
+@pytest.mark.parametrize("poison", ["nan_temp", "inf_temp", "negative_snow",
+                                    "none"])
+def test_snow_kernels_with_poisoned_forcing(models, oracle, poison):
+    """The snow kernels' SANE form (one v_min for the thermal state's clamp, no
+    sign check of the pack in the idle vote) is only entered when the pre-pass
+    found every temperature finite and no snowfall negative, and the wave's
+    parameters and the initial states allow it.  Forcing that breaks those
+    premises must give what the reference gives -- NaNs where it has them."""
+    from rrmpg_amd.models import _snowgr4j as core
+    from rrmpg_amd.models import cemaneige as cmod
+    from rrmpg_amd.models import cemaneigegr4j as fmod
+    h = golden("syn_cemaneigehystgr4j")
+    rng = np.random.default_rng(104 + 1000 * SEED)
+    t = 400
+    lp, lm, fr, etp = (h[k][:t].copy() for k in ("layer_prec", "layer_mean",
+                                                 "frac_solid", "etp"))
+    if poison == "nan_temp":
+        lm[137, 2] = np.nan
+    elif poison == "inf_temp":
+        lm[90, 0] = np.inf
+        lm[200, 4] = -np.inf
+    elif poison == "negative_snow":
+        lp[50, 1] = -3.0            # prec * frac < 0 on a frost day
+        fr[50, 1] = 1.0
+    n = 130                         # two full waves and a tail
+    for inits_c in [(3.0, -0.2), (0.0, 0.0)]:
+        flat = np.column_stack([rng.uniform(0, 1, n), rng.uniform(0, 10, n)])
+        with np.errstate(all="ignore"):
+            ref = oracle.simulate_cemaneige(lp, lm, fr, inits_c, flat,
+                                            return_storages=True, nthreads=8)
+        out, _ = cmod._run((lp, lm, fr), inits_c,
+                           _records(models.Cemaneige, flat), True, True, None)
+        for a, b, name in zip(out, ref, ["outflow", "G", "eTG"]):
+            assert np.array_equal(a, b, equal_nan=True), (poison, name)
+    flat = np.column_stack([rng.uniform(0, 1, n), rng.uniform(0, 10, n),
+                            rng.uniform(10, 1200, n), rng.uniform(-5, 3, n),
+                            rng.uniform(20, 300, n), rng.uniform(0.5, 2.9, n)])
+    inits = (3.0, -0.2, 0.4, 0.5)
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_cemaneigegr4j(lp, lm, etp, fr, inits, flat,
+                                            return_storages=True, nthreads=8)
+    out, _ = fmod._run((lp, lm, fr, etp), inits,
+                       _records(models.CemaneigeGR4J, flat), True, True, None)
+    for a, b, name in zip(out, ref, ["qsim", "G", "eTG", "s_store", "r_store"]):
+        _same(a, b, "%s cemaneigegr4j %s" % (poison, name))
+    assert np.array_equal(out[1], ref[1], equal_nan=True)
+    assert np.array_equal(out[2], ref[2], equal_nan=True)
+    fice = np.array([0.0, 0.1, 0.3, 0.6, 0.9])
+    flat = np.column_stack([rng.uniform(0, 1, n), rng.uniform(0, 10, n),
+                            rng.uniform(10, 1200, n), rng.uniform(-5, 3, n),
+                            rng.uniform(20, 300, n), rng.uniform(1.1, 2.9, n),
+                            rng.uniform(0, 30, n)])
+    inits5 = (3.0, -0.2, 0.4, 0.5, 0.6)
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_snow_gr4j(False, True, lp, lm, etp, fr, inits5,
+                                        flat, frac_ice=fice,
+                                        return_storages=True, nthreads=8)
+    out, _ = core.run(False, True, (lp, lm, fr, etp), fice, inits5,
+                      _records(models.CemaneigeGR4JIce, flat), True, True,
+                      None)
+    for k, a in out.items():
+        if a is not None:
+            _same(a, ref[k], "%s ice %s" % (poison, k))
