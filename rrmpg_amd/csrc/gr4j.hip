@@ -20,10 +20,10 @@ struct __attribute__((aligned(32))) GrDay {
     double net;      // prec - etp if wet else etp - prec (:90, :102)
     double qobs;     // the day's observation (0 when no metric is fused)
     int wet;         // prec >= etp (:89)
-    int net_ok;      // net is +0 or in [2^-900, 2^196): a numerator the
-                     // 3-FMA quotient net/x1 serves (gr4j_core.h
-                     // gr4j_num_mask, decided here once per day instead of
-                     // by six vector instructions in every wave)
+    int net_ok;      // net is a numerator the 3-FMA quotient net/x1 serves
+                     // (gr4j_core.h gr4j_num_ok: +0 or positive and below
+                     // 2^196), decided here once per day instead of by
+                     // vector instructions in every wave
     int pad[2];
 };
 
@@ -39,8 +39,7 @@ __global__ void gr4j_pack_forcing(const double *__restrict__ prec,
     d.wet = p >= e;
     d.net = d.wet ? p - e : e - p;
     d.qobs = qobs ? qobs[t] : 0.0;
-    d.net_ok = (d.net == 0.0 && !__builtin_signbit(d.net)) ||
-               (d.net >= 0x1p-900 && d.net < 0x1p196);
+    d.net_ok = gr4j_num_ok(d.net);
     d.pad[0] = d.pad[1] = 0;
     days[t] = d;
 }

@@ -50,7 +50,9 @@ struct Gr4jPar {
 // 32-bit instructions at 2 cycles each instead of two fp64 compares at 4;
 // profiles/ubench): everything else -- negatives, NaN, inf, subnormals --
 // falls outside it and sends the wave through the IEEE division, where every
-// lane is re-examined with the full test (div_by_invariant_m).
+// lane is re-examined with the full test (div_by_invariant_m).  This strict
+// form guards the quotients of the snow routine, whose results are
+// bit-identical to the reference's.
 __device__ __forceinline__ lanemask_t gr4j_num_mask(double a)
 {
     const unsigned hi = (unsigned)__double2hiint(a);
@@ -58,12 +60,59 @@ __device__ __forceinline__ lanemask_t gr4j_num_mask(double a)
            lanes_plus_zero(a);
 }
 
-// a / x for the per-lane invariant x (bit-identical to `/`, see common.h);
-// stores run dry, so exact zeros stay on the fast form
+// GR4J's own quotients (s/x1, the percolation's and the routing store's
+// arguments, net/x1) use the test without its lower bound: a is +0 or
+// positive and below 2^196 -- ONE unsigned compare of the high word (sign
+// bit set, NaN, inf and anything >= 2^196 are above the bound).  What the
+// lower bound bought: for 0 < a < 2^-900 the residual of the 3-FMA form can
+// underflow, and the quotient is then only faithful -- within one ulp of a/b
+// instead of correctly rounded (tests/native/invdiv_harness.cpp: 5 % of such
+// numerators, never more than one ulp).  A store or flux of 1e-271 mm is no
+// hydrology, the GR4J family is a few-ulp restatement of the reference's libm
+// calls to begin with (tolerance 1e-10 relative), and
+// the three instructions of the strict test were a twelfth of the day's
+// vector work (GR4J 55.6 -> 54.0 ms, 125k sets 7.8 -> 7.2, fused 100.1 ->
+// 96.3).  The per-lane choice in the slow path uses the same relaxed test,
+// so a set's result never depends on its wave neighbours.
+#ifndef RR_GR4J_STRICT_VOTES
+#define RR_GR4J_STRICT_VOTES 0
+#endif
+#define GR4J_NUM_HI_WORD 0x4C300000u        // high word of 2^196
+__device__ __forceinline__ bool gr4j_num_ok(double a)
+{
+#if RR_GR4J_STRICT_VOTES
+    return inv_div_numerator_ok0(a) && fabs(a) <= GR4J_NUM_HI;
+#else
+    return (unsigned)__double2hiint(a) < GR4J_NUM_HI_WORD;
+#endif
+}
+__device__ __forceinline__ lanemask_t gr4j_num_lanes(double a)
+{
+#if RR_GR4J_STRICT_VOTES
+    return gr4j_num_mask(a);
+#else
+    return RR_LANES((unsigned)__double2hiint(a) < GR4J_NUM_HI_WORD);
+#endif
+}
+
+// a / x for the per-lane invariant x; stores run dry, so exact zeros stay on
+// the fast form
+__device__ __forceinline__ double gr4j_div_m(double a, lanemask_t a_ok,
+                                             const InvDivisor &d,
+                                             lanemask_t d_ok)
+{
+    double q = inv_div_core(a, d);
+    if (RR_ANY_OUTSIDE(a_ok & d_ok)) {
+        const bool ok = gr4j_num_ok(a) && d.ok;
+        const double exact = a / d.b;
+        q = ok ? q : exact;
+    }
+    return q;
+}
 __device__ __forceinline__ double gr4j_div(double a, const InvDivisor &d,
                                            lanemask_t d_ok)
 {
-    return div_by_invariant_m(a, gr4j_num_mask(a), d, d_ok, GR4J_NUM_HI);
+    return gr4j_div_m(a, gr4j_num_lanes(a), d, d_ok);
 }
 
 // _s_curve1 (gr4j_model.py:159-173); t is the integer ordinate index
@@ -475,10 +524,10 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     // one division per day instead of two.
     double E, D;
     fast_tanh_parts<CONSTS>(
-        div_by_invariant_m(net, net_m, P.inv_x1, P.x1_m, GR4J_NUM_HI), E, D);
+        gr4j_div_m(net, net_m, P.inv_x1, P.x1_m), E, D);
     // One vote covers the 3-FMA quotient s/x1 and the folded form: with
-    // s in {0} u [2^-900, 2^196) and |x1| in [2^-100, 2^100] (invdiv.h) the
-    // quotient is exact and |s/x1| <= 2^296, so c*E and k*E (E <= 1.2e17,
+    // 0 <= s < 2^196 and |x1| in [2^-100, 2^100] (invdiv.h) the quotient is
+    // RN(s/x1) (gr4j_num_lanes) and |s/x1| <= 2^296, so c*E and k*E (E <= 1.2e17,
     // |c| <= 2^692) stay finite
     // -- they are D times the reference's own c*th, k*th and would otherwise
     // overflow before those do.  The folded quotient itself is taken with
@@ -491,7 +540,7 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     double c, k;
     gr4j_store_coefficients(wet, s, P.x1, sx, c, k);
     const double den = D + k * E;
-    const lanemask_t fast = gr4j_num_mask(s) & P.x1_m &
+    const lanemask_t fast = gr4j_num_lanes(s) & P.x1_m &
                             RR_LANES(fabs(den) >= 0x1p-100);
     double frac = fast_div_core(c * E, den);
     if (RR_ANY_OUTSIDE(fast)) {
@@ -507,8 +556,8 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
             const double th = E / D;
             exact = ce * th / (1 + ke * th);
         }
-        const bool ok = inv_div_numerator_ok0(s) && fabs(s) <= GR4J_NUM_HI &&
-                        P.inv_x1.ok && fabs(den) >= 0x1p-100;
+        const bool ok = gr4j_num_ok(s) && P.inv_x1.ok &&
+                        fabs(den) >= 0x1p-100;
         frac = ok ? frac : exact;
     }
     // s - e_s + p_s (:114) and p_n - p_s (:123) with the branch's zeros
@@ -573,6 +622,6 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
     const bool wet = prec >= etp;                               // :89
     const double net = wet ? prec - etp : etp - prec;           // :90, :102
     return gr4j_step_net<UH, CONSTS>(P, s, r, uh, net, wet,
-                                        gr4j_num_mask(net),
+                                        gr4j_num_lanes(net),
                                         static_cast<MID &&>(mid));
 }

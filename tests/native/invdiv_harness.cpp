@@ -46,5 +46,38 @@ int main(int argc, char **argv) {
         }
     }
     printf("checked %ld\nmismatches %ld\n", checked, bad);
+
+    // GR4J's own quotients drop the numerator's lower bound (gr4j_core.h
+    // gr4j_num_ok): positive numerators of ANY magnitude below 2^196,
+    // subnormals included.  Below 2^-900 the residual a - b q0 can underflow,
+    // and the 3-FMA form is then only FAITHFUL: measured here in ulps of the
+    // IEEE quotient (a subnormal quotient's ulp is 2^-1074).
+    long tiny_checked = 0, tiny_off = 0;
+    double tiny_worst = 0.0;
+    for (long i = 0; i < n / 4; ++i) {
+        const uint64_t ma = rnd(), mb = rnd();
+        const int eb = (int)(rnd() % 201) - 100;
+        const double b = mk(mb, eb, 0);
+        double a;
+        if (i & 1) {                     // positive subnormal
+            uint64_t bits = ma >> (12 + rnd() % 52);
+            if (!bits) bits = 1;
+            memcpy(&a, &bits, 8);
+        } else {                         // tiny normal, 2^-1022 .. 2^-850
+            a = mk(ma, -1022 + (int)(rnd() % 172), 0);
+        }
+        const InvDivisor d = make_inv_divisor(b);
+        if (!d.ok) continue;
+        tiny_checked++;
+        const double q = inv_div_core(a, d), want = a / b;
+        int e;
+        frexp(want, &e);
+        const double ulp = (want < 0x1p-1022) ? 0x1p-1074 : ldexp(1.0, e - 53);
+        const double diff = fabs(q - want) / ulp;
+        if (diff > tiny_worst) tiny_worst = diff;
+        if (q != want) tiny_off++;
+    }
+    printf("tiny_checked %ld\ntiny_worst_ulps %.0f\ntiny_not_rn %ld\n",
+           tiny_checked, tiny_worst, tiny_off);
     return bad != 0;
 }

@@ -57,6 +57,11 @@ def test_invariant_division_is_bit_exact(tmp_path):
     vals = dict(re.findall(r"^(\w+) ([0-9]+)", out, flags=re.M))
     assert int(vals["mismatches"]) == 0, out
     assert int(vals["checked"]) > 15_000_000, out
+    # numerators below the strict vote's 2^-900 (GR4J's own quotients admit
+    # them, gr4j_core.h gr4j_num_ok): the 3-FMA form is faithful there --
+    # never more than one ulp from the IEEE quotient
+    assert int(vals["tiny_checked"]) > 4_000_000, out
+    assert int(vals["tiny_worst_ulps"]) <= 1, out
 
 
 def test_pow_tables_header_matches_its_generator(tmp_path):
