@@ -221,7 +221,9 @@ struct UhRegs {
             u2[j] = (j + 1 < N2MAX)
                 ? uh_fma(o2[j], p2, u2[(j + 1 < N2MAX) ? j + 1 : j])
                 : o2[j] * p2;
-        const lanemask_t finite = lanes_finite(p1) & lanes_finite(p2);
+        // (p1 = 0.9 p and p2 = 0.1 p of the same p: one is finite iff the
+        // other is)
+        const lanemask_t finite = lanes_finite(p1);
         if (RR_ANY_OUTSIDE(finite)) {
             // (lengths made opaque: hipcc otherwise hoists the 3 * N1MAX + 1
             // slot masks `j < n` of this never-taken path out of the time
@@ -320,7 +322,9 @@ struct UhLds {
             U2(j) = nv;
             if (j == 0) head2 = nv;
         }
-        const lanemask_t finite = lanes_finite(p1) & lanes_finite(p2);
+        // (p1 = 0.9 p and p2 = 0.1 p of the same p: one is finite iff the
+        // other is)
+        const lanemask_t finite = lanes_finite(p1);
         if (RR_ANY_OUTSIDE(finite)) {
             for (int j = 0; j < n1w; ++j)
                 if (j >= n1) U1(j) = 0.0;
