@@ -48,11 +48,19 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
                                  const double *__restrict__ PE_m,
                                  const double *__restrict__ T_m,
                                  const double *__restrict__ qobs, int64_t T,
-                                 HbvDay *__restrict__ days)
+                                 HbvDay *__restrict__ days,
+                                 int *__restrict__ odd_prec)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
     const int64_t c = blockIdx.y;
+    // odd_prec[c][block]: did this block of days see precipitation that is
+    // NaN, negative or -0 (the wrapper rejects negative values; the C-ABI
+    // takes anything)?  Rules out the kernel's TAME loop.  One flag per
+    // block, written unconditionally: nothing to zero beforehand.
+    const double pv = t < T ? prec[c * T + t] : 0.0;
+    const int odd = __syncthreads_or(!(pv >= 0.0) || __builtin_signbit(pv));
+    if (threadIdx.x == 0) odd_prec[c * gridDim.x + blockIdx.x] = odd;
+    if (t >= T) return;
     const int64_t g = c * T + t;
     int m = month[g];
     m = m < 0 ? 0 : (m > 11 ? 11 : m);   // memory safety only; the wrapper
@@ -89,7 +97,12 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 // LDS and every lane reads them back by broadcast -- the staging north_star
 // sketched.  Kept to document the comparison (profiles/README.md): the scalar
 // path is the faster one, it costs no vector-memory or LDS instruction at all.
-template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0>
+// TAME: the kernel carries a second copy of the time loop for waves that
+// qualify for it (see day_step); without it the kernel is the general loop
+// alone -- what hbv_launch picks for sweeps of exactly two waves per SIMD,
+// where the second copy's register pressure costs more than it saves.
+template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
+          bool TAME = true>
 __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     const HbvDay *__restrict__ days, int64_t T, double snow_init,
     double soil_init, double s1_init, double s2_init,
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     int64_t N, double *__restrict__ qsim, double *__restrict__ snow_out,
     double *__restrict__ soil_out, double *__restrict__ s1_out,
     double *__restrict__ s2_out, int64_t ld, const double *__restrict__ qobs,
-    double *__restrict__ sse)
+    double *__restrict__ sse, const int *__restrict__ odd_prec)
 {
     __shared__ FpPowLogEntry powlog[FP_POWLOG_N];
     for (int j = threadIdx.x; j < FP_POWLOG_N; j += RR_BLOCK)
@@ -175,14 +188,30 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     // costs a second scalar add per day and, in the unrolled loop, a VALU
     // compare -- there is no 64-bit signed scalar compare)
     const int Ti = (int)T;
-    auto day_step = [&](const HbvDay f, int t, auto &&mid) {
+    // `tame` (a std::bool_constant): the wave runs the copy of the time loop
+    // in which `min(snow, melt)` (:94) is one v_min_f64.  numba's min(a, b) is
+    // `b if b < a else a`: a compare and a 64-bit select, because the
+    // hardware minimum differs from it for a NaN snow pack (it would return
+    // the melt) and for a melt of -0 against an empty pack (it would return
+    // -0).  Neither exists in a wave whose lanes all have a degree-day factor
+    // that is not negative (melt = DD * (temp - T_t) with temp >= T_t is then
+    // never -0), whose initial pack is a number that is not negative, and
+    // whose precipitation -- the pre-pass counts this -- is never NaN,
+    // negative or -0: the pack stays in {+0} u (0, inf].  Bit-identical by
+    // construction; any other wave runs the general copy.
+    auto day_step = [&](const HbvDay f, int t, auto &&mid, auto tame) {
         row += ld;
 
         // snow routine (hbvedu_model.py:87-96)
         const double melt = DD * (f.temp - T_t);
         const bool cold = f.temp < T_t;
         const double snow_n = cold ? snow + f.prec : nb_max(0.0, snow - melt);
-        const double liquid_water = cold ? 0.0 : f.prec + nb_min(snow, melt);
+        double least;
+        if constexpr (decltype(tame)::value)
+            asm("v_min_f64 %0, %1, %2" : "=v"(least) : "v"(snow), "v"(melt));
+        else
+            least = nb_min(snow, melt);
+        const double liquid_water = cold ? 0.0 : f.prec + least;
         // first operation of the soil update (:111), taken here so that
         // liquid_water itself is dead after the power block (it lives on as
         // prec_eff, in place, on the days without the power)
@@ -271,67 +300,90 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         (void)t;
     };
 
-    if constexpr (FORCING == 1) {
-        __shared__ HbvDay tile[RR_BLOCK];
-        for (int t0 = 1; t0 < Ti; t0 += RR_BLOCK) {
-            const int tt = t0 + threadIdx.x;
-            tile[threadIdx.x] = days[tt < Ti ? tt : Ti - 1];
-            __syncthreads();
-            const int n = (Ti - t0 < RR_BLOCK) ? (Ti - t0) : RR_BLOCK;
-            for (int k = 0; k < n; ++k) {
-                const HbvDay f = tile[k];  // uniform address: LDS broadcast
-                day_step(f, t0 + k, [] {});
+    __shared__ HbvDay tile[FORCING == 1 ? RR_BLOCK : 1];
+    (void)tile;
+    auto time_loop = [&](auto tame) {
+        if constexpr (FORCING == 1) {
+            for (int t0 = 1; t0 < Ti; t0 += RR_BLOCK) {
+                const int tt = t0 + threadIdx.x;
+                tile[threadIdx.x] = days[tt < Ti ? tt : Ti - 1];
+                __syncthreads();
+                const int n = (Ti - t0 < RR_BLOCK) ? (Ti - t0) : RR_BLOCK;
+                for (int k = 0; k < n; ++k) {
+                    const HbvDay f = tile[k];  // uniform address: LDS broadcast
+                    day_step(f, t0 + k, [] {}, tame);
+                }
+                __syncthreads();
             }
-            __syncthreads();
+        } else if constexpr (FORCING == 2) {
+            // small sweeps (at most two waves per SIMD): nothing hides the
+            // scalar load's latency, so the next day's record is requested in
+            // the middle of this day's arithmetic -- after the power block, whose
+            // wait for its table entry (lgkmcnt counts LDS and scalar loads
+            // alike) would otherwise wait for the record as well.  Two records
+            // alternate (loop unrolled by two: no register copies); the fetch
+            // runs one record ahead, so it may touch record T -- the workspace
+            // holds one spare record for that, its content is never used.
+            // (constant address space: the records are read-only for this
+            // kernel, which is what lets the load stay scalar once its address
+            // has gone through the asm that pins it in place)
+            typedef const HbvDay __attribute__((address_space(4))) *cp_t;
+            cp_t pn = (cp_t)(days + 2);
+            auto fetch = [&](HbvDay &dst) {
+                asm volatile("" : "+s"(pn));
+                dst.temp = pn->temp; dst.prec = pn->prec;     // one load burst
+                dst.dtemp = pn->dtemp; dst.pe_m = pn->pe_m; dst.qobs = pn->qobs;
+                pn += 1;
+            };
+            HbvDay a = days[1], b;
+            // (a "use" of the first record ahead of the loop: otherwise hipcc
+            // leaves half of its load in flight across the loop entry and then
+            // waits for ALL scalar loads -- the prefetch included -- at that
+            // half's first use in every iteration)
+            asm volatile("" : : "s"(a.temp), "s"(a.prec), "s"(a.dtemp),
+                         "s"(a.pe_m), "s"(a.qobs));
+            int t = 1;
+            for (; t + 1 < Ti; t += 2) {
+                day_step(a, t, [&] { fetch(b); }, tame);
+                day_step(b, t + 1, [&] { fetch(a); }, tame);
+            }
+            if (t < Ti) day_step(a, t, [] {}, tame);
+        } else {
+            // (two days per trip, written out -- the votes are convergent
+            // operations, which keeps hipcc from unrolling a loop with a
+            // remainder on its own: one taken branch per two days)
+            int t = 1;
+            for (; t + 1 < Ti; t += 2) {
+                const HbvDay f0 = days[t];     // wave-uniform -> s_load_dwordx8
+                day_step(f0, t, [] {}, tame);
+                const HbvDay f1 = days[t + 1];
+                day_step(f1, t + 1, [] {}, tame);
+            }
+            if (t < Ti) {
+                const HbvDay f = days[t];
+                day_step(f, t, [] {}, tame);
+            }
         }
-    } else if constexpr (FORCING == 2) {
-        // small sweeps (at most two waves per SIMD): nothing hides the
-        // scalar load's latency, so the next day's record is requested in
-        // the middle of this day's arithmetic -- after the power block, whose
-        // wait for its table entry (lgkmcnt counts LDS and scalar loads
-        // alike) would otherwise wait for the record as well.  Two records
-        // alternate (loop unrolled by two: no register copies); the fetch
-        // runs one record ahead, so it may touch record T -- the workspace
-        // holds one spare record for that, its content is never used.
-        // (constant address space: the records are read-only for this
-        // kernel, which is what lets the load stay scalar once its address
-        // has gone through the asm that pins it in place)
-        typedef const HbvDay __attribute__((address_space(4))) *cp_t;
-        cp_t pn = (cp_t)(days + 2);
-        auto fetch = [&](HbvDay &dst) {
-            asm volatile("" : "+s"(pn));
-            dst.temp = pn->temp; dst.prec = pn->prec;     // one load burst
-            dst.dtemp = pn->dtemp; dst.pe_m = pn->pe_m; dst.qobs = pn->qobs;
-            pn += 1;
-        };
-        HbvDay a = days[1], b;
-        // (a "use" of the first record ahead of the loop: otherwise hipcc
-        // leaves half of its load in flight across the loop entry and then
-        // waits for ALL scalar loads -- the prefetch included -- at that
-        // half's first use in every iteration)
-        asm volatile("" : : "s"(a.temp), "s"(a.prec), "s"(a.dtemp),
-                     "s"(a.pe_m), "s"(a.qobs));
-        int t = 1;
-        for (; t + 1 < Ti; t += 2) {
-            day_step(a, t, [&] { fetch(b); });
-            day_step(b, t + 1, [&] { fetch(a); });
-        }
-        if (t < Ti) day_step(a, t, [] {});
+    };
+    // DD: +0, positive, +inf or NaN (v_cmp_class mask 0x3c3)
+    bool tame_wave = false;
+    if constexpr (TAME) {
+        // any flag of this catchment's pre-pass blocks set?
+        const int nb = (int)((T + 255) / 256);
+        const int *flags = odd_prec + (int64_t)blockIdx.y * nb;
+        lanemask_t odd = 0;
+        for (int k = threadIdx.x; k - (int)threadIdx.x < nb; k += RR_BLOCK)
+            odd |= RR_LANES(k < nb && flags[k] != 0);
+        tame_wave = odd == 0 && snow_init >= 0.0 &&
+                    !__builtin_signbit(snow_init) &&
+                    (rr_exec() & ~lanes_of_class(DD, 0x3c3)) == 0;
+    }
+    if constexpr (TAME) {
+        if (tame_wave) time_loop(std::true_type{});
+        else time_loop(std::false_type{});
     } else {
-        // (two days per trip, written out -- the votes are convergent
-        // operations, which keeps hipcc from unrolling a loop with a
-        // remainder on its own: one taken branch per two days)
-        int t = 1;
-        for (; t + 1 < Ti; t += 2) {
-            const HbvDay f0 = days[t];     // wave-uniform -> s_load_dwordx8
-            day_step(f0, t, [] {});
-            const HbvDay f1 = days[t + 1];
-            day_step(f1, t + 1, [] {});
-        }
-        if (t < Ti) {
-            const HbvDay f = days[t];
-            day_step(f, t, [] {});
-        }
+        (void)tame_wave;
+        time_loop(std::false_type{});
     }
     if (WITH_SSE && active) sse[i] = acc;
 }
@@ -340,8 +392,12 @@ extern "C" size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N)
 {
     (void)N;
     if (T < 0) T = 0;
-    // + 1: the spare record the prefetching kernel variant may touch
-    return rr_align256((size_t)((T > 0 ? T : 1) + 1) * sizeof(HbvDay));
+    // + 1: the spare record the prefetching kernel variant may touch; + the
+    // pre-pass's flags of odd precipitation values (one int per 256 days)
+    // behind it
+    if (T < 1) T = 1;
+    return rr_align256((size_t)(T + 1) * sizeof(HbvDay) +
+                       (size_t)rr_ceil_div(T, 256) * sizeof(int));
 }
 
 // Shared by the single- and multi-catchment entry points.
@@ -361,10 +417,11 @@ static int hbv_launch(const double *temp, const double *prec,
         return RR_E_SIZE;
     }
     HbvDay *days = (HbvDay *)workspace;
+    int *odd_prec = (int *)(days + (size_t)T * (size_t)C + 1);
     hipLaunchKernelGGL(hbv_pack_forcing,
                        dim3((unsigned)rr_ceil_div(T, 256), (unsigned)C),
                        dim3(256), 0, st, temp, prec, month, PE_m, T_m,
-                       (qobs && sse) ? qobs : nullptr, T, days);
+                       (qobs && sse) ? qobs : nullptr, T, days, odd_prec);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK), (unsigned)C);
     const bool any_s = snow != nullptr;
     // forcing variant: 0 one scalar load at the top of each day; 1 LDS
@@ -382,15 +439,20 @@ static int hbv_launch(const double *temp, const double *prec,
     if (pinned >= 0) variant = (int)pinned;
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
                  [&](auto Q, auto S, auto E) {
-        auto go = [&](auto V) {
-            hbvedu_kernel<Q.value, S.value, E.value, V.value>
+        auto go = [&](auto V, auto tame) {
+            hbvedu_kernel<Q.value, S.value, E.value, V.value, tame.value>
                 <<<grid, dim3(RR_BLOCK), 0, st>>>(
                     days, T, snow_init, soil_init, s1_init, s2_init, inits,
-                    params, N, qsim, snow, soil, s1, s2, ld, qobs, sse);
+                    params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
+                    odd_prec);
         };
-        if (variant == 1) go(std::integral_constant<int, 1>{});
-        else if (variant == 2) go(std::integral_constant<int, 2>{});
-        else go(std::integral_constant<int, 0>{});
+        // (measured, kernel ms with / without the second loop copy: 65k sets
+        // 3.14 / 3.22, 125k 3.76 / 3.70, 250k 7.45 / 7.62, 1M 27.4 / 27.8)
+        const bool two_per_simd = waves > 1024 && waves <= 2048;
+        if (variant == 1) go(std::integral_constant<int, 1>{}, std::false_type{});
+        else if (variant == 2) go(std::integral_constant<int, 2>{}, std::true_type{});
+        else if (two_per_simd) go(std::integral_constant<int, 0>{}, std::false_type{});
+        else go(std::integral_constant<int, 0>{}, std::true_type{});
     });
     RR_HIP(hipGetLastError());
     return RR_OK;
@@ -443,7 +505,8 @@ extern "C" size_t rr_hbvedu_catchments_workspace_bytes(int64_t T, int64_t C,
     (void)N;
     if (T < 1) T = 1;
     if (C < 1) C = 1;
-    return rr_align256(((size_t)T * (size_t)C + 1) * sizeof(HbvDay));
+    return rr_align256(((size_t)T * (size_t)C + 1) * sizeof(HbvDay) +
+                       (size_t)C * (size_t)rr_ceil_div(T, 256) * sizeof(int));
 }
 
 extern "C" int rr_hbvedu_simulate_catchments_dev(

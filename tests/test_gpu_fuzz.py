@@ -298,3 +298,63 @@ def test_snow_kernels_with_poisoned_forcing(models, oracle, poison):
     for k, a in out.items():
         if a is not None:
             _same(a, ref[k], "%s ice %s" % (poison, k))
+
+
+@pytest.mark.parametrize("poison", ["nan_prec", "negative_prec",
+                                    "minus_zero_prec", "nan_snow_init",
+                                    "minus_zero_snow_init", "none"])
+def test_hbvedu_with_poisoned_snow_inputs(models, oracle, hbv_variant, poison):
+    """HBV-Edu's TAME copy of the time loop takes min(snow, melt) with one
+    v_min_f64, which differs from numba's min for a NaN pack and for a melt of
+    -0 against an empty pack.  It is only entered when the pre-pass found no
+    precipitation that is NaN, negative or -0, the initial pack is a number
+    that is not negative, and no lane has a negative degree-day factor.
+    Inputs that break those premises must still give the reference's values,
+    bit for bit in the snow series."""
+    from rrmpg_amd.models import hbvedu as hmod
+    g = golden("syn_hbvedu")
+    rng = np.random.default_rng(105 + 1000 * SEED)
+    t = 400
+    temp, prec = g["temp"][:t].copy(), g["prec"][:t].copy()
+    month0 = (g["month"][:t] - 1).astype(np.int8)
+    snow_init = 0.0
+    if poison == "nan_prec":
+        prec[33] = np.nan
+    elif poison == "negative_prec":
+        prec[np.argmin(temp[:200])] = -4.0          # a frost day: pack < 0
+    elif poison == "minus_zero_prec":
+        prec[prec == 0.0] = -0.0
+    elif poison == "nan_snow_init":
+        snow_init = np.nan
+    elif poison == "minus_zero_snow_init":
+        snow_init = -0.0
+    n = 200
+    lo = np.array([-1, 3, 100, 1, .01, 90, .05, .01, .01, .01, 2.])
+    hi = np.array([1, 7, 200, 7, .07, 180, .2, .1, .05, .05, 5.])
+    flat = rng.uniform(lo, hi, (n, 11))
+    flat[::7, 1] = 0.0              # DD = +0: melt is +0 on warm days
+    flat[3::11, 1] = -0.0           # DD = -0 (one lane in some waves)
+    flat[5::50, 1] = -2.0           # a negative degree-day factor
+    inits = (snow_init, 100., 3., 10.)
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_hbvedu(temp, prec, month0, g["PE_m"], g["T_m"],
+                                     inits, flat, return_storage=True,
+                                     nthreads=8)
+    out, _ = hmod._run((temp, prec, month0, g["PE_m"], g["T_m"]), inits,
+                       _records(models.HBVEdu, flat), True, True, None)
+    assert np.array_equal(out[1], ref[1], equal_nan=True), poison + ": snow"
+    assert np.array_equal(np.signbit(out[1]), np.signbit(ref[1])), poison
+    for a, b, name in zip(out, ref, ["qsim", "snow", "soil", "s1", "s2"]):
+        nan_a, nan_b = np.isnan(a), np.isnan(b)
+        assert np.array_equal(nan_a, nan_b), (poison, name)
+        ok = ~nan_b & np.isfinite(b)
+        assert np.allclose(a[ok], b[ok], rtol=1e-9, atol=1e-9), (poison, name)
+    # a block of tame lanes only (every premise holds when poison == "none")
+    tame = flat[(flat[:, 1] > 0)][:64]
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_hbvedu(temp, prec, month0, g["PE_m"], g["T_m"],
+                                     inits, tame, return_storage=True)
+    out, _ = hmod._run((temp, prec, month0, g["PE_m"], g["T_m"]), inits,
+                       _records(models.HBVEdu, tame), True, True, None)
+    assert np.array_equal(out[1], ref[1], equal_nan=True), poison + ": snow"
+    assert np.array_equal(np.signbit(out[1]), np.signbit(ref[1])), poison
