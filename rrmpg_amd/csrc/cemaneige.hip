@@ -31,8 +31,9 @@
 //   [0,L) snow, [L,2L) rain, [2L,3L) mean_temp, [3L] etp, then the day's
 //   observation (cema_day_meta)
 // `insane`: counts the values that rule out the SANE form of the snow routine
-// (snow_core.h cema_day): a snowfall below zero, a temperature that is not
-// finite (or beyond 1e300).  Zeroed by rr_cema_prepass before the launch.
+// (snow_core.h cema_day, snownext.hip cema_hyst_day): a snowfall that is not
+// a number in [0, 1e290], a temperature that is not finite (or beyond 1e300).
+// Zeroed by rr_cema_prepass before the launch.
 __global__ void cema_pack(const double *__restrict__ prec,
                           const double *__restrict__ mean_temp,
                           const double *__restrict__ frac,
@@ -53,7 +54,8 @@ __global__ void cema_pack(const double *__restrict__ prec,
     d[L + l] = rain;
     d[2 * L + l] = temp;
     if (etp && l == 0) d[3 * L] = etp[t];
-    if (snow < 0.0 || !(fabs(temp) <= 1e300)) atomicAdd(insane, 1ull);
+    if (!(snow >= 0.0 && snow <= 1e290) || !(fabs(temp) <= 1e300))
+        atomicAdd(insane, 1ull);
 }
 
 // The trailing slot of every record: the day's observed discharge

@@ -23,6 +23,20 @@ __device__ __forceinline__ double nb_max(double a, double b) {
 __device__ __forceinline__ double nb_min(double a, double b) {
     return (b < a) ? b : a;
 }
+// The hardware's own minimum / maximum (IEEE minNum / maxNum: a NaN operand is
+// dropped, -0 < +0), written out because from C++ hipcc first quiets the
+// operands with a v_max x, x of its own.  They replace nb_min / nb_max only
+// where a kernel has established that the operands cannot be NaN or -0.
+__device__ __forceinline__ double rr_hw_min(double a, double b) {
+    double d;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ double rr_hw_max(double a, double b) {
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 // ---- division by a per-lane loop invariant ---------------------------------
 // a / b where b is fixed for the lane's whole time loop (FC, PWP, x1, x3 ...).

@@ -18,8 +18,21 @@
 // sca_prev0: what the reference reads as sca[t-1] at t = 0 -- row -1, i.e. 0
 // (or sca_init when T == 1); sca_init itself never survives (quirk Q8).
 // FIRST: day 0 (peeled off the kernels' time loops, see snow_core.h cema_day).
-// SANE: as in snow_core.h cema_day -- the thermal state cannot be NaN, so its
-// clamp is one v_min_f64.
+// SANE: the wave has established (cema_hyst_wave_is_sane) what snow_core.h's
+// cema_day asks for -- the thermal state cannot be NaN, its clamp is one
+// v_min_f64 -- and, for the hysteresis: the pack G is a finite number >= +0
+// (initial pack <= 1e300 and snowfall <= 1e290 are, melt <= pack), Kf >= +0,
+// Thacc > 0 and within the
+// 3-FMA quotient's range, Rsp and Psolannual finite, the covered area of "day
+// -1" a number in [+0, 1e300].  Then, in either branch, the covered area
+// before its clamp is a number >= +0 (previous area + a quotient >= +0, or
+// G / Thmax with Thmax > 0 finite, or 0): the clamp to [0, 1] (:145, numba's
+// min(max(.)): two compares and two 64-bit selects) is ONE v_min_f64 with 1;
+// the melt factor 0.9 sca + 0.1 is then in [0.1, 1.0] (0.9 + 0.1 rounds to
+// 1.0, and rounding is monotonic), so melt = factor * pot_melt <= pot_melt
+// <= G and `melt = min(melt, G)` (:151) is the identity; and the two
+// maxima / minima of non-negative numbers (:128, :134-137) are the hardware's.
+// Ten vector instructions per layer and day, bit-identical by construction.
 template <int L, bool FIRST, bool SANE = false>
 __device__ __forceinline__ double cema_hyst_day(
     const double *__restrict__ day, const double *__restrict__ psol,
@@ -59,15 +72,24 @@ __device__ __forceinline__ double cema_hyst_day(
             sc = prev + div_by_invariant_m(
                             snow_balance, inv_div_numerator_mask0(snow_balance),
                             inv_Thacc, thacc_m);
-            swe_max[l] = nb_max(swe_max[l], g);
+            swe_max[l] = SANE ? rr_hw_max(swe_max[l], g)
+                              : nb_max(swe_max[l], g);
         } else {                                           // :130-142
             const double Thmelt = psol[l] * Rsp;
-            const double Thmax = (swe_max[l] > Thmelt) ? Thmelt : swe_max[l];
+            const double Thmax =
+                SANE ? rr_hw_min(swe_max[l], Thmelt)
+                     : ((swe_max[l] > Thmelt) ? Thmelt : swe_max[l]);
             sc = (Thmax > 0) ? g / Thmax : 0.0;
         }
-        sc = nb_min(nb_max(sc, 0.0), 1.0);                 // :145
-        double melt = (0.9 * sc + 0.1) * pot_melt;         // :148
-        melt = nb_min(melt, g);                            // :151
+        double melt;
+        if constexpr (SANE) {
+            sc = rr_hw_min(sc, 1.0);                       // :145
+            melt = (0.9 * sc + 0.1) * pot_melt;            // :148, :151
+        } else {
+            sc = nb_min(nb_max(sc, 0.0), 1.0);             // :145
+            melt = (0.9 * sc + 0.1) * pot_melt;            // :148
+            melt = nb_min(melt, g);                        // :151
+        }
         g = g - melt;                                      // :154
         if (g == 0) swe_max[l] = 0.0;                      // :157-158
         G[l] = g;
@@ -76,6 +98,27 @@ __device__ __forceinline__ double cema_hyst_day(
         c = (l == 0) ? rain + melt : c + (rain + melt);    // :162, :166
     }
     return cema_layer_mean<L>(c);
+}
+
+// Whether the wave may run the SANE form of cema_hyst_day (its comment).
+__device__ __forceinline__ bool cema_hyst_wave_is_sane(
+    const double *gtresh, int L, double CTG, double Kf,
+    const InvDivisor &inv_Thacc, double Rsp, double snow_pack_init,
+    double thermal_state_init, double sca_prev0)
+{
+    if (!cema_wave_is_sane(gtresh, L, CTG, snow_pack_init, thermal_state_init))
+        return false;
+    bool psol_ok = true;                       // Psolannual[l], wave-uniform
+    for (int l = 0; l < L; ++l) psol_ok = psol_ok && fabs(gtresh[L + l]) <= 1e300;
+    // Kf: +0, positive or +inf (v_cmp_class mask 0x3c0)
+    const lanemask_t lanes_ok = lanes_of_class(Kf, 0x3c0) &
+                                RR_LANES(inv_Thacc.ok) &
+                                RR_LANES(inv_Thacc.b > 0.0) &
+                                RR_LANES(fabs(Rsp) <= 1e300);
+    return psol_ok && snow_pack_init >= 0.0 && snow_pack_init <= 1e300 &&
+           sca_prev0 >= 0.0 &&
+           !__builtin_signbit(sca_prev0) && sca_prev0 <= 1e300 &&
+           (rr_exec() & ~lanes_ok) == 0;
 }
 
 // Where the optional parameters sit in a record of `npar` doubles:
@@ -214,7 +257,13 @@ snow_gr4j_kernel(
         }
     };
     // (two copies of the time loop, see cemaneige.hip cemaneige_kernel)
-    if (cema_wave_is_sane(gtresh, L, CTG, snow_pack_init, thermal_state_init)) {
+    const bool sane_wave =
+        HYST ? cema_hyst_wave_is_sane(gtresh, L, CTG, Kf, inv_Thacc, Rsp,
+                                      snow_pack_init, thermal_state_init,
+                                      sca_prev0)
+             : cema_wave_is_sane(gtresh, L, CTG, snow_pack_init,
+                                 thermal_state_init);
+    if (sane_wave) {
         one_day(std::true_type{}, std::true_type{}, 0);
         for (int64_t t = 1; t < T; ++t)
             one_day(std::false_type{}, std::true_type{}, t);

@@ -298,6 +298,39 @@ def test_snow_kernels_with_poisoned_forcing(models, oracle, poison):
     for k, a in out.items():
         if a is not None:
             _same(a, ref[k], "%s ice %s" % (poison, k))
+    # hysteresis (+ ice): its SANE form additionally needs Kf >= +0, Thacc > 0
+    # inside the 3-FMA quotient's range, finite Rsp -- lanes that break this
+    # (every third wave has some) send their wave through the general form
+    for ice in (False, True):
+        cols = 9 if ice else 8
+        flat = np.column_stack([rng.uniform(0, 1, n), rng.uniform(0, 10, n),
+                                rng.uniform(1, 1000, n), rng.uniform(0, 1, n),
+                                rng.uniform(10, 1200, n), rng.uniform(-5, 3, n),
+                                rng.uniform(20, 300, n),
+                                rng.uniform(1.1, 2.9, n),
+                                rng.uniform(0, 30, n)])[:, :cols]
+        flat[0, 2] = 0.0            # Thacc = 0: 0/0 on days without snowfall
+        flat[1, 2] = -50.0          # negative Thacc
+        flat[2, 1] = -0.0           # Kf = -0
+        flat[3, 1] = 0.0            # Kf = +0 (allowed)
+        flat[4, 3] = np.nan         # Rsp
+        flat[5, 3] = 0.0            # Rsp = 0: Thmelt = 0
+        flat[6, 1] = np.inf         # Kf = inf (allowed)
+        cls = models.CemaneigeHystGR4JIce if ice else models.CemaneigeHystGR4J
+        with np.errstate(all="ignore"):
+            ref = oracle.simulate_snow_gr4j(True, ice, lp, lm, etp, fr, inits5,
+                                            flat, frac_ice=fice if ice else None,
+                                            return_storages=True, nthreads=8)
+        out, _ = core.run(True, ice, (lp, lm, fr, etp), fice if ice else None,
+                          inits5, _records(cls, flat), True, True, None)
+        for k, a in out.items():
+            if a is None:
+                continue
+            if k in ("G", "eTG", "sca"):
+                assert np.array_equal(a, ref[k], equal_nan=True), \
+                    (poison, ice, k)
+            else:
+                _same(a, ref[k], "%s hyst %s" % (poison, k))
 
 
 @pytest.mark.parametrize("poison", ["nan_prec", "negative_prec",
