@@ -193,12 +193,15 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     // `b if b < a else a`: a compare and a 64-bit select, because the
     // hardware minimum differs from it for a NaN snow pack (it would return
     // the melt) and for a melt of -0 against an empty pack (it would return
-    // -0).  Neither exists in a wave whose lanes all have a degree-day factor
-    // that is not negative (melt = DD * (temp - T_t) with temp >= T_t is then
-    // never -0), whose initial pack is a number that is not negative, and
-    // whose precipitation -- the pre-pass counts this -- is never NaN,
-    // negative or -0: the pack stays in {+0} u (0, inf].  Bit-identical by
-    // construction; any other wave runs the general copy.
+    // -0).  Neither matters in a wave whose lanes all have a degree-day factor
+    // that is not negative, whose initial pack is a number that is not
+    // negative, and whose precipitation -- the pre-pass flags this -- is
+    // never NaN, negative or -0: the pack stays in {+0} u (0, inf], and the
+    // melt DD * (temp - T_t) of a day with temp >= T_t is -0 only for
+    // temp = -0 against T_t = +0, where the one use of the minimum is its
+    // sum with a precipitation that is not -0 -- the same +0, or prec,
+    // either way.  Bit-identical by construction; any other wave runs the
+    // general copy.
     auto day_step = [&](const HbvDay f, int t, auto &&mid, auto tame) {
         row += ld;
 
