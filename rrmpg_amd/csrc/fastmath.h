@@ -465,8 +465,8 @@ FP_FN double inv_fourth_root_core3(double bb)
 // full-rate FMAs and no hardware estimate -- the Newton form above costs two
 // quarter-rate instructions (16 cycles each) + 8, i.e. about twice as much.
 // The result is the rounding of 1 + u P(u) with u P(u) exact to ~2^-60: error
-// <= 0.51 ulp against the exact root of 1 + u, <= 0.76 ulp against the
-// reference's own expression, which rounds 1 + u first.  GR4J's percolation
+// <= 0.51 ulp against the exact root of 1 + u.  (The reference rounds
+// 1 + v**4 first; the caller therefore passes u = (1 + v**4) - 1, exact.)  GR4J's percolation
 // (gr4j_model.py:117) has u = (4/9 S/x1)**4 <= 0.0391 whenever the production
 // store is not above its capacity, which the model's equations maintain.
 // CONSTS: 0 coefficients in SGPR pairs, 1 in VGPR pairs, 2 fetched from

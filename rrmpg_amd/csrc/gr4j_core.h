@@ -579,20 +579,27 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     const double v2 = v * v;
     constexpr bool votes = !std::is_same<UH, UhRegs<10>>::value;
     // v <= 4/9 while the store is within its capacity: the root of 1 + v**4
-    // is then a degree-7 polynomial in v**4 (fastmath.h); a wave with a lane
-    // beyond that takes the general form for those lanes
-    const double u = v2 * v2;
+    // is then a degree-7 polynomial (fastmath.h); a wave with a lane beyond
+    // that takes the general form for those lanes.  The polynomial's argument
+    // is (1 + v**4) - 1, not v**4: the reference rounds 1 + v**4 before it
+    // takes the power, and for a nearly empty store that rounding decides
+    // between a percolation of exactly 0 and one of 1e-16 S -- nothing in a
+    // sane run, but the difference between r == 0 and r > 0 for a routing
+    // store with a negative x3, whose exchange term is 0 in one case and NaN
+    // in the other (found by the fuzz soak).  The subtraction is exact.
+    const double b1 = 1 + v2 * v2;
     double root;
     if constexpr (RR_R4_POLY_ENABLED<UH>) {
+        const double u = b1 - 1;
         root = inv_fourth_root_1p_small<gr4j_r4_consts<UH, CONSTS>()>(u);
         const lanemask_t small = RR_LANES(u <= FP_R4_UMAX);
         if (RR_ANY_OUTSIDE(small)) {
             asm volatile("");                       // keep this a branch
-            const double general = gr4j_inv_fourth_root<votes>(1 + u);
+            const double general = gr4j_inv_fourth_root<votes>(b1);
             root = (u <= FP_R4_UMAX) ? root : general;
         }
     } else {
-        root = gr4j_inv_fourth_root<votes>(1 + u);
+        root = gr4j_inv_fourth_root<votes>(b1);
     }
     const double perc = sn * (1 - root);
     mid();

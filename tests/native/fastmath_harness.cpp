@@ -151,15 +151,16 @@ int main(int argc, char **argv) {
     printf("r4_3_exact_ok %d\n", inv_fourth_root_core3(1.0) == 1.0 &&
                                   inv_fourth_root_core3(16.0) == 0.5);
 
-    // the polynomial root of 1 + u, u = v^4 <= FP_R4_UMAX (GR4J's percolation):
-    // against the reference's own expression, which rounds 1 + u first
+    // the polynomial root of b = 1 + v^4 (rounded, as the reference has it),
+    // evaluated at u = b - 1 <= FP_R4_UMAX (GR4J's percolation)
     double wrp = 0, wrpx = 0;
     for (long i = 0; i < n; ++i) {
         double v = (i & 1) ? 0.4516 * u01() : exp2(-40 + 38.85 * u01());
-        double u = (v * v) * (v * v);
+        double b = 1 + (v * v) * (v * v);
+        double u = b - 1;                  // exact; what the kernels pass
         if (u > FP_R4_UMAX) continue;
         double err = ulp_err(inv_fourth_root_1p_small<0>(u),
-                             powl((long double)(1 + u), -0.25L));
+                             powl((long double)b, -0.25L));
         if (err > wrp) { wrp = err; wrpx = u; }
     }
     printf("worst_ulp_inv_fourth_root_poly %.4f at u=%.17g\n", wrp, wrpx);

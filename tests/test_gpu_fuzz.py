@@ -23,14 +23,30 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
 
+def _jitter(rng, x):
+    """x with every non-zero entry moved one ulp up or down at random: a
+    perturbation injected on every day, as the one-ulp difference between two
+    correct `pow`s / `tanh`s is."""
+    x = np.asarray(x, dtype=np.float64)
+    up = rng.random(x.shape) < 0.5
+    y = np.where(up, np.nextafter(x, np.inf), np.nextafter(x, -np.inf))
+    return np.where(x == 0, x, y)
+
+
 def _same(a, b, what, b_perturbed=None):
-    """b_perturbed: the oracle's own result for initial states moved by one ulp.
-    Where that alone moves a set's series by `amp` (relative), the set is
-    ill-conditioned -- a wild Beta or recession constant makes the dynamics
-    unstable -- and a one-ulp difference between two correct `pow`s, injected
-    every day, grows the same way: such a set is compared at 1000 * amp
-    instead of the flat tolerance (its NaN / inf pattern still has to match
-    exactly)."""
+    """b_perturbed: the oracle's own result(s) for slightly perturbed inputs
+    (one array or a list): initial states moved by one ulp, the forcing
+    jittered by one ulp per day (_jitter), the parameters moved by one ulp (a
+    routing store of x3 = 0.5 mm against inflows of millimetres loses three
+    digits a day to the cancellation in r + uh1 + exchange -- the reference's
+    own fp64 arithmetic is then 1e-13 off the exact value per day, measured
+    against a 40-digit evaluation -- and no jitter of the forcing shows that).  Where that alone moves a set's
+    series by `amp` (relative), the set is ill-conditioned -- a wild Beta or
+    recession constant makes the dynamics unstable (K_0 = 7.5: every day above
+    the threshold multiplies a difference by -6.5) -- and a one-ulp difference
+    between two correct `pow`s, injected every day, grows the same way: such a
+    set is compared at 1000 * amp instead of the flat tolerance (its NaN / inf
+    pattern still has to match exactly)."""
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape, what
     nan_a, nan_b = np.isnan(a), np.isnan(b)
@@ -49,13 +65,26 @@ def _same(a, b, what, b_perturbed=None):
         diff = np.where(ok, np.abs(a - b), 0.0)
         rtol = np.where(np.arange(b.shape[-1]) % 2 == 0, RTOL, 1e-6)
         if b_perturbed is not None:
-            b2 = np.asarray(b_perturbed)
-            both = ok & np.isfinite(b2)
-            d2 = np.where(both, np.abs(b2 - b), 0.0)
-            scale = np.maximum(fin, 1e-2 * np.maximum(colmax, 1e-9))
-            amp = (d2 / scale).reshape(-1, b.shape[-1]).max(axis=0)
-            rtol = np.maximum(rtol, 1e3 * amp)
-        excess = diff - (rtol * fin + 1e-2 * rtol * np.maximum(colmax, 1e-9))
+            probes = (b_perturbed if isinstance(b_perturbed, (list, tuple))
+                      else [b_perturbed])
+            for b2 in probes:
+                b2 = np.asarray(b2)
+                both = ok & np.isfinite(b2)
+                d2 = np.where(both, np.abs(b2 - b), 0.0)
+                scale = np.maximum(fin, 1e-2 * np.maximum(colmax, 1e-9))
+                amp = (d2 / scale).reshape(-1, b.shape[-1]).max(axis=0)
+                # (a probe that overflows or changes a degenerate set's
+                # regime: "do not compare the values of this set")
+                amp = np.nan_to_num(amp, nan=1.0, posinf=1.0)
+                rtol = np.maximum(rtol, np.minimum(1e3 * amp, 1e3))
+        # (wild sets: nothing below 1e-12 mm counts -- an exact zero against
+        # the 1e-15 a differently rounded cancellation leaves)
+        floor = np.where(np.arange(b.shape[-1]) % 2 == 0, 0.0, 1e-12)
+        # the probes must not loosen the in-bounds majority
+        even = rtol[::2]
+        assert (even > 100 * RTOL).mean() < 0.2, what + ": probes too loose"
+        tol = rtol * fin + 1e-2 * rtol * np.maximum(colmax, 1e-9) + floor
+        excess = np.where(diff <= tol, 0.0, diff - tol)
     assert excess.max(initial=0.0) <= 0, "%s: excess %g at %s" % (
         what, excess.max(), np.unravel_index(np.argmax(excess), excess.shape))
 
@@ -120,13 +149,20 @@ def test_hbvedu_fuzz(models, oracle, hbv_variant):
                                       tuple(np.nextafter(v, np.inf) for v in
                                             (0., 100., 3., 10.)), flat,
                                       return_storage=True, nthreads=8)
+        # ... and with the precipitation jittered by one ulp on every wet day
+        # (an instability that sets in late has forgotten the initial states)
+        ref3 = oracle.simulate_hbvedu(g["temp"][:t],
+                                      _jitter(rng, g["prec"][:t]),
+                                      g["month"][:t] - 1, g["PE_m"], g["T_m"],
+                                      (0., 100., 3., 10.), flat,
+                                      return_storage=True, nthreads=8)
     out = models.HBVEdu().simulate(g["temp"][:t], g["prec"][:t],
                                    g["month"][:t], g["PE_m"], g["T_m"], 0.,
                                    100., 3., 10., return_storage=True,
                                    params=_records(models.HBVEdu, flat))
-    for a, b, b2, n in zip(out, ref, ref2,
-                           ["qsim", "snow", "soil", "s1", "s2"]):
-        _same(a, b, "hbv " + n, b2)
+    for a, b, b2, b3, n in zip(out, ref, ref2, ref3,
+                               ["qsim", "snow", "soil", "s1", "s2"]):
+        _same(a, b, "hbv " + n, [b2, b3] if n != "snow" else None)
     assert np.isnan(ref[0]).any() and np.isfinite(ref[0]).any()
     # the probe must not loosen the well-conditioned majority
     with np.errstate(all="ignore"):
@@ -146,15 +182,32 @@ def test_gr4j_fuzz(models, oracle):
     bad = ~((flat[:, 3] > 0) & (flat[:, 3] <= 20))
     flat[bad, 3] = rng.uniform(0.2, 19.5, bad.sum())
     t = 400
+    def probes(f):
+        """oracle runs for the conditioning probes of _same: parameters (all
+        but x4, which fixes the hydrographs' lengths) and evapotranspiration
+        moved by one ulp"""
+        fj = f.copy()
+        fj[:, :3] = _jitter(rng, f[:, :3])
+        with np.errstate(all="ignore"):
+            return [oracle.simulate_gr4j(g["prec"][:t], g["etp"][:t],
+                                         (0.6, 0.7), fj, return_storage=True,
+                                         nthreads=8),
+                    oracle.simulate_gr4j(g["prec"][:t],
+                                         _jitter(rng, g["etp"][:t]),
+                                         (0.6, 0.7), f, return_storage=True,
+                                         nthreads=8)]
+
     with np.errstate(all="ignore"):
         ref = oracle.simulate_gr4j(g["prec"][:t], g["etp"][:t], (0.6, 0.7),
                                    flat, return_storage=True, nthreads=8)
+    pr = probes(flat)
     for sl in (slice(0, 640), slice(0, 64)):   # both start at an even set
         out = models.GR4J().simulate(g["prec"][:t], g["etp"][:t], 0.6, 0.7,
                                      return_storage=True,
                                      params=_records(models.GR4J, flat[sl]))
-        for a, b, n in zip(out, ref, ["qsim", "s_store", "r_store"]):
-            _same(a, b[:, sl], "gr4j " + n)
+        for j, (a, b, n) in enumerate(zip(out, ref,
+                                          ["qsim", "s_store", "r_store"])):
+            _same(a, b[:, sl], "gr4j " + n, [q[j][:, sl] for q in pr])
     # register tiers too: all x4 <= 3 / <= 5 / <= 10
     for cap in (2.9, 4.9, 9.9):
         f2 = flat.copy()
@@ -164,7 +217,7 @@ def test_gr4j_fuzz(models, oracle):
                                        (0.6, 0.7), f2, nthreads=8)
         out = models.GR4J().simulate(g["prec"][:t], g["etp"][:t], 0.6, 0.7,
                                      params=_records(models.GR4J, f2))
-        _same(out, ref, "gr4j tier %g" % cap)
+        _same(out, ref, "gr4j tier %g" % cap, [q[0] for q in probes(f2)])
 
 
 def test_snow_models_fuzz(models, oracle):
@@ -191,11 +244,32 @@ def test_snow_models_fuzz(models, oracle):
             ref = oracle.simulate_snow_gr4j(hyst, ice, *forcing, inits, flat,
                                             frac_ice=fice if ice else None,
                                             return_storages=True, nthreads=8)
+            # conditioning probe for the GR4J part: evapotranspiration
+            # jittered by one ulp a day (the snow states do not see it)
+            ref2 = oracle.simulate_snow_gr4j(
+                hyst, ice, forcing[0], forcing[1], _jitter(rng, forcing[2]),
+                forcing[3], inits, flat, frac_ice=fice if ice else None,
+                return_storages=True, nthreads=8)
+            # ... and the layer precipitation (its melt reaches the stores)
+            ref3 = oracle.simulate_snow_gr4j(
+                hyst, ice, _jitter(rng, forcing[0]), forcing[1], forcing[2],
+                forcing[3], inits, flat, frac_ice=fice if ice else None,
+                return_storages=True, nthreads=8)
+            # ... and x1, x2, x3 (cancellation in the routing store, _same)
+            fj = flat.copy()
+            ix1 = cls._param_list.index('x1')
+            fj[:, ix1:ix1 + 3] = _jitter(rng, flat[:, ix1:ix1 + 3])
+            ref4 = oracle.simulate_snow_gr4j(
+                hyst, ice, *forcing, inits, fj,
+                frac_ice=fice if ice else None, return_storages=True,
+                nthreads=8)
         out, _ = core.run(hyst, ice, layers, fice if ice else None, inits,
                           _records(cls, flat), True, True, None)
         for k, a in out.items():
             if a is not None:
-                _same(a, ref[k], "%s %s" % (cls.__name__, k))
+                _same(a, ref[k], "%s %s" % (cls.__name__, k),
+                      [ref2[k], ref3[k], ref4[k]]
+                      if k in ("qsim", "s_store", "r_store") else None)
     # Cemaneige alone with wild CTG / Kf
     flat = _wild_params(rng, np.array([0., 0.]), np.array([1., 10.]), 320)
     with np.errstate(all="ignore"):
@@ -229,10 +303,24 @@ def test_cemaneigegr4j_fuzz(models, oracle, fused_variant):
         ref = oracle.simulate_cemaneigegr4j(layers[0], layers[1], layers[3],
                                             layers[2], inits, flat,
                                             return_storages=True, nthreads=8)
+        # conditioning probes for the GR4J part (see _same)
+        ref2 = oracle.simulate_cemaneigegr4j(
+            layers[0], layers[1], _jitter(rng, layers[3]), layers[2], inits,
+            flat, return_storages=True, nthreads=8)
+        ref3 = oracle.simulate_cemaneigegr4j(
+            _jitter(rng, layers[0]), layers[1], layers[3], layers[2], inits,
+            flat, return_storages=True, nthreads=8)
+        fj = flat.copy()
+        fj[:, 2:5] = _jitter(rng, flat[:, 2:5])          # x1, x2, x3
+        ref4 = oracle.simulate_cemaneigegr4j(
+            layers[0], layers[1], layers[3], layers[2], inits, fj,
+            return_storages=True, nthreads=8)
     out, _ = fmod._run(layers, inits, _records(models.CemaneigeGR4J, flat),
                        True, True, None)
-    for a, b, n in zip(out, ref, ["qsim", "G", "eTG", "s_store", "r_store"]):
-        _same(a, b, "cemaneigegr4j " + n)
+    for a, b, b2, b3, b4, n in zip(out, ref, ref2, ref3, ref4,
+                                   ["qsim", "G", "eTG", "s_store", "r_store"]):
+        _same(a, b, "cemaneigegr4j " + n,
+              [b2, b3, b4] if n in ("qsim", "s_store", "r_store") else None)
 
 
 @pytest.mark.parametrize("poison", ["nan_temp", "inf_temp", "negative_snow",
