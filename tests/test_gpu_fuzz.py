@@ -479,3 +479,57 @@ def test_hbvedu_with_poisoned_snow_inputs(models, oracle, hbv_variant, poison):
                        _records(models.HBVEdu, tame), True, True, None)
     assert np.array_equal(out[1], ref[1], equal_nan=True), poison + ": snow"
     assert np.array_equal(np.signbit(out[1]), np.signbit(ref[1])), poison
+
+
+def test_kernel_variants_agree_bit_for_bit(models):
+    """The size-dependent kernel choices must not change a single bit: a sweep
+    sharded over GPUs (other launch sizes, hence other variants) has to give
+    the numbers of the unsharded one.  HBV-Edu: plain loop / prefetch loop /
+    LDS forcing, each with and without the TAME copy (the launch size decides:
+    300 sets vs 90,000 sets sit in different windows); CemaneigeGR4J: the
+    many-waves and the small-sweep kernel."""
+    from rrmpg_amd import _lib
+    from rrmpg_amd.models import cemaneigegr4j as fmod
+    from rrmpg_amd.models import hbvedu as hmod
+    g = golden("syn_hbvedu")
+    rng = np.random.default_rng(106 + 1000 * SEED)
+    t = 300
+    forcing = (g["temp"][:t], g["prec"][:t], (g["month"][:t] - 1).astype(np.int8),
+               g["PE_m"], g["T_m"])
+    lo = np.array([-1, 3, 100, 1, .01, 90, .05, .01, .01, .01, 2.])
+    hi = np.array([1, 7, 200, 7, .07, 180, .2, .1, .05, .05, 5.])
+    n = 300
+    flat = rng.uniform(lo, hi, (n, 11))
+    rec = _records(models.HBVEdu, flat)
+    inits = (0., 100., 3., 10.)
+    base = None
+    for v in (-1, 0, 2, 1):
+        with _lib.debug_option("hbv_variant", v):
+            out, _ = hmod._run(forcing, inits, rec, True, True, None)
+        if base is None:
+            base = out
+        for a, b in zip(out, base):
+            assert np.array_equal(a, b), "HBV variant %d" % v
+    # the same sets inside a launch of two waves per SIMD (no TAME copy)
+    big = np.tile(flat, (300, 1))[:90_000]
+    outb, _ = hmod._run(forcing, inits, _records(models.HBVEdu, big), True,
+                        False, None)
+    assert np.array_equal(outb[0][:, :n], base[0])
+    assert np.array_equal(outb[0][:, 60_000:60_000 + n], base[0])
+    # fused kernel variants
+    h = golden("syn_cemaneigehystgr4j")
+    layers = tuple(h[k][:t] for k in ("layer_prec", "layer_mean",
+                                      "frac_solid", "etp"))
+    lo = np.array([0, 0, 10, -5, 20, 0.5])
+    hi = np.array([1, 10, 1200, 3, 300, 4.9])
+    flat = rng.uniform(lo, hi, (n, 6))
+    rec = _records(models.CemaneigeGR4J, flat)
+    base = None
+    for v in (1, 2, 0):
+        with _lib.debug_option("fused_variant", v):
+            out, _ = fmod._run(layers, (3.0, -0.2, 0.4, 0.5), rec, True, True,
+                               None)
+        if base is None:
+            base = out
+        for a, b in zip(out, base):
+            assert np.array_equal(a, b), "fused variant %d" % v
