@@ -124,6 +124,15 @@ UB_KERNEL(rcp_f64,
 UB_KERNEL(rsq_f64,
     "v_rsq_f64 %0, %0\n" "v_rsq_f64 %1, %1\n" "v_rsq_f64 %2, %2\n" "v_rsq_f64 %3, %3\n" "v_rsq_f64 %4, %4\n" "v_rsq_f64 %5, %5\n" "v_rsq_f64 %6, %6\n" "v_rsq_f64 %7, %7\n",
     "v_rsq_f64 %0, %0\n" "v_rsq_f64 %0, %0\n" "v_rsq_f64 %0, %0\n" "v_rsq_f64 %0, %0\n" "v_rsq_f64 %0, %0\n" "v_rsq_f64 %0, %0\n" "v_rsq_f64 %0, %0\n" "v_rsq_f64 %0, %0\n")
+// one quarter-rate instruction among seven full-rate ones (per instruction of
+// the group; 8 x 4.3 would be 4.3, 16 + 7 x 4.3 would be 5.8)
+UB_KERNEL(mix_rsq_7fma,
+    "v_rsq_f64 %0, %0\n" "v_fma_f64 %1, %1, %10, %11\n" "v_fma_f64 %2, %2, %10, %11\n" "v_fma_f64 %3, %3, %10, %11\n" "v_fma_f64 %4, %4, %10, %11\n" "v_fma_f64 %5, %5, %10, %11\n" "v_fma_f64 %6, %6, %10, %11\n" "v_fma_f64 %7, %7, %10, %11\n",
+    "v_rsq_f64 %0, %0\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n")
+// ... and among three
+UB_KERNEL(mix_rsq_3fma,
+    "v_rsq_f64 %0, %0\n" "v_fma_f64 %1, %1, %10, %11\n" "v_fma_f64 %2, %2, %10, %11\n" "v_fma_f64 %3, %3, %10, %11\n" "v_rsq_f64 %4, %4\n" "v_fma_f64 %5, %5, %10, %11\n" "v_fma_f64 %6, %6, %10, %11\n" "v_fma_f64 %7, %7, %10, %11\n",
+    "v_rsq_f64 %0, %0\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n" "v_rsq_f64 %0, %0\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n" "v_fma_f64 %0, %0, %10, %11\n")
 UB_KERNEL(sqrt_f64,
     "v_sqrt_f64 %0, %0\n" "v_sqrt_f64 %1, %1\n" "v_sqrt_f64 %2, %2\n" "v_sqrt_f64 %3, %3\n" "v_sqrt_f64 %4, %4\n" "v_sqrt_f64 %5, %5\n" "v_sqrt_f64 %6, %6\n" "v_sqrt_f64 %7, %7\n",
     "v_sqrt_f64 %0, %0\n" "v_sqrt_f64 %0, %0\n" "v_sqrt_f64 %0, %0\n" "v_sqrt_f64 %0, %0\n" "v_sqrt_f64 %0, %0\n" "v_sqrt_f64 %0, %0\n" "v_sqrt_f64 %0, %0\n" "v_sqrt_f64 %0, %0\n")
@@ -264,7 +273,7 @@ static const Entry entries[] = {
     E(fma_f64), E(fma_f64_sgpr), E(add_f64), E(mul_f64), E(max_f64),
     E(min_f64), E(mov_b64), E(ldexp_f64), E(rndne_f64), E(fract_f64),
     E(cvt_f64_i32), E(cvt_i32_f64), E(frexp_mant_f64), E(frexp_exp_f64),
-    E(rcp_f64), E(rsq_f64), E(sqrt_f64), E(div_scale_f64), E(div_fmas_f64),
+    E(rcp_f64), E(rsq_f64), E(mix_rsq_7fma), E(mix_rsq_3fma), E(sqrt_f64), E(div_scale_f64), E(div_fmas_f64),
     E(div_fixup_f64), E(trig_preop_f64), E(cmp_lt_f64_vcc),
     E(cmp_lt_f64_sgpr), E(cmp_class_f64_vcc), E(cmp_class_f64_sgpr),
     E(cndmask_b32_vcc), E(cndmask_b32_sgpr), E(mov_b32), E(add_u32),
