@@ -262,6 +262,14 @@ UB_KERNEL_I(mov_b32_indep,
     "v_mov_b32 %0, %8\n" "v_mov_b32 %1, %8\n" "v_mov_b32 %2, %8\n" "v_mov_b32 %3, %8\n" "v_mov_b32 %4, %8\n" "v_mov_b32 %5, %8\n" "v_mov_b32 %6, %8\n" "v_mov_b32 %7, %8\n", 1)
 UB_KERNEL_I(fma_f32_indep,
     "v_fma_f32 %0, %0, %8, %8\n" "v_fma_f32 %1, %1, %8, %8\n" "v_fma_f32 %2, %2, %8, %8\n" "v_fma_f32 %3, %3, %8, %8\n" "v_fma_f32 %4, %4, %8, %8\n" "v_fma_f32 %5, %5, %8, %8\n" "v_fma_f32 %6, %6, %8, %8\n" "v_fma_f32 %7, %7, %8, %8\n", 1)
+// 32-bit transcendentals (operands are bit patterns; only the issue cost
+// matters): would an fp32 seed be cheaper than the fp64 one?
+UB_KERNEL_I(rsq_f32_indep,
+    "v_rsq_f32 %0, %0\n" "v_rsq_f32 %1, %1\n" "v_rsq_f32 %2, %2\n" "v_rsq_f32 %3, %3\n" "v_rsq_f32 %4, %4\n" "v_rsq_f32 %5, %5\n" "v_rsq_f32 %6, %6\n" "v_rsq_f32 %7, %7\n", 1)
+UB_KERNEL_I(rcp_f32_indep,
+    "v_rcp_f32 %0, %0\n" "v_rcp_f32 %1, %1\n" "v_rcp_f32 %2, %2\n" "v_rcp_f32 %3, %3\n" "v_rcp_f32 %4, %4\n" "v_rcp_f32 %5, %5\n" "v_rcp_f32 %6, %6\n" "v_rcp_f32 %7, %7\n", 1)
+UB_KERNEL_I(sqrt_f32_indep,
+    "v_sqrt_f32 %0, %0\n" "v_sqrt_f32 %1, %1\n" "v_sqrt_f32 %2, %2\n" "v_sqrt_f32 %3, %3\n" "v_sqrt_f32 %4, %4\n" "v_sqrt_f32 %5, %5\n" "v_sqrt_f32 %6, %6\n" "v_sqrt_f32 %7, %7\n", 1)
 UB_KERNEL_I(lshl_add_u32_indep,
     "v_lshl_add_u32 %0, %0, 1, %8\n" "v_lshl_add_u32 %1, %1, 1, %8\n" "v_lshl_add_u32 %2, %2, 1, %8\n" "v_lshl_add_u32 %3, %3, 1, %8\n" "v_lshl_add_u32 %4, %4, 1, %8\n" "v_lshl_add_u32 %5, %5, 1, %8\n" "v_lshl_add_u32 %6, %6, 1, %8\n" "v_lshl_add_u32 %7, %7, 1, %8\n", 1)
 
@@ -280,7 +288,7 @@ static const Entry entries[] = {
     E(and_b32), E(lshl_add_u32), E(ashrrev_i32), E(lshl_add_u64),
     E(mad_u64_u32), E(fma_f32), E(cvt_f32_f64), E(cvt_f64_f32),
     E(readlane_b32), E(readfirstlane_b32), E(writelane_b32),
-    E(sel_vop2_vcc), E(sel_vop3_vcc), E(sel_vop3_sgpr), E(cmp_sel2_vcc), E(cmp_sel2_sgpr), E(addc_co_vcc), E(add_co_vcc), E(mov_b32_indep), E(fma_f32_indep), E(lshl_add_u32_indep)};
+    E(sel_vop2_vcc), E(sel_vop3_vcc), E(sel_vop3_sgpr), E(cmp_sel2_vcc), E(cmp_sel2_sgpr), E(addc_co_vcc), E(add_co_vcc), E(mov_b32_indep), E(fma_f32_indep), E(rsq_f32_indep), E(rcp_f32_indep), E(sqrt_f32_indep), E(lshl_add_u32_indep)};
 
 static double run(kern_t k, int waves_per_simd, int iters,
                   unsigned long long *d_out, unsigned long long mask)
