@@ -177,7 +177,8 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     };
     // the time loop exists twice: for waves that may use the SANE form of
     // the snow routine (any sane run) and for the rest
-    if (cema_wave_is_sane(gtresh, L, CTG, snow_pack_init, thermal_state_init)) {
+    if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
+                          thermal_state_init)) {
         one_day(std::true_type{}, std::true_type{}, 0);
         for (int64_t t = 1; t < T; ++t)
             one_day(std::false_type{}, std::true_type{}, t);
@@ -321,7 +322,8 @@ cemaneigegr4j_kernel(
         }
     };
     // (two copies of the time loop, see cemaneige_kernel)
-    if (cema_wave_is_sane(gtresh, L, CTG, snow_pack_init, thermal_state_init)) {
+    if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
+                          thermal_state_init)) {
         one_day(std::true_type{}, std::true_type{}, 0);
         for (int64_t t = 1; t < T; ++t)
             one_day(std::false_type{}, std::true_type{}, t);

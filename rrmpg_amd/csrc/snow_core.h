@@ -124,6 +124,8 @@ __device__ __forceinline__ void cema_gt_to_regs(cema_gt_ptr_t gt_tab,
 //     state and finite temperatures make it a convex combination of finite
 //     values --, so `if e > 0: e = 0` (:93-96) is one v_min_f64 (which would
 //     turn a NaN into 0) instead of a compare and a 64-bit select;
+//   * the potential melt Kf * temp can never be NaN (Kf is not), so its cap
+//     by the pack is the hardware minimum;
 //   * the snow pack can never be negative -- an initial pack and snowfall
 //     that are not negative, and melt <= pack --, so the factor
 //     0.9 ratio + 0.1 of a day without melt is finite and positive without
@@ -159,7 +161,10 @@ __device__ __forceinline__ double cema_day(
         double pot_melt = 0.0;                             // :99-106
         if (e == 0 && temp > 0) {
             pot_melt = Kf * temp;
-            if (pot_melt > g) pot_melt = g;
+            // (SANE: Kf is not NaN, so neither is the product, and numba's
+            // `if pot_melt > G: pot_melt = G` is the hardware minimum)
+            if (SANE) pot_melt = rr_hw_min(pot_melt, g);
+            else if (pot_melt > g) pot_melt = g;
         }
         // Most days of a year nothing melts in a layer: frost (temp <= 0,
         // the same for every lane) or no snow left (G == 0 in every lane), so
@@ -209,13 +214,15 @@ __device__ __forceinline__ double cema_day(
 // pre-pass's count of temperatures that are not finite and snowfalls that are
 // negative, a 64-bit integer).
 __device__ __forceinline__ bool cema_wave_is_sane(const double *gtresh, int L,
-                                                  double CTG,
+                                                  double CTG, double Kf,
                                                   double snow_pack_init,
                                                   double thermal_state_init)
 {
     const long long bad_forcing =
         *(const long long *)(gtresh + 4 * L + 1);
-    const lanemask_t ctg_ok = RR_LANES(CTG >= 0.0) & RR_LANES(CTG <= 1.0);
+    // (Kf: anything but NaN -- v_cmp_class mask 0x3fc)
+    const lanemask_t ctg_ok = RR_LANES(CTG >= 0.0) & RR_LANES(CTG <= 1.0) &
+                              lanes_of_class(Kf, 0x3fc);
     return bad_forcing == 0 && !(snow_pack_init < 0.0) &&
            fabs(thermal_state_init) <= 1e300 && (rr_exec() & ~ctg_ok) == 0;
 }

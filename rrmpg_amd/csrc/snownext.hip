@@ -62,7 +62,8 @@ __device__ __forceinline__ double cema_hyst_day(
         double pot_melt = 0.0;                             // :113-120
         if (e == 0 && temp > 0) {
             pot_melt = Kf * temp;
-            if (pot_melt > g) pot_melt = g;
+            if (SANE) pot_melt = rr_hw_min(pot_melt, g);   // (Kf is not NaN)
+            else if (pot_melt > g) pot_melt = g;
         }
         const double snow_balance = snow - pot_melt;       // :123
         double sc;
@@ -106,7 +107,8 @@ __device__ __forceinline__ bool cema_hyst_wave_is_sane(
     const InvDivisor &inv_Thacc, double Rsp, double snow_pack_init,
     double thermal_state_init, double sca_prev0)
 {
-    if (!cema_wave_is_sane(gtresh, L, CTG, snow_pack_init, thermal_state_init))
+    if (!cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
+                           thermal_state_init))
         return false;
     bool psol_ok = true;                       // Psolannual[l], wave-uniform
     for (int l = 0; l < L; ++l) psol_ok = psol_ok && fabs(gtresh[L + l]) <= 1e300;
@@ -261,7 +263,7 @@ snow_gr4j_kernel(
         HYST ? cema_hyst_wave_is_sane(gtresh, L, CTG, Kf, inv_Thacc, Rsp,
                                       snow_pack_init, thermal_state_init,
                                       sca_prev0)
-             : cema_wave_is_sane(gtresh, L, CTG, snow_pack_init,
+             : cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
                                  thermal_state_init);
     if (sane_wave) {
         one_day(std::true_type{}, std::true_type{}, 0);
