@@ -202,8 +202,14 @@ __device__ __forceinline__ double cema_day(
                 // second load + wait where the reciprocal is first used)
                 asm volatile("" : : "s"(inv_gt.b), "s"(inv_gt.rb));
             }
+            // (SANE: the thresholds are not negative -- no snowfall is -- so
+            // `G / G_tresh if G < G_tresh else 1` is the hardware minimum of
+            // the quotient and 1: a quotient of inf or NaN, G_tresh = 0, is
+            // dropped for the 1 the reference takes there)
             const double ratio =                           // :109-112
-                (g < inv_gt.b)
+                SANE ? rr_hw_min(div_by_invariant_m(g, gr4j_num_mask(g),
+                                                    inv_gt, gt_ok), 1.0)
+                : (g < inv_gt.b)
                     ? div_by_invariant_m(g, gr4j_num_mask(g), inv_gt, gt_ok)
                     : 1.0;
             melt = (0.9 * ratio + 0.1) * pot_melt;         // :115
