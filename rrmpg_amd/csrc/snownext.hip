@@ -69,9 +69,11 @@ __device__ __forceinline__ double cema_hyst_day(
         double sc;
         if (snow_balance >= 0) {                           // :126-129
             const double prev = FIRST ? sca_prev0 : sca[l];
-            // (a day without snowfall or melt has snow_balance == 0)
+            // (a day without snowfall or melt has snow_balance == 0; the
+            // balance is not negative here, so the cheap integer form of the
+            // numerator vote -- +0 or [2^-900, 2^196) -- applies)
             sc = prev + div_by_invariant_m(
-                            snow_balance, inv_div_numerator_mask0(snow_balance),
+                            snow_balance, gr4j_num_mask(snow_balance),
                             inv_Thacc, thacc_m);
             swe_max[l] = SANE ? rr_hw_max(swe_max[l], g)
                               : nb_max(swe_max[l], g);
