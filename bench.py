@@ -89,6 +89,10 @@ def parse_args():
                     help="measurement hook: pin the CemaneigeGR4J kernel "
                          "variant (RR_OPT_FUSED_VARIANT: 1 many-waves, "
                          "2 small-sweep)")
+    ap.add_argument("--gr4j-variant", type=int, default=0,
+                    help="measurement hook: pin the GR4J kernel variant "
+                         "(RR_OPT_GR4J_VARIANT: 1 one wave per 64 sets, "
+                         "2 wave-specialised)")
     ap.add_argument("--no-parity-spot", action="store_true")
     return ap.parse_args()
 
@@ -376,6 +380,10 @@ def main():
     if args.hbv_variant >= 0:
         _lib.check(_lib.load().rr_debug_set_option(
             _lib.OPTIONS["hbv_variant"], args.hbv_variant),
+            "rr_debug_set_option")
+    if args.gr4j_variant > 0:
+        _lib.check(_lib.load().rr_debug_set_option(
+            _lib.OPTIONS["gr4j_variant"], args.gr4j_variant),
             "rr_debug_set_option")
     if args.fused_variant > 0:
         _lib.check(_lib.load().rr_debug_set_option(

@@ -109,7 +109,16 @@ int rr_release_cached_memory(void);
                                   * (default); 1 the many-waves kernel; 2 the
                                   * small-sweep kernel (constants and melt
                                   * thresholds in VGPRs) wherever it exists  */
-#define RR_OPT_COUNT_          6
+#define RR_OPT_GR4J_VARIANT    6 /* GR4J kernel: 0 the library's choice
+                                  * (default: the optimistic kernel where it
+                                  * exists); 1 gr4j_kernel, one wave per 64
+                                  * sets, every vote decided on the spot; 2
+                                  * wave-specialised (production / routing
+                                  * halves of the day in two waves of a
+                                  * workgroup); 3 gr4j_kernel in workgroups of
+                                  * four waves; 4 optimistic (branch-free day,
+                                  * redone if a vote failed)                 */
+#define RR_OPT_COUNT_          7
 int rr_debug_set_option(int option, int64_t value);
 int64_t rr_debug_get_option(int option);
 
@@ -284,6 +293,14 @@ int rr_cemaneigegr4j_simulate(const double *prec, const double *mean_temp,
  * per-call array copies of rrmpg/utils/metrics.py:29-299. */
 int rr_column_sums_dev(const double *qsim, int64_t ld, const double *obs,
                        int64_t T, int64_t N, double *sums, void *stream);
+/* The same with the first three sums taken about `shift`:
+ *   { sum (q-c), sum (q-c)^2, sum (q-c)*(obs-c), sum (obs-q)^2 },  c = shift.
+ * With c = mean(obs) the variance / covariance the host derives for KGE,
+ * alpha and r (np.std / pearsonr in rrmpg/utils/metrics.py:139-299, which are
+ * two-pass) do not cancel for large, nearly constant series. */
+int rr_column_sums_shifted_dev(const double *qsim, int64_t ld,
+                               const double *obs, int64_t T, int64_t N,
+                               double shift, double *sums, void *stream);
 
 /* ---- Monte-Carlo parameter sets drawn in HBM ------------------------------
  * Fills params[n][k] (device, the AoS block every rr_*_simulate_dev takes)

@@ -37,6 +37,9 @@ _SIGNATURES = {
     "rr_debug_get_option": (_i64, [ctypes.c_int]),
     "rr_column_sums_dev": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp,
                                           _vp]),
+    "rr_column_sums_shifted_dev": (ctypes.c_int,
+                                   [_vp, _i64, _vp, _i64, _i64, _dbl, _vp,
+                                    _vp]),
     "rr_sample_params_dev": (ctypes.c_int,
                              [ctypes.c_uint64, ctypes.c_int, _f64p, _f64p,
                               ctypes.POINTER(ctypes.c_int), ctypes.c_int,
@@ -185,7 +188,7 @@ def set_device(index):
 
 # include/rrhip.h RR_OPT_*
 OPTIONS = {"hbv_variant": 1, "gr4j_force_lds": 2, "max_block_cols": 3,
-           "gather_threads": 4, "fused_variant": 5}
+           "gather_threads": 4, "fused_variant": 5, "gr4j_variant": 6}
 
 
 class debug_option:

@@ -69,6 +69,48 @@ __device__ __forceinline__ lanemask_t rr_exec() { return RR_LANES(true); }
 // otherwise: the wave's instruction buffer is refilled every time).
 #define RR_ANY_OUTSIDE(m) __builtin_expect((rr_exec() & ~(m)) != 0, 0)
 
+// What a vote does with its answer.  Every fast form in these kernels is
+// guarded by "is some lane of the wave outside the form's domain?"
+//   CarefulVotes     decide at once: the wave branches into the reference's
+//                    own operation for those lanes (two scalar instructions
+//                    and a branch per vote);
+//   OptimisticVotes  note the lanes in a mask (one scalar AND) and go on with
+//                    the fast form everywhere; the caller asks any() ONCE at
+//                    the end of the day and, if so, redoes that day from its
+//                    untouched start state with CarefulVotes.  No sane run
+//                    ever redoes a day, and a sweep of a few waves per SIMD
+//                    -- where every scalar instruction and branch costs the
+//                    wave an issue turn that nobody else fills -- runs a
+//                    branch-free day (gr4j.hip, cemaneige.hip).
+// Either way a lane inside the domain gets the fast form's value and a lane
+// outside it the reference operation's, so results are bit-identical.
+// (the "unlikely" has to sit in the `if` itself -- RR_VOTE / RR_VOTES_FAILED --
+// : hipcc consumes __builtin_expect before it inlines, so one inside these
+// members would never reach the caller's branch and the slow blocks would
+// be laid out in line again)
+#define RR_VOTE(votes, m) __builtin_expect((votes).outside(m), 0)
+#define RR_VOTES_FAILED(votes) __builtin_expect((votes).any(), 0)
+struct CarefulVotes {
+    static constexpr bool optimistic = false;
+    __device__ __forceinline__ bool outside(lanemask_t m) const
+    {
+        return (rr_exec() & ~m) != 0;
+    }
+};
+struct OptimisticVotes {
+    static constexpr bool optimistic = true;
+    lanemask_t good = ~0ull;
+    __device__ __forceinline__ bool outside(lanemask_t m)
+    {
+        good &= m;
+        return false;
+    }
+    __device__ __forceinline__ bool any() const
+    {
+        return (rr_exec() & ~good) != 0;
+    }
+};
+
 // Class tests written directly into an SGPR pair with one v_cmp_class_f64
 // (spelled as an integer or class test in C++ they go through the VGPR round
 // trip above).  Class bits: 3 -normal, 4 -subnormal, 5 -0, 6 +0, 7 +subnormal,
@@ -128,12 +170,14 @@ __device__ __forceinline__ lanemask_t inv_div_numerator_mask0(
 // (shared by all quotients of one numerator), d_ok = RR_LANES(d.ok), hoisted
 // out of the time loop by the caller.  If any active lane is outside the fast form's domain the whole
 // wave evaluates the IEEE division and those lanes take it.
+template <class V = CarefulVotes>
 __device__ __forceinline__ double div_by_invariant_m(double a, lanemask_t a_ok,
                                                      const InvDivisor &d,
                                                      lanemask_t d_ok,
-                                                     double hi = 0x1p900) {
+                                                     double hi = 0x1p900,
+                                                     V &&votes = V()) {
     double q = inv_div_core(a, d);
-    if (RR_ANY_OUTSIDE(a_ok & d_ok)) {
+    if (RR_VOTE(votes, a_ok & d_ok)) {
         const bool ok = inv_div_numerator_ok0(a) && fabs(a) <= hi && d.ok;
         const double exact = a / d.b;
         q = ok ? q : exact;        // ok lanes: both values are RN(a / b)

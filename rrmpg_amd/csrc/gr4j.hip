@@ -79,8 +79,15 @@ constexpr int gr4j_min_waves()
            : std::is_same<UH, UhLds>::value   ? 6 : 2;
 }
 
-template <class UH, bool Q, bool S, bool E>
-__global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
+// WPG: waves per workgroup, each with its own 64 sets.  The dispatcher
+// balances workgroups over CUs, not waves over the four SIMDs of a CU
+// (profiles/ubench/wave_placement.hip: 1954 single-wave workgroups leave 108
+// SIMDs with three waves and 202 with one); the waves of ONE workgroup go to
+// different SIMDs, so groups of four waves fill every SIMD of their CU
+// evenly -- which decides the kernel time of a sweep of a few waves per SIMD.
+template <class UH, bool Q, bool S, bool E, int WPG = 1>
+__global__ __launch_bounds__(WPG * RR_BLOCK, (gr4j_min_waves<UH>() + WPG - 1) / WPG)
+void gr4j_kernel(
     const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
     const double *__restrict__ params, int64_t N,
     const int *__restrict__ plan, int force_lds,
@@ -91,7 +98,13 @@ __global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
     if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
-    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const int wave = (WPG == 1) ? 0
+        : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = (WPG == 1) ? (int)threadIdx.x
+                                : ((int)threadIdx.x & (RR_BLOCK - 1));
+    const int64_t first = ((int64_t)blockIdx.x * WPG + wave) * RR_BLOCK;
+    if (WPG > 1 && first >= N) return;      // a wave beyond the sweep
+    const int64_t i = first + lane;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 4;
     Gr4jPar P;
@@ -105,8 +118,7 @@ __global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
     double r = r_init * P.x3;   // gr4j_model.py:65
     double acc = 0.0;
     // output rows: wave-uniform base + lane offset (common.h rr_store_row)
-    const int lane_off = threadIdx.x * 8;
-    const int64_t first = (int64_t)blockIdx.x * RR_BLOCK;
+    const int lane_off = lane * 8;
     const unsigned row_bytes = rr_row_bytes(first, N);
     int64_t row = first;
 
@@ -144,6 +156,264 @@ __global__ __launch_bounds__(RR_BLOCK, (gr4j_min_waves<UH>())) void gr4j_kernel(
         row += ld;
     }
     if (E && active) sse[i] = acc;
+}
+
+// ---- optimistic variant: a branch-free day ----------------------------------
+// Every fast form of the day is guarded by a wave vote, and each vote costs
+// the loop two scalar instructions and a branch (twelve branches a day in
+// gr4j_kernel).  With four or more waves on a SIMD somebody else's vector
+// work fills those issue turns; a sweep of one or two waves per SIMD -- one
+// GPU's shard of a strong-scaled sweep, every `fit` population -- pays for
+// each of them (measured: 2.4 ns per vector instruction at two waves per
+// SIMD against 1.94 at five, with the vector pipe 20 % idle).  Here the votes
+// only note their lanes (OptimisticVotes, common.h: one scalar AND each), the
+// day runs the fast forms straight through, and ONE branch at its end asks
+// whether any vote failed; if so the day is redone from its start state with
+// the deciding votes of gr4j_kernel.  That start state is still there
+// because the states exist in two generations -- production store, routing
+// store and the hydrograph slots of day k are read from one and written to
+// the other, two days per trip -- which costs 12 register pairs (3+7 slots)
+// and not a single move.  Bit-identical to gr4j_kernel: a lane inside every
+// domain gets the fast forms' values either way, and a day with a lane
+// outside one IS gr4j_kernel's day.
+template <class UH>
+constexpr bool gr4j_has_optimistic()
+{
+    return std::is_same<UH, UhRegs<3>>::value ||
+           std::is_same<UH, UhRegs<5>>::value;
+}
+
+#ifndef GR4J_OPT_CONSTS
+#define GR4J_OPT_CONSTS GR4J_CONSTS_SGPR
+#endif
+#ifndef GR4J_OPT_MINWAVES
+#define GR4J_OPT_MINWAVES (std::is_same<UH, UhRegs<3>>::value ? 4 : 3)
+#endif
+template <class UH, bool Q, bool S, bool E>
+__global__ __launch_bounds__(RR_BLOCK, GR4J_OPT_MINWAVES)
+void gr4j_opt_kernel(
+    const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
+    const double *__restrict__ params, int64_t N,
+    const int *__restrict__ plan, int force_lds,
+    double *__restrict__ qsim, double *__restrict__ s_store,
+    double *__restrict__ r_store, int64_t ld,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    int n1cap, n2cap;
+    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = i < N;
+    const double *p = params + (active ? i : N - 1) * 4;
+    Gr4jPar P;
+    P.set(p[0], p[1], p[2], p[3]);
+    UH uh;
+    typename UH::Slots ua, ub;
+    uh.init(P.x4, ua);
+    double sa = s_init * P.x1, sb;   // gr4j_model.py:64
+    double ra = r_init * P.x3, rb;   // gr4j_model.py:65
+    double acc = 0.0;
+    const int lane_off = threadIdx.x * 8;
+    const int64_t first = (int64_t)blockIdx.x * RR_BLOCK;
+    const unsigned row_bytes = rr_row_bytes(first, N);
+    int64_t row = first;
+    typedef const GrDay __attribute__((address_space(4))) *day_ptr_t;
+    const day_ptr_t dp = (day_ptr_t)days;
+    GrDay f;
+    f.net = dp[0].net; f.qobs = dp[0].qobs; f.wet = dp[0].wet;
+    f.net_ok = dp[0].net_ok;
+    auto day = [&](const double s_in, const double r_in,
+                   const typename UH::Slots &u_in, double &s_out,
+                   double &r_out, typename UH::Slots &u_out, int64_t k) {
+        const double net = f.net, qobs_k = f.qobs;
+        const bool wet = f.wet != 0;
+        const lanemask_t net_m = f.net_ok ? ~0ull : 0ull;
+        auto fetch_next = [&]() {
+            day_ptr_t nx = dp + (k + 1);
+            asm volatile("" : "+s"(nx));         // keeps the load at this spot
+            f.net = nx->net; f.qobs = nx->qobs; f.wet = nx->wet;
+            f.net_ok = nx->net_ok;
+        };
+        OptimisticVotes votes;
+        double s = s_in, r = r_in;
+        double p_r = gr4j_production<UH, GR4J_OPT_CONSTS>(
+            P, s, net, wet, net_m, fetch_next, votes);
+        double q = gr4j_routing<UH>(P, r, uh, u_in, u_out, p_r, votes);
+        if (RR_VOTES_FAILED(votes)) {
+            // some lane left a fast form's domain: this day again, from its
+            // untouched start state, every vote decided on the spot
+            asm volatile("");
+            s = s_in;
+            r = r_in;
+            p_r = gr4j_production<UH, GR4J_OPT_CONSTS>(P, s, net, wet, net_m);
+            q = gr4j_routing<UH>(P, r, uh, u_in, u_out, p_r);
+        }
+        s_out = s;
+        r_out = r;
+        if (Q) rr_store_row(qsim + row, row_bytes, lane_off, q);
+        if (S) {
+            rr_store_row(s_store + row, row_bytes, lane_off, s);
+            rr_store_row(r_store + row, row_bytes, lane_off, r);
+        }
+        if (E) {
+            const double d = qobs_k - q;
+            acc = __builtin_fma(d, d, acc);
+        }
+        row += ld;
+    };
+    int64_t k = 0;
+    for (; k + 1 < T; k += 2) {
+        day(sa, ra, ua, sb, rb, ub, k);
+        day(sb, rb, ub, sa, ra, ua, k + 1);
+    }
+    if (k < T) day(sa, ra, ua, sb, rb, ub, k);
+    if (E && active) sse[i] = acc;
+}
+
+// ---- wave-specialised variant: the day's two halves in two waves ------------
+// A sweep of at most a few waves per SIMD (one GPU's shard of a strong-scaled
+// sweep, every `fit` population) cannot fill the fp64 pipe with one wave per
+// 64 sets: a lone wave issues an instruction every 5.5 cycles, two every 4.6,
+// and nothing hides their scalar work and branches.  GR4J's day is
+// feed-forward between its halves (gr4j_core.h gr4j_production /
+// gr4j_routing), so a workgroup of TWO waves serves 64 sets: one wave runs the
+// production stores of days [bK, (b+1)K) while the other routes the amounts of
+// the block before, which it finds in an LDS ring [2][K][64]; one s_barrier
+// per K days is the whole synchronisation.  Twice the waves for the same
+// arithmetic, half the dependent chain per wave; results bit-identical to
+// gr4j_kernel (the same two functions, the same order).
+#ifndef GR4J_PIPE_DAYS
+#define GR4J_PIPE_DAYS 8
+#endif
+__device__ __forceinline__ void rr_lds_release_barrier()
+{
+    // LDS writes of this wave done, then the workgroup barrier; the "memory"
+    // clobber keeps the compiler's LDS accesses on their side of it.  (Not
+    // __syncthreads(): its fence would also wait for the row stores.)
+#ifdef GR4J_PIPE_NOSYNC
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+template <class UH>
+constexpr bool gr4j_has_pipe()
+{
+    return std::is_same<UH, UhRegs<3>>::value ||
+           std::is_same<UH, UhRegs<5>>::value;
+}
+
+#define GR4J_PIPE_PAIRS 2      // pairs of waves per workgroup (4 waves: one
+                               // per SIMD of the CU, see gr4j_kernel's WPG)
+template <class UH, bool Q, bool S, bool E>
+__global__ __launch_bounds__(2 * GR4J_PIPE_PAIRS * RR_BLOCK) void
+gr4j_pipe_kernel(
+    const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
+    const double *__restrict__ params, int64_t N,
+    const int *__restrict__ plan, int force_lds,
+    double *__restrict__ qsim, double *__restrict__ s_store,
+    double *__restrict__ r_store, int64_t ld,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    constexpr int K = GR4J_PIPE_DAYS;
+    __shared__ double rings[GR4J_PIPE_PAIRS][2][K][RR_BLOCK];
+    int n1cap, n2cap;
+    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
+    const int lane = threadIdx.x & (RR_BLOCK - 1);
+    // wave w of the group: pair w % PAIRS; which half it runs alternates with
+    // the workgroup so that the heavier half does not always land on the same
+    // SIMDs of a CU
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave % GR4J_PIPE_PAIRS;
+    const bool producer =
+        (((wave / GR4J_PIPE_PAIRS) ^ (int)blockIdx.x) & 1) == 0;
+    double (*ring)[K][RR_BLOCK] = rings[pair];
+    const int64_t first =
+        ((int64_t)blockIdx.x * GR4J_PIPE_PAIRS + pair) * RR_BLOCK;
+    // (a pair beyond the sweep still takes part in the barriers: it runs on
+    // set N - 1 and stores nothing)
+    const int64_t i = first + lane;
+    const bool active = i < N;
+    const double *p = params + (active ? i : N - 1) * 4;
+    const int lane_off = lane * 8;
+    const unsigned row_bytes = rr_row_bytes(first, N);
+    typedef const GrDay __attribute__((address_space(4))) *day_ptr_t;
+    const day_ptr_t dp = (day_ptr_t)days;
+    const int64_t nblk = (T + K - 1) / K;
+    if (producer) {
+        Gr4jPar P;
+        P.set(p[0], p[1], p[2], p[3]);
+        double s = s_init * P.x1;   // gr4j_model.py:64
+        GrDay f;
+        f.net = dp[0].net; f.wet = dp[0].wet; f.net_ok = dp[0].net_ok;
+        int64_t row = first;
+        for (int64_t b = 0; b < nblk; ++b) {
+            double *half = &ring[b & 1][0][lane];
+#pragma unroll 1
+            for (int d = 0; d < K; ++d) {
+                const int64_t k = b * K + d;
+                if (k < T) {
+                    const double net = f.net;
+                    const bool wet = f.wet != 0;
+                    const lanemask_t net_m = f.net_ok ? ~0ull : 0ull;
+                    auto fetch_next = [&]() {
+                        day_ptr_t nx = dp + (k + 1);
+                        asm volatile("" : "+s"(nx));
+                        f.net = nx->net; f.wet = nx->wet;
+                        f.net_ok = nx->net_ok;
+                    };
+                    half[d * RR_BLOCK] =
+                        gr4j_production<UH, GR4J_CONSTS_SGPR>(
+                            P, s, net, wet, net_m, fetch_next);
+                    if (S) rr_store_row(s_store + row, row_bytes, lane_off, s);
+                    row += ld;
+                }
+            }
+            rr_lds_release_barrier();
+        }
+        rr_lds_release_barrier();       // (the consumer's last block)
+    } else {
+        Gr4jPar P;
+        P.set(p[0], p[1], p[2], p[3]);
+        UH uh;
+        uh.init(P.x4);
+        double r = r_init * P.x3;   // gr4j_model.py:65
+        double acc = 0.0;
+        int64_t row = first;
+        rr_lds_release_barrier();       // (the producer's first block)
+        // the routed amount and the observation of day k + 1 are requested
+        // while day k is worked on (LDS and scalar-cache latencies would
+        // otherwise be sat out once per day)
+        double p_next = ring[0][0][lane];
+        double qobs_next = dp[0].qobs;
+        for (int64_t b = 0; b < nblk; ++b) {
+            const double *half = &ring[b & 1][0][lane];
+#pragma unroll 1
+            for (int d = 0; d < K; ++d) {
+                const int64_t k = b * K + d;
+                if (k < T) {
+                    const double p_r = p_next, qobs_k = qobs_next;
+                    if (d + 1 < K) p_next = half[(d + 1) * RR_BLOCK];
+                    {
+                        day_ptr_t nx = dp + (k + 1);   // (spare record at T)
+                        asm volatile("" : "+s"(nx));
+                        qobs_next = nx->qobs;
+                    }
+                    const double q = gr4j_routing<UH>(P, r, uh, p_r);
+                    if (Q) rr_store_row(qsim + row, row_bytes, lane_off, q);
+                    if (S) rr_store_row(r_store + row, row_bytes, lane_off, r);
+                    if (E) {
+                        const double dq = qobs_k - q;
+                        acc = __builtin_fma(dq, dq, acc);
+                    }
+                    row += ld;
+                }
+            }
+            rr_lds_release_barrier();
+            p_next = ring[(b + 1) & 1][0][lane];
+        }
+        if (E && active) sse[i] = acc;
+    }
 }
 
 extern "C" size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N)
@@ -228,12 +498,47 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     const bool q = qsim != nullptr, s = s_store != nullptr, e = qobs && sse;
     const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     // every tier is enqueued; the kernels pick the one the plan selects
+    const int variant = (int)rr_option(RR_OPT_GR4J_VARIANT);
+    const int64_t waves = rr_ceil_div(N, RR_BLOCK);
     rr_dispatch3(q, s, e, [&](auto Q, auto S, auto E) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
+            constexpr size_t lds =
+                std::is_same<UH, UhLds>::value ? GR4J_LDS_BYTES : 0;
+            if constexpr (gr4j_has_pipe<UH>()) {
+                if (variant == 2) {
+                    gr4j_pipe_kernel<UH, Q.value, S.value, E.value>
+                        <<<dim3((unsigned)rr_ceil_div(waves, GR4J_PIPE_PAIRS)),
+                           dim3(2 * GR4J_PIPE_PAIRS * RR_BLOCK), 0, st>>>(
+                            days, T, s_init, r_init, params, N, d_plan,
+                            force_lds, qsim, s_store, r_store, ld, qobs, sse);
+                    return;
+                }
+            }
+            if constexpr (gr4j_has_optimistic<UH>()) {
+                // (the default wherever it exists: faster at every sweep
+                // size, by 1-2 % at a million sets and 8-15 % at one or two
+                // waves per SIMD)
+                if (variant == 4 || variant == 0) {
+                    gr4j_opt_kernel<UH, Q.value, S.value, E.value>
+                        <<<grid, block, 0, st>>>(
+                            days, T, s_init, r_init, params, N, d_plan,
+                            force_lds, qsim, s_store, r_store, ld, qobs, sse);
+                    return;
+                }
+            }
+            if constexpr (!std::is_same<UH, UhLds>::value) {
+                if (variant == 3) {
+                    gr4j_kernel<UH, Q.value, S.value, E.value, 4>
+                        <<<dim3((unsigned)rr_ceil_div(waves, 4)),
+                           dim3(4 * RR_BLOCK), 0, st>>>(
+                            days, T, s_init, r_init, params, N, d_plan,
+                            force_lds, qsim, s_store, r_store, ld, qobs, sse);
+                    return;
+                }
+            }
             gr4j_kernel<UH, Q.value, S.value, E.value>
-                <<<grid, block,
-                   std::is_same<UH, UhLds>::value ? GR4J_LDS_BYTES : 0, st>>>(
+                <<<grid, block, lds, st>>>(
                     days, T, s_init, r_init, params, N, d_plan, force_lds,
                     qsim, s_store, r_store, ld, qobs, sse);
         });

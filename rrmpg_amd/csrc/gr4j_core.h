@@ -97,22 +97,24 @@ __device__ __forceinline__ lanemask_t gr4j_num_lanes(double a)
 
 // a / x for the per-lane invariant x; stores run dry, so exact zeros stay on
 // the fast form
+template <class V = CarefulVotes>
 __device__ __forceinline__ double gr4j_div_m(double a, lanemask_t a_ok,
                                              const InvDivisor &d,
-                                             lanemask_t d_ok)
+                                             lanemask_t d_ok, V &&votes = V())
 {
     double q = inv_div_core(a, d);
-    if (RR_ANY_OUTSIDE(a_ok & d_ok)) {
+    if (RR_VOTE(votes, a_ok & d_ok)) {
         const bool ok = gr4j_num_ok(a) && d.ok;
         const double exact = a / d.b;
         q = ok ? q : exact;
     }
     return q;
 }
+template <class V = CarefulVotes>
 __device__ __forceinline__ double gr4j_div(double a, const InvDivisor &d,
-                                           lanemask_t d_ok)
+                                           lanemask_t d_ok, V &&votes = V())
 {
-    return gr4j_div_m(a, gr4j_num_lanes(a), d, d_ok);
+    return gr4j_div_m(a, gr4j_num_lanes(a), d, d_ok, votes);
 }
 
 // _s_curve1 (gr4j_model.py:159-173); t is the integer ordinate index
@@ -160,10 +162,19 @@ template <int N1MAX>
 struct UhRegs {
     static constexpr int TIER = N1MAX;
     static constexpr int N2MAX = 2 * N1MAX + 1;
-    double u1[N1MAX], u2[N2MAX], o1[N1MAX], o2[N2MAX];
+    // the convolution slots; a struct of their own so that a kernel can keep
+    // TWO generations of them (the optimistic time loops: a day reads one and
+    // writes the other, and the day's start state survives until the day is
+    // known to be good -- OptimisticVotes, common.h)
+    struct Slots {
+        double u1[N1MAX], u2[N2MAX];
+    };
+    Slots z;                       // the in-place kernels' one generation
+    double o1[N1MAX], o2[N2MAX];
     int n1, n2;
 
-    __device__ __forceinline__ void init(double x4)
+    __device__ __forceinline__ void init(double x4) { init(x4, z); }
+    __device__ __forceinline__ void init(double x4, Slots &u)
     {
         n1 = gr4j_num_uh1(x4);
         n2 = gr4j_num_uh2(x4);
@@ -177,7 +188,7 @@ struct UhRegs {
             const double cur = gr4j_s_curve1(j + 1, x4);
             o1[j] = (j < n1) ? cur - prev : 0.0;
             prev = cur;
-            u1[j] = 0.0;
+            u.u1[j] = 0.0;
         }
         prev = 0.0;
 #pragma unroll
@@ -185,7 +196,7 @@ struct UhRegs {
             const double cur = gr4j_s_curve2(j + 1, x4);
             o2[j] = (j < n2) ? cur - prev : 0.0;
             prev = cur;
-            u2[j] = 0.0;
+            u.u2[j] = 0.0;
         }
     }
 
@@ -204,8 +215,12 @@ struct UhRegs {
     // with per-lane selects.  A non-finite p (never in a sane run) leaves the real slots
     // right as well -- they only read padding that was still zero -- but
     // writes 0*NaN into the padding, so on such days the wave re-zeroes it.
-    __device__ __forceinline__ void route(double p1, double p2, double &head1,
-                                          double &head2)
+    // `in` -> `out`: two generations, or the same object (slot j is written
+    // after slot j + 1 was read and is not read again).
+    template <class V = CarefulVotes>
+    __device__ __forceinline__ void route(const Slots &in, Slots &out,
+                                          double p1, double p2, double &head1,
+                                          double &head2, V &&votes = V())
     {
         // (uh_fma: a three-address v_fma_f64 written out, because hipcc
         // turns __builtin_fma into the two-address v_fmac on the NEXT slot's
@@ -213,30 +228,37 @@ struct UhRegs {
         // per slot at the end of every day)
 #pragma unroll
         for (int j = 0; j < N1MAX; ++j)
-            u1[j] = (j + 1 < N1MAX)
-                ? uh_fma(o1[j], p1, u1[(j + 1 < N1MAX) ? j + 1 : j])
+            out.u1[j] = (j + 1 < N1MAX)
+                ? uh_fma(o1[j], p1, in.u1[(j + 1 < N1MAX) ? j + 1 : j])
                 : o1[j] * p1;
 #pragma unroll
         for (int j = 0; j < N2MAX; ++j)
-            u2[j] = (j + 1 < N2MAX)
-                ? uh_fma(o2[j], p2, u2[(j + 1 < N2MAX) ? j + 1 : j])
+            out.u2[j] = (j + 1 < N2MAX)
+                ? uh_fma(o2[j], p2, in.u2[(j + 1 < N2MAX) ? j + 1 : j])
                 : o2[j] * p2;
         // (p1 = 0.9 p and p2 = 0.1 p of the same p: one is finite iff the
         // other is)
         const lanemask_t finite = lanes_finite(p1);
-        if (RR_ANY_OUTSIDE(finite)) {
+        if (RR_VOTE(votes, finite)) {
             // (lengths made opaque: hipcc otherwise hoists the 3 * N1MAX + 1
             // slot masks `j < n` of this never-taken path out of the time
             // loop and parks them in that many SGPR pairs)
             int m1 = n1, m2 = n2;
             asm volatile("" : "+v"(m1), "+v"(m2));
 #pragma unroll
-            for (int j = 0; j < N1MAX; ++j) u1[j] = (j < m1) ? u1[j] : 0.0;
+            for (int j = 0; j < N1MAX; ++j)
+                out.u1[j] = (j < m1) ? out.u1[j] : 0.0;
 #pragma unroll
-            for (int j = 0; j < N2MAX; ++j) u2[j] = (j < m2) ? u2[j] : 0.0;
+            for (int j = 0; j < N2MAX; ++j)
+                out.u2[j] = (j < m2) ? out.u2[j] : 0.0;
         }
-        head1 = u1[0];
-        head2 = u2[0];
+        head1 = out.u1[0];
+        head2 = out.u2[0];
+    }
+    __device__ __forceinline__ void route(double p1, double p2, double &head1,
+                                          double &head2)
+    {
+        route(z, z, p1, p2, head1, head2);
     }
 };
 
@@ -247,6 +269,7 @@ struct UhRegs {
 //   then the same again for the ordinates.
 struct UhLds {
     static constexpr int TIER = 0;
+    struct Slots {};     // (in place only: no second generation in LDS)
     double *base;        // this lane's column: base[slot * RR_BLOCK]
     int n1cap, n2cap;    // launch-wide capacities (host scan of max x4)
     int n1, n2;          // this lane's lengths
@@ -436,12 +459,13 @@ constexpr int gr4j_r4_consts()
               std::is_same<UH, UhRegs<5>>::value))) ? 1 : 2;
 }
 
-template <bool GUARD_BY_VOTE = true>
-__device__ __forceinline__ double gr4j_inv_fourth_root(double b)
+template <bool GUARD_BY_VOTE = true, class V = CarefulVotes>
+__device__ __forceinline__ double gr4j_inv_fourth_root(double b,
+                                                       V &&votes = V())
 {
     if constexpr (!GUARD_BY_VOTE) return inv_fourth_root(b);
     double y = inv_fourth_root_core3(b);
-    if (RR_ANY_OUTSIDE(lanes_of_class(b, 0x100))) {
+    if (RR_VOTE(votes, lanes_of_class(b, 0x100))) {
         asm volatile("");                   // keep this a branch
         y = (b < __builtin_inf()) ? y : ((b != b) ? b : 0.0);
     }
@@ -451,8 +475,8 @@ __device__ __forceinline__ double gr4j_inv_fourth_root(double b)
 // FAST_ROOT = false keeps the compiler's IEEE sqrt inline: measured faster in
 // the UhRegs<10> kernels (2 waves per SIMD, every register taken -- there the
 // extra branch costs more than the 7 instructions it saves: 233.7 vs 226.8 ms).
-template <bool FAST_ROOT = true>
-__device__ __forceinline__ double pow_3_5(double x)
+template <bool FAST_ROOT = true, class V = CarefulVotes>
+__device__ __forceinline__ double pow_3_5(double x, V &&votes = V())
 {
     if constexpr (!FAST_ROOT) return x * x * x * sqrt(x);
     // +0, positive subnormal or positive normal: one class test
@@ -463,7 +487,7 @@ __device__ __forceinline__ double pow_3_5(double x)
     double xr;
     asm("v_max_f64 %0, %1, %2" : "=v"(xr) : "v"(x), "s"(0x1p-500));
     double root = fast_sqrt_core(xr);
-    if (RR_ANY_OUTSIDE(ok)) {
+    if (RR_VOTE(votes, ok)) {
         // (the empty asm keeps this a branch: hipcc would otherwise evaluate
         // the IEEE sqrt for every wave and select)
         asm volatile("");
@@ -516,11 +540,21 @@ __device__ __attribute__((noinline)) double gr4j_store_change_reference(
 struct Gr4jNoHook {
     __device__ __forceinline__ void operator()() const {}
 };
-template <class UH, int CONSTS = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook>
-__device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
-                                                double &r, UH &uh, double net,
-                                                bool wet, lanemask_t net_m,
-                                                MID &&mid = MID())
+// The day is cut where its data flow is feed-forward: the PRODUCTION half
+// (net rainfall, production store, percolation, :89-123) only ever hands the
+// routed amount p_r to the ROUTING half (hydrographs, exchange, routing
+// store, discharge, :126-154), which never feeds anything back.  The
+// wave-specialised kernels (gr4j.hip gr4j_pipe_kernel, cemaneige.hip) run
+// the halves in different waves of a workgroup, a few days apart; everybody
+// else calls them back to back through gr4j_step_net.  Same instruction
+// sequence either way, so the results are bit-identical.
+template <class UH, int CONSTS = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook,
+          class V = CarefulVotes>
+__device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
+                                                  double net, bool wet,
+                                                  lanemask_t net_m,
+                                                  MID &&mid = MID(),
+                                                  V &&votes = V())
 {
     // tanh(net/x1) = E / D (fastmath.h: E = expm1(2a)/2, D = E + 1); its
     // quotient is folded into the store update's own:
@@ -528,7 +562,7 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     // one division per day instead of two.
     double E, D;
     fast_tanh_parts<CONSTS>(
-        gr4j_div_m(net, net_m, P.inv_x1, P.x1_m), E, D);
+        gr4j_div_m(net, net_m, P.inv_x1, P.x1_m, votes), E, D);
     // One vote covers the 3-FMA quotient s/x1 and the folded form: with
     // 0 <= s < 2^196 and |x1| in [2^-100, 2^100] (invdiv.h) the quotient is
     // RN(s/x1) (gr4j_num_lanes) and |s/x1| <= 2^296, so c*E and k*E (E <= 1.2e17,
@@ -547,7 +581,7 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
     const lanemask_t fast = gr4j_num_lanes(s) & P.x1_m &
                             RR_LANES(fabs(den) >= 0x1p-100);
     double frac = fast_div_core(c * E, den);
-    if (RR_ANY_OUTSIDE(fast)) {
+    if (RR_VOTE(votes, fast)) {
         double exact;
         if constexpr (std::is_same<UH, UhRegs<10>>::value) {
             // measured: out of line is 2 % faster in these kernels, 1-2 %
@@ -575,9 +609,9 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
         excess = 0.0;
     }
     // percolation (:117); **4 is two squarings
-    const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1, P.x1_m);
+    const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1, P.x1_m, votes);
     const double v2 = v * v;
-    constexpr bool votes = !std::is_same<UH, UhRegs<10>>::value;
+    constexpr bool by_vote = !std::is_same<UH, UhRegs<10>>::value;
     // v <= 4/9 while the store is within its capacity: the root of 1 + v**4
     // is then a degree-7 polynomial (fastmath.h); a wave with a lane beyond
     // that takes the general form for those lanes.  The polynomial's argument
@@ -593,36 +627,73 @@ __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
         const double u = b1 - 1;
         root = inv_fourth_root_1p_small<gr4j_r4_consts<UH, CONSTS>()>(u);
         const lanemask_t small = RR_LANES(u <= FP_R4_UMAX);
-        if (RR_ANY_OUTSIDE(small)) {
+        if (RR_VOTE(votes, small)) {
             asm volatile("");                       // keep this a branch
-            const double general = gr4j_inv_fourth_root<votes>(b1);
+            const double general = gr4j_inv_fourth_root<by_vote>(b1);
             root = (u <= FP_R4_UMAX) ? root : general;
         }
     } else {
-        root = gr4j_inv_fourth_root<votes>(b1);
+        root = gr4j_inv_fourth_root<by_vote>(b1, votes);
     }
     const double perc = sn * (1 - root);
     mid();
-    sn = sn - perc;                                             // :120
-    const double p_r = perc + excess;                           // :123
+    s = sn - perc;                                              // :120
+    return perc + excess;                                       // p_r, :123
+}
+
+// `in` -> `out`: the hydrograph slots' two generations (UhRegs::Slots), or
+// the same object.
+template <class UH, class V = CarefulVotes>
+__device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
+                                               UH &uh,
+                                               const typename UH::Slots &in,
+                                               typename UH::Slots &out,
+                                               double p_r, V &&votes = V())
+{
+    constexpr bool by_vote = !std::is_same<UH, UhRegs<10>>::value;
     const double p_r_uh1 = 0.9 * p_r;                           // :126-127
     const double p_r_uh2 = 0.1 * p_r;
 
     double head1, head2;
-    uh.route(p_r_uh1, p_r_uh2, head1, head2);                   // :130-136
+    if constexpr (std::is_same<UH, UhLds>::value)
+        uh.route(p_r_uh1, p_r_uh2, head1, head2);               // :130-136
+    else
+        uh.route(in, out, p_r_uh1, p_r_uh2, head1, head2, votes);
 
     const double gw_exchange =
-        P.x2 * pow_3_5<votes>(gr4j_div(r, P.inv_x3, P.x3_m));   // :139
+        P.x2 * pow_3_5<by_vote>(gr4j_div(r, P.inv_x3, P.x3_m, votes),
+                                votes);                         // :139
     double rn = nb_max(0.0, r + head1 + gw_exchange);           // :142
-    const double w = gr4j_div(rn, P.inv_x3, P.x3_m);
+    const double w = gr4j_div(rn, P.inv_x3, P.x3_m, votes);
     const double w2 = w * w;
     const double q_r =
-        rn * (1 - gr4j_inv_fourth_root<votes>(1 + w2 * w2));    // :145
+        rn * (1 - gr4j_inv_fourth_root<by_vote>(1 + w2 * w2, votes)); // :145
     rn = rn - q_r;                                              // :148
     const double q_d = nb_max(0.0, head2 + gw_exchange);        // :151
-    s = sn;
     r = rn;
     return q_r + q_d;                                           // :154
+}
+template <class UH>
+__device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
+                                               UH &uh, double p_r)
+{
+    if constexpr (std::is_same<UH, UhLds>::value) {
+        typename UH::Slots none;
+        return gr4j_routing<UH>(P, r, uh, none, none, p_r);
+    } else {
+        return gr4j_routing<UH>(P, r, uh, uh.z, uh.z, p_r);
+    }
+}
+
+template <class UH, int CONSTS = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook>
+__device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
+                                                double &r, UH &uh, double net,
+                                                bool wet, lanemask_t net_m,
+                                                MID &&mid = MID())
+{
+    const double p_r = gr4j_production<UH, CONSTS>(
+        P, s, net, wet, net_m, static_cast<MID &&>(mid));
+    return gr4j_routing<UH>(P, r, uh, p_r);
 }
 
 template <class UH, int CONSTS = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook>

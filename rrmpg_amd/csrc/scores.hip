@@ -8,6 +8,8 @@
 // (and of sums over the observations alone, taken on the host), so one pass
 // over qsim[T][ld] produces them for every parameter set at once:
 //     sums[i] = { sum q, sum q^2, sum q*obs, sum (obs - q)^2 }
+// (rr_column_sums_shifted_dev: the first three about a shift c, i.e. of q - c
+// and obs - c, which keeps variance / covariance free of cancellation)
 // One lane per column, rows streamed top to bottom: each wave reads 512
 // contiguous bytes per row -- a pure HBM-bandwidth kernel (8 B per
 // model-timestep read, nothing written but 32 B per set).  Accumulation is
@@ -19,7 +21,7 @@
 
 __global__ __launch_bounds__(256) void column_sums_kernel(
     const double *__restrict__ qsim, int64_t ld, const double *__restrict__ obs,
-    int64_t T, int64_t N, double *__restrict__ sums)
+    int64_t T, int64_t N, double shift, double *__restrict__ sums)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -30,9 +32,13 @@ __global__ __launch_bounds__(256) void column_sums_kernel(
         const double q = __builtin_nontemporal_load(p);
         const double o = obs[t];            // wave-uniform -> scalar load
         const double d = o - q;
-        s_q += q;
-        s_qq += q * q;
-        s_qo += q * o;
+        // (moments about `shift`, not about 0: with shift = mean(obs) the
+        // variance and covariance the host derives from them do not cancel
+        // for a series that is large and nearly constant)
+        const double qc = q - shift, oc = o - shift;
+        s_q += qc;
+        s_qq += qc * qc;
+        s_qo += qc * oc;
         s_dd += d * d;
         p += ld;
     }
@@ -44,6 +50,14 @@ extern "C" int rr_column_sums_dev(const double *qsim, int64_t ld,
                                   const double *obs, int64_t T, int64_t N,
                                   double *sums, void *stream)
 {
+    return rr_column_sums_shifted_dev(qsim, ld, obs, T, N, 0.0, sums, stream);
+}
+
+extern "C" int rr_column_sums_shifted_dev(const double *qsim, int64_t ld,
+                                          const double *obs, int64_t T,
+                                          int64_t N, double shift,
+                                          double *sums, void *stream)
+{
     int rc = rr_check_common("rr_column_sums_dev", T, N, ld, qsim, obs, sums);
     if (rc != RR_OK) return rc;
     if (N == 0) return RR_OK;
@@ -53,7 +67,8 @@ extern "C" int rr_column_sums_dev(const double *qsim, int64_t ld,
     }
     hipLaunchKernelGGL(column_sums_kernel,
                        dim3((unsigned)rr_ceil_div(N, 256)), dim3(256), 0,
-                       (hipStream_t)stream, qsim, ld, obs, T, N, sums);
+                       (hipStream_t)stream, qsim, ld, obs, T, N, shift,
+                       sums);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -560,11 +560,14 @@ def snow_layers(prec, mean_temp, min_temp, max_temp, met_station_height,
     return tuple(outs)
 
 
-def column_sums(qsim, obs):
+def column_sums(qsim, obs, shift=0.0):
     """Per-column {sum q, sum q^2, sum q*obs, sum (obs-q)^2} of a resident
     discharge tensor qsim [T, N] against obs [T] (both on the GPU), in one
-    HBM-bandwidth-bound pass (rr_column_sums_dev).  Feed the result (moved to
-    the host) to rrmpg_amd.utils.metrics.scores_from_sums."""
+    HBM-bandwidth-bound pass (rr_column_sums_shifted_dev).  Feed the result
+    (moved to the host) to rrmpg_amd.utils.metrics.scores_from_sums with the
+    same `shift`: the first three sums are taken of q - shift and obs - shift,
+    and shift = mean(obs) keeps the variance / correlation scores (KGE,
+    alpha, r) free of cancellation for large, nearly constant series."""
     lib = _lib.load()
     if qsim.dim() != 2 or qsim.stride(1) != 1 or qsim.dtype != torch.float64:
         raise ValueError("qsim must be a float64 [T, N] tensor with "
@@ -574,11 +577,10 @@ def column_sums(qsim, obs):
     if obs.numel() != t:
         raise ValueError("Arrays must have the same size.")
     sums = torch.empty((n, 4), dtype=torch.float64, device=qsim.device)
-    rc = lib.rr_column_sums_dev(qsim.data_ptr(), qsim.stride(0),
-                                obs.data_ptr(), t, n, sums.data_ptr(),
-                                torch.cuda.current_stream(
-                                    qsim.device).cuda_stream)
-    _lib.check(rc, "rr_column_sums_dev")
+    rc = lib.rr_column_sums_shifted_dev(
+        qsim.data_ptr(), qsim.stride(0), obs.data_ptr(), t, n, float(shift),
+        sums.data_ptr(), torch.cuda.current_stream(qsim.device).cuda_stream)
+    _lib.check(rc, "rr_column_sums_shifted_dev")
     return sums
 
 

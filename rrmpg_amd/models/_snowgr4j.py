@@ -177,13 +177,20 @@ class QScaScorer:
         ens.run(block, qsim, storages=st)
         ens.check()
         key = "mse" if loss_metric == "mse" else "kge"
-        sums = self.rrdev.column_sums(qsim, self.obs_d).cpu().numpy()
-        part = scores_from_sums(sums, self.obs)[key]
+        # only the score that is asked for: the MSE is defined for any
+        # observations (an NDSI band that is constantly 0, a constant
+        # discharge), as calc_mse is in the reference's loss
+        # (cemaneigehystgr4j.py:661-667); the KGE raises for them as
+        # calc_kge does.  Moments about mean(obs) (column_sums' shift).
+        def score(series, obs_d, obs_h):
+            shift = float(np.mean(obs_h))
+            sums = self.rrdev.column_sums(series, obs_d, shift).cpu().numpy()
+            return scores_from_sums(sums, obs_h, only=(key,),
+                                    shift=shift)[key]
+        part = score(qsim, self.obs_d, self.obs)
         total = 0.75 * (part if key == "mse" else 1 - part)
         for b in range(5):
-            sums = self.rrdev.column_sums(st["sca"][:, b, :],
-                                          self.ndsi_d[b]).cpu().numpy()
-            part = scores_from_sums(sums, self.ndsi[b])[key]
+            part = score(st["sca"][:, b, :], self.ndsi_d[b], self.ndsi[b])
             total = total + 0.05 * (part * 1e4 if key == "mse" else 1 - part)
         return total
 

@@ -127,38 +127,67 @@ def calc_r(obs, sim):
     return pearsonr(obs, sim)
 
 
-def scores_from_sums(sums, obs):
+ALL_SCORES = ("mse", "rmse", "nse", "kge", "alpha", "beta", "r")
+
+
+def scores_from_sums(sums, obs, only=None, shift=0.0):
     """Every score of this module for N simulated series at once, from the
     per-column sums the GPU produces in one pass (rrmpg_amd.device.
-    column_sums: {sum q, sum q^2, sum q*obs, sum (obs-q)^2} per column).
+    column_sums: {sum q, sum q^2, sum q*obs, sum (obs-q)^2} per column, the
+    first three about `shift` -- pass the value given to column_sums).
 
-    Returns a dict of arrays [N]: mse, rmse, nse, kge, alpha, beta, r.
-    Same definitions (and the same RuntimeErrors for degenerate
-    observations) as calc_mse / calc_rmse / calc_nse / calc_kge /
-    calc_alpha_nse / calc_beta_nse / calc_r.
+    Returns a dict of arrays [N]: mse, rmse, nse, kge, alpha, beta, r -- or
+    only those named in `only`.  Same definitions as calc_mse / calc_rmse /
+    calc_nse / calc_kge / calc_alpha_nse / calc_beta_nse / calc_r, and, like
+    them, a score raises RuntimeError for observations it is not defined for
+    (NSE: all equal; KGE / alpha / beta: standard deviation or mean 0) only
+    when it is asked for: `only=("mse",)` accepts any observations, as
+    calc_mse does (reference: rrmpg/utils/metrics.py:110-136).
     """
     obs = validate_array_input(obs, np.float64, 'obs')
     sums = np.asarray(sums, dtype=np.float64).reshape(-1, 4)
+    want = ALL_SCORES if only is None else tuple(only)
+    unknown = set(want) - set(ALL_SCORES)
+    if unknown:
+        raise ValueError("unknown score(s): %s" % sorted(unknown))
     t = obs.size
     s_q, s_qq, s_qo, s_dd = sums.T
+    out = {}
+    mse = s_dd / t
+    if "mse" in want:
+        out["mse"] = mse
+    if "rmse" in want:
+        out["rmse"] = np.sqrt(mse)
+    if "nse" in want:
+        out["nse"] = 1 - s_dd / _nse_denominator(obs)
+    moments = [k for k in ("kge", "alpha", "beta", "r") if k in want]
+    if not moments:
+        return out
     mean_obs, std_obs = np.mean(obs), np.std(obs)
-    if mean_obs == 0:
+    if mean_obs == 0 and ("kge" in want or "beta" in want):
         raise RuntimeError("KGE not definied if the mean of the observations "
                            "equals 0.")
-    if std_obs == 0:
+    if std_obs == 0 and ("kge" in want or "alpha" in want or "beta" in want):
         raise RuntimeError("KGE not definied if the standard deviation of "
                            "the observations equals 0.")
-    mean_q = s_q / t
-    var_q = np.maximum(s_qq / t - mean_q ** 2, 0.0)
+    # moments about `shift` (c): mean and covariance move with it, the
+    # variance does not
+    mean_qc = s_q / t                          # mean(q) - c
+    mean_oc = mean_obs - shift
+    mean_q = mean_qc + shift
+    var_q = np.maximum(s_qq / t - mean_qc ** 2, 0.0)
     std_q = np.sqrt(var_q)
-    cov = s_qo / t - mean_q * mean_obs
+    cov = s_qo / t - mean_qc * mean_oc
     with np.errstate(divide="ignore", invalid="ignore"):
         r = cov / (std_q * std_obs)
-    alpha = std_q / std_obs
-    beta = mean_q / mean_obs
-    mse = s_dd / t
-    return dict(mse=mse, rmse=np.sqrt(mse),
-                nse=1 - s_dd / _nse_denominator(obs),
-                kge=1 - np.sqrt((r - 1) ** 2 + (alpha - 1) ** 2
-                                + (beta - 1) ** 2),
-                alpha=alpha, beta=(mean_q - mean_obs) / std_obs, r=r)
+        alpha = std_q / std_obs
+        if "kge" in want:
+            out["kge"] = 1 - np.sqrt((r - 1) ** 2 + (alpha - 1) ** 2
+                                     + (mean_q / mean_obs - 1) ** 2)
+        if "alpha" in want:
+            out["alpha"] = alpha
+        if "beta" in want:
+            out["beta"] = (mean_q - mean_obs) / std_obs
+        if "r" in want:
+            out["r"] = r
+    return out

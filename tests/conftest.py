@@ -62,3 +62,14 @@ def fused_variant(request):
     from rrmpg_amd import _lib
     with _lib.debug_option("fused_variant", request.param):
         yield request.param
+
+
+# The GR4J kernel: 1 = one wave per 64 sets (large sweeps), 2 = the
+# wave-specialised kernel (production / routing halves of the day in two
+# waves of a workgroup, an LDS ring between them; small sweeps), 0 = the
+# library's own choice by sweep size.
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["auto", "one-wave", "two-waves", "four-wave-groups", "optimistic"])
+def gr4j_variant(request):
+    from rrmpg_amd import _lib
+    with _lib.debug_option("gr4j_variant", request.param):
+        yield request.param

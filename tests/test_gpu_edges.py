@@ -39,7 +39,7 @@ def _padded(torch, t, n, pad):
 
 
 @pytest.mark.parametrize("t", [1, 2, 3, 400])
-def test_hbv_gr4j_abc_edge_shapes(env, oracle, t, hbv_variant):
+def test_hbv_gr4j_abc_edge_shapes(env, oracle, t, hbv_variant, gr4j_variant):
     torch, rrdev, syn, models = env
     f = syn.make_forcing(max(t, 2))
     f = {k: (v[:t] if getattr(v, "shape", (0,))[0] >= t and k not in

@@ -173,7 +173,7 @@ def test_hbvedu_fuzz(models, oracle, hbv_variant):
     assert (amp.max(axis=0)[1::2] < 1e-9).mean() > 0.5   # most wild ones too
 
 
-def test_gr4j_fuzz(models, oracle):
+def test_gr4j_fuzz(models, oracle, gr4j_variant):
     g = golden("syn_gr4j")
     rng = np.random.default_rng(101 + 1000 * SEED)
     lo, hi = np.array([100, -5, 20, 1.1]), np.array([1200, 3, 300, 2.9])
@@ -533,3 +533,21 @@ def test_kernel_variants_agree_bit_for_bit(models):
             base = out
         for a, b in zip(out, base):
             assert np.array_equal(a, b), "fused variant %d" % v
+    # GR4J: one wave per 64 sets / production and routing in two waves
+    from rrmpg_amd.models import gr4j as gmod
+    lo = np.array([10, -5, 20, 0.5])
+    hi = np.array([1200, 3, 300, 4.9])
+    for hi_x4 in (2.9, 4.9):            # both register tiers with a pipe form
+        hi[3] = hi_x4
+        flat = rng.uniform(lo, hi, (n, 4))
+        rec = _records(models.GR4J, flat)
+        qobs = rng.uniform(0, 3, t)
+        base = None
+        for v in (1, 2, 3, 4, 0):
+            with _lib.debug_option("gr4j_variant", v):
+                out, sse = gmod._run(h["layer_prec"][:t, 0], h["etp"][:t], 0.4,
+                                     0.5, rec, True, True, qobs)
+            if base is None:
+                base = list(out) + [sse]
+            for a, b in zip(list(out) + [sse], base):
+                assert np.array_equal(a, b), "GR4J variant %d" % v

@@ -269,6 +269,18 @@ def test_next_tier_fit_losses(models):
         one = hmod._loss_Q_SCA(Xpop[:, 1], obs, layers, ndsi, inits, metric,
                                scorer)
         assert abs(one - dev[1]) <= 1e-12 * abs(dev[1])
+    # observations no KGE is defined for -- an NDSI band that is constantly 0
+    # (a snow-free low band), a constant band -- are fine for the MSE loss, as
+    # for the reference's calc_mse (cemaneigehystgr4j.py:661-667), and raise
+    # calc_kge's RuntimeError for the KGE loss on either path
+    flat_ndsi = (np.zeros(t), np.full(t, 40.0)) + ndsi[2:]
+    sc_flat = core.QScaScorer(False, layers, None, inits, obs, flat_ndsi)
+    host = hmod._loss_Q_SCA(Xpop, obs, layers, flat_ndsi, inits, "mse")
+    dev = hmod._loss_Q_SCA(Xpop, obs, layers, flat_ndsi, inits, "mse", sc_flat)
+    assert np.max(np.abs(dev - host) / np.abs(host)) < 1e-9
+    for sc in (None, sc_flat):
+        with pytest.raises(RuntimeError, match="KGE not definied"):
+            hmod._loss_Q_SCA(Xpop, obs, layers, flat_ndsi, inits, "kge", sc)
     gi = golden("syn_cemaneigehystgr4jice")
     Xi2 = np.stack([gi["params"][1], gi["params"][4]], 1)
     sc_i = core.QScaScorer(True, layers, gi["frac_ice"], inits, obs, ndsi)

@@ -180,7 +180,7 @@ def test_nan_propagation_matches_reference(models, hbv_variant):
 
 
 # ------------------------------------------------------------------ GR4J
-def test_gr4j_kat_excel(models):
+def test_gr4j_kat_excel(models, gr4j_variant):
     g = golden("kat_gr4j")
     m = models.GR4J(params=dict(zip(models.GR4J._param_list,
                                     g["params"].tolist())))
@@ -190,7 +190,7 @@ def test_gr4j_kat_excel(models):
     assert rel_err(qsim, g["ref_qsim"]) < RTOL
 
 
-def test_gr4j_golden_both_uh_tiers(models, oracle):
+def test_gr4j_golden_both_uh_tiers(models, oracle, gr4j_variant):
     g = golden("syn_gr4j")
     flat = g["params"]
     i = g["inits"]
@@ -218,7 +218,7 @@ def test_gr4j_golden_both_uh_tiers(models, oracle):
     assert (q.sum(0) > 0).all()
 
 
-def test_gr4j_random_vs_oracle_and_limits(models, oracle):
+def test_gr4j_random_vs_oracle_and_limits(models, oracle, gr4j_variant):
     g = golden("syn_gr4j")
     rng = np.random.default_rng(21)
     lo, hi = np.array([100, -5, 20, 1.1]), np.array([1200, 3, 300, 2.9])
@@ -249,7 +249,7 @@ def test_gr4j_random_vs_oracle_and_limits(models, oracle):
                                params=_records(models.GR4J, bad))
 
 
-def test_gr4j_zero_rain(models):
+def test_gr4j_zero_rain(models, gr4j_variant):
     m = models.GR4J()
     qsim = m.simulate(prec=np.zeros(100), etp=np.random.uniform(0, 3, 100),
                       s_init=0, r_init=0)

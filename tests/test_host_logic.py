@@ -333,6 +333,44 @@ def test_metrics_known_answers():
                        [calc_nse(obs, sim[:, 0]), calc_nse(obs, sim[:, 1])])
 
 
+def test_scores_from_sums_asks_only_for_what_is_defined():
+    """scores_from_sums: every score from the four column sums (about any
+    shift); a score raises for degenerate observations only when it is asked
+    for, as the calc_* functions do."""
+    from rrmpg_amd.utils import metrics as M
+    rng = np.random.default_rng(3)
+    obs = rng.uniform(0.5, 3, 200)
+    sim = obs[:, None] * rng.uniform(0.8, 1.2, (200, 5)) + rng.normal(
+        0, 0.1, (200, 5))
+    for shift in (0.0, float(obs.mean())):
+        qc, oc = sim - shift, obs - shift
+        sums = np.stack([qc.sum(0), (qc * qc).sum(0), (qc * oc[:, None]).sum(0),
+                         ((obs[:, None] - sim) ** 2).sum(0)], 1)
+        sc = M.scores_from_sums(sums, obs, shift=shift)
+        assert set(sc) == set(M.ALL_SCORES)
+        for j in range(5):
+            for name, fn in [("mse", M.calc_mse), ("rmse", M.calc_rmse),
+                             ("nse", M.calc_nse), ("kge", M.calc_kge),
+                             ("alpha", M.calc_alpha_nse),
+                             ("beta", M.calc_beta_nse)]:
+                assert abs(sc[name][j] - fn(obs, sim[:, j])) < 1e-11, name
+            assert abs(sc["r"][j] - M.calc_r(obs, sim[:, j])[0]) < 1e-11
+    zero = np.zeros(200)
+    sums0 = np.stack([sim.sum(0), (sim * sim).sum(0), 0 * sim.sum(0),
+                      (sim ** 2).sum(0)], 1)
+    only = M.scores_from_sums(sums0, zero, only=("mse", "rmse"))
+    assert set(only) == {"mse", "rmse"}
+    assert np.allclose(only["mse"], [M.calc_mse(zero, sim[:, j])
+                                     for j in range(5)])
+    for key in ("kge", "nse", "alpha", "beta"):
+        with pytest.raises(RuntimeError):
+            M.scores_from_sums(sums0, zero, only=(key,))
+    with pytest.raises(RuntimeError):
+        M.scores_from_sums(sums0, zero)
+    with pytest.raises(ValueError, match="unknown score"):
+        M.scores_from_sums(sums0, obs, only=("nash",))
+
+
 def test_array_checks():
     assert not check_for_negatives(np.array([1, 2, 3, 4, 5], dtype=np.float64))
     assert check_for_negatives(np.array([1, 2, -3, 4, 5], dtype=np.float64))
@@ -370,7 +408,9 @@ def test_debug_options_and_cache_release_need_no_gpu():
     assert lib.rr_debug_get_option(opt["hbv_variant"]) == -1
     assert lib.rr_debug_set_option(opt["hbv_variant"], 7) == -4    # RR_E_PARAM
     assert lib.rr_debug_get_option(opt["fused_variant"]) == 0
-    assert lib.rr_debug_set_option(opt["fused_variant"], 3) == -4
+    assert lib.rr_debug_set_option(opt["fused_variant"], 4) == -4
+    assert lib.rr_debug_get_option(opt["gr4j_variant"]) == 0
+    assert lib.rr_debug_set_option(opt["gr4j_variant"], 5) == -4
     assert b"does not take" in lib.rr_last_error()
     assert lib.rr_debug_set_option(99, 0) == -4
     assert lib.rr_debug_get_option(99) == -2 ** 63
