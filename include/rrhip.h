@@ -106,9 +106,14 @@ int rr_release_cached_memory(void);
                                   * host threads scattering the staging ring
                                   * of a large gather into the caller's array */
 #define RR_OPT_FUSED_VARIANT   5 /* CemaneigeGR4J kernel: 0 by sweep size
-                                  * (default); 1 the many-waves kernel; 2 the
-                                  * small-sweep kernel (constants and melt
-                                  * thresholds in VGPRs) wherever it exists  */
+                                  * (default: 3 for at most two waves per
+                                  * SIMD, else 1); 1 the many-waves kernel; 2
+                                  * the small-sweep kernel (constants and melt
+                                  * thresholds in VGPRs) wherever it exists; 3
+                                  * the small-sweep kernel with an optimistic
+                                  * GR4J half (votes noted, the half redone if
+                                  * one failed); 4 the many-waves kernel with
+                                  * an optimistic GR4J half                   */
 #define RR_OPT_GR4J_VARIANT    6 /* GR4J kernel: 0 the library's choice
                                   * (default: the optimistic kernel where it
                                   * exists); 1 gr4j_kernel, one wave per 64

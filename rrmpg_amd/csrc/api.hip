@@ -49,7 +49,7 @@ extern "C" int rr_debug_set_option(int option, int64_t value)
     switch (option) {
     case RR_OPT_HBV_VARIANT: ok = value >= -1 && value <= 2; break;
     case RR_OPT_GR4J_FORCE_LDS: ok = value == 0 || value == 1; break;
-    case RR_OPT_FUSED_VARIANT: ok = value >= 0 && value <= 3; break;
+    case RR_OPT_FUSED_VARIANT: ok = value >= 0 && value <= 4; break;
     case RR_OPT_GR4J_VARIANT: ok = value >= 0 && value <= 4; break;
     case RR_OPT_MAX_BLOCK_COLS: ok = value >= 0; break;
     case RR_OPT_GATHER_THREADS: ok = value >= 0 && value <= 256; break;

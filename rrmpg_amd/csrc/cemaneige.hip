@@ -335,6 +335,149 @@ cemaneigegr4j_kernel(
     if (we && active) sse[i] = acc;
 }
 
+// ---- optimistic variant of the fused kernel -----------------------------------
+// gr4j.hip gr4j_opt_kernel's idea for the GR4J half of the coupled day: its
+// nine votes only note their lanes, the half runs straight through, and one
+// branch at its end redoes it -- from the untouched start state, every vote
+// decided on the spot as in cemaneigegr4j_kernel -- if a vote failed.  Both
+// stores and the hydrograph slots exist in two generations; a day reads one
+// and writes the other, two days per trip.  The snow routine in front of it
+// stays as it is, in place (measured: with its six votes optimistic as well
+// -- two generations of the ten snow states, the day's record fetched again
+// for the redo -- the kernel got 4-9 % slower, not faster).  Bit-identical to
+// cemaneigegr4j_kernel by construction.
+template <class UH>
+struct Gr4jGen {
+    double s, r;
+    typename UH::Slots u;
+};
+
+template <int L, class UH>
+constexpr bool coupled_has_optimistic()
+{
+    return L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
+                      std::is_same<UH, UhRegs<5>>::value);
+}
+
+#ifndef COUPLED_OPT_MINWAVES
+#define COUPLED_OPT_MINWAVES 3
+#endif
+template <int L, class UH, bool SMALL>
+__global__ __launch_bounds__(RR_BLOCK, (SMALL ? 2 : COUPLED_OPT_MINWAVES)) void
+cemaneigegr4j_opt_kernel(
+    CoupledOut /* read through the kernarg segment, see above */,
+    const double *__restrict__ days, const double *__restrict__ gtresh,
+    int64_t T, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *__restrict__ params,
+    int64_t N, const int *__restrict__ plan, int force_lds, int wq, int ws,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    int n1cap, n2cap;
+    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = i < N;
+    const double *p = params + (active ? i : N - 1) * 6;
+    const double CTG = p[0], Kf = p[1];
+    Gr4jPar P;
+    P.set(p[2], p[3], p[4], p[5]);
+    const double omc = 1 - CTG;
+    double G[L], eTG[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
+    const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
+    const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
+    typedef Gr4jGen<UH> Gen;
+    Gen A, B;
+    UH uh;
+    uh.init(P.x4, A.u);
+    A.s = s_init * P.x1;
+    A.r = r_init * P.x3;
+    double acc = 0.0;
+    const bool we = sse != nullptr;
+    constexpr int D = cema_record_len(L, true);
+    CemaGtRegs<L> gt_regs;
+    if constexpr (SMALL) cema_gt_to_regs<L>(gt_tab, gt_regs);
+    constexpr int CONSTS = SMALL ? GR4J_CONSTS_VGPR : GR4J_CONSTS_JIT;
+    const cema_rec_ptr_t drec = (cema_rec_ptr_t)days;
+    double day[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) day[k] = drec[k];
+    // (always_inline: with its three call sites per copy of the time loop
+    // the inliner would otherwise leave the day as a FUNCTION, its states
+    // and the day record passed through memory)
+    auto one_day = [&](auto first, auto sane, const Gen &in, Gen &out,
+                       int64_t t) __attribute__((always_inline)) {
+        const double liquid =
+            cema_day<L, decltype(first)::value, SMALL, decltype(sane)::value>(
+                day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
+                omc, Kf, G, eTG, &gt_regs);
+        const double etp_t = day[3 * L], qobs_t = day[D - 1];
+        auto fetch_next = [&]() {
+            // (day T-1 requests the spare record behind the last one)
+            cema_rec_ptr_t nx = drec + (t + 1) * D;
+            asm volatile("" : "+s"(nx));     // keeps the loads at this spot
+#pragma unroll
+            for (int k = 0; k < D; ++k) day[k] = nx[k];
+        };
+        const bool wet = liquid >= etp_t;                   // gr4j_model.py:89
+        const double net = wet ? liquid - etp_t : etp_t - liquid;
+        const lanemask_t net_m = gr4j_num_lanes(net);
+        OptimisticVotes votes;
+        double s = in.s, r = in.r;
+        double p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
+                                                 fetch_next, votes);
+        double q = gr4j_routing<UH>(P, r, uh, in.u, out.u, p_r, votes);
+        if (RR_VOTES_FAILED(votes)) {
+            // some lane left a fast form's domain: the GR4J day again from
+            // its untouched start state, every vote decided on the spot
+            asm volatile("");
+            s = in.s;
+            r = in.r;
+            p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m);
+            q = gr4j_routing<UH>(P, r, uh, in.u, out.u, p_r);
+        }
+        out.s = s;
+        out.r = r;
+        if (active && (wq | ws)) {
+            coupled_out_ptr_t po =
+                (coupled_out_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(po));     // keeps the load at this spot
+            CoupledOut o;                    // one s_load_dwordx16
+            o.qsim = po->qsim; o.G = po->G; o.eTG = po->eTG;
+            o.s_store = po->s_store; o.r_store = po->r_store;
+            const int64_t ld = po->ld;
+            if (wq) o.qsim[t * ld + i] = q;
+            if (ws) {
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    o.G[(t * L + l) * ld + i] = G[l];
+                    o.eTG[(t * L + l) * ld + i] = eTG[l];
+                }
+                o.s_store[t * ld + i] = s;
+                o.r_store[t * ld + i] = r;
+            }
+        }
+        if (we) {
+            const double d = qobs_t - q;   // the day's observation
+            acc = __builtin_fma(d, d, acc);
+        }
+    };
+    auto run = [&](auto sane) __attribute__((always_inline)) {
+        one_day(std::true_type{}, sane, A, B, 0);        // day 0, peeled
+        for (int64_t t = 1; t < T; t += 2) {
+            one_day(std::false_type{}, sane, B, A, t);
+            if (t + 1 < T) one_day(std::false_type{}, sane, A, B, t + 1);
+        }
+    };
+    // (two copies of the time loop, see cemaneige_kernel)
+    if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
+                          thermal_state_init))
+        run(std::true_type{});
+    else
+        run(std::false_type{});
+    if (we && active) sse[i] = acc;
+}
+
 // ---- more than RR_CEMANEIGE_MAX_LAYERS elevation layers ----------------------
 // Same day step with a run-time layer count; the per-layer snow states live
 // in an HBM scratch [2][L][N] (lane-contiguous, so every access is a coalesced
@@ -709,10 +852,40 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
     // (1024 SIMDs on an MI355X)
     const bool small = (int64_t)grid.x <= 2048 &&
                        rr_option(RR_OPT_FUSED_VARIANT) != 1;
+    const int fv = (int)rr_option(RR_OPT_FUSED_VARIANT);
     dispatch_layers((int)L, [&](auto LL) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
             const size_t lds = std::is_same<UH, UhLds>::value ? lds_bytes : 0;
+            if constexpr (coupled_has_optimistic<LL.value, UH>()) {
+                // 3: small-sweep form with an optimistic GR4J half -- the
+                // default for at most two waves per SIMD (125k sets: 14.35 ->
+                // 13.96 ms) --, 4: many-waves form with one (measured slower
+                // than the careful kernel, 97 vs 90 ms at a million sets:
+                // kept for measurements and tests)
+                if (fv == 3 || fv == 4 || (fv == 0 && small)) {
+                    const bool sm = fv == 3 || (fv == 0 && small);
+#ifndef COUPLED_OPT_NO_SMALL
+                    if (sm)
+                        cemaneigegr4j_opt_kernel<LL.value, UH, true>
+                            <<<grid, block, 0, st>>>(
+                                out, days, gt, T, snow_pack_init,
+                                thermal_state_init, s_init, r_init, params, N,
+                                d_plan, force_lds, qsim != nullptr,
+                                G != nullptr, qo, sse);
+#endif
+#ifndef COUPLED_OPT_NO_BIG
+                    if (!sm)
+                        cemaneigegr4j_opt_kernel<LL.value, UH, false>
+                            <<<grid, block, 0, st>>>(
+                                out, days, gt, T, snow_pack_init,
+                                thermal_state_init, s_init, r_init, params, N,
+                                d_plan, force_lds, qsim != nullptr,
+                                G != nullptr, qo, sse);
+#endif
+                    return;
+                }
+            }
             if constexpr (coupled_has_small<LL.value, UH>()) {
                 if (small || rr_option(RR_OPT_FUSED_VARIANT) == 2) {
                     cemaneigegr4j_kernel<LL.value, UH, true>

@@ -107,7 +107,14 @@ struct OptimisticVotes {
     }
     __device__ __forceinline__ bool any() const
     {
-        return (rr_exec() & ~good) != 0;
+        // (a wave-uniform value by construction -- every mask is a ballot --
+        // but not always to the compiler's divergence analysis, which then
+        // builds a per-lane branch around the redo block: said explicitly)
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)good);
+        const unsigned hi =
+            __builtin_amdgcn_readfirstlane((unsigned)(good >> 32));
+        const lanemask_t g = ((lanemask_t)hi << 32) | lo;
+        return (rr_exec() & ~g) != 0;
     }
 };
 

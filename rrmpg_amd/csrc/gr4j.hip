@@ -223,7 +223,8 @@ void gr4j_opt_kernel(
     f.net_ok = dp[0].net_ok;
     auto day = [&](const double s_in, const double r_in,
                    const typename UH::Slots &u_in, double &s_out,
-                   double &r_out, typename UH::Slots &u_out, int64_t k) {
+                   double &r_out, typename UH::Slots &u_out, int64_t k)
+        __attribute__((always_inline)) {
         const double net = f.net, qobs_k = f.qobs;
         const bool wet = f.wet != 0;
         const lanemask_t net_m = f.net_ok ? ~0ull : 0ull;
@@ -260,12 +261,10 @@ void gr4j_opt_kernel(
         }
         row += ld;
     };
-    int64_t k = 0;
-    for (; k + 1 < T; k += 2) {
+    for (int64_t k = 0; k < T; k += 2) {
         day(sa, ra, ua, sb, rb, ub, k);
-        day(sb, rb, ub, sa, ra, ua, k + 1);
+        if (k + 1 < T) day(sb, rb, ub, sa, ra, ua, k + 1);
     }
-    if (k < T) day(sa, ra, ua, sb, rb, ub, k);
     if (E && active) sse[i] = acc;
 }
 

@@ -84,11 +84,12 @@ typedef const CemaGt __attribute__((address_space(4))) *cema_gt_ptr_t;
 // c / L (the layer mean, np.mean's division by the size): L is a constant,
 // so the correctly rounded 3-FMA quotient of invdiv.h applies; c is a sum of
 // non-negative fluxes, anything else takes the IEEE division.
-template <int L>
-__device__ __forceinline__ double cema_layer_mean(double c)
+template <int L, class V = CarefulVotes>
+__device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 {
     const InvDivisor inv_L = {(double)L, 1.0 / (double)L, true};
-    return div_by_invariant_m(c, gr4j_num_mask(c), inv_L, ~0ull);
+    return div_by_invariant_m(c, gr4j_num_mask(c), inv_L, ~0ull, 0x1p900,
+                              votes);
 }
 
 // One day of the snow routine for all L layers of one parameter set
@@ -132,12 +133,17 @@ __device__ __forceinline__ void cema_gt_to_regs(cema_gt_ptr_t gt_tab,
 //     asking (the idle vote's second compare).
 // Three vector instructions per layer and day; bit-identical by construction
 // (and checked: every snow fixture is bit-exact in both forms).
-template <int L, bool FIRST, bool GT_REGS = false, bool SANE = false>
-__device__ __forceinline__ double cema_day(
+// G_in / eTG_in -> G / eTG: the states' two generations (the optimistic time
+// loops, common.h OptimisticVotes), or the same arrays (a layer's state is
+// read before it is written).
+template <int L, bool FIRST, bool GT_REGS = false, bool SANE = false,
+          class V = CarefulVotes>
+__device__ __forceinline__ double cema_day_io(
     const double *__restrict__ day, cema_gt_ptr_t gt_tab, lanemask_t gt_ok,
     double snow_pack_init, double thermal_state_init, double CTG,
-    double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L],
-    const CemaGtRegs<L> *gt_regs = nullptr)
+    double one_minus_CTG, double Kf, const double (&G_in)[L],
+    const double (&eTG_in)[L], double (&G)[L], double (&eTG)[L],
+    const CemaGtRegs<L> *gt_regs = nullptr, V &&votes = V())
 {
     double c = 0.0;
 #pragma unroll
@@ -148,8 +154,8 @@ __device__ __forceinline__ double cema_day(
             g = snow_pack_init;
             e = thermal_state_init;
         } else {
-            g = G[l] + snow;
-            e = CTG * eTG[l] + one_minus_CTG * temp;
+            g = G_in[l] + snow;
+            e = CTG * eTG_in[l] + one_minus_CTG * temp;
         }
         if (SANE && !FIRST) {
             // (written out: from C++ hipcc quiets the operand with a
@@ -206,12 +212,13 @@ __device__ __forceinline__ double cema_day(
             // `G / G_tresh if G < G_tresh else 1` is the hardware minimum of
             // the quotient and 1: a quotient of inf or NaN, G_tresh = 0, is
             // dropped for the 1 the reference takes there)
+            // (the quotient -- and its vote -- for every lane: a vote inside
+            // a per-lane conditional would make the vote mask a per-lane
+            // value)
+            const double gq = div_by_invariant_m(g, gr4j_num_mask(g), inv_gt,
+                                                 gt_ok, 0x1p900, votes);
             const double ratio =                           // :109-112
-                SANE ? rr_hw_min(div_by_invariant_m(g, gr4j_num_mask(g),
-                                                    inv_gt, gt_ok), 1.0)
-                : (g < inv_gt.b)
-                    ? div_by_invariant_m(g, gr4j_num_mask(g), inv_gt, gt_ok)
-                    : 1.0;
+                SANE ? rr_hw_min(gq, 1.0) : ((g < inv_gt.b) ? gq : 1.0);
             melt = (0.9 * ratio + 0.1) * pot_melt;         // :115
         }
         g = g - melt;                                      // :118
@@ -219,7 +226,19 @@ __device__ __forceinline__ double cema_day(
         eTG[l] = e;
         c = (l == 0) ? rain + melt : c + (rain + melt);    // :121, :125
     }
-    return cema_layer_mean<L>(c);
+    return cema_layer_mean<L>(c, votes);
+}
+
+template <int L, bool FIRST, bool GT_REGS = false, bool SANE = false>
+__device__ __forceinline__ double cema_day(
+    const double *__restrict__ day, cema_gt_ptr_t gt_tab, lanemask_t gt_ok,
+    double snow_pack_init, double thermal_state_init, double CTG,
+    double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L],
+    const CemaGtRegs<L> *gt_regs = nullptr)
+{
+    return cema_day_io<L, FIRST, GT_REGS, SANE>(
+        day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
+        one_minus_CTG, Kf, G, eTG, G, eTG, gt_regs);
 }
 
 

@@ -525,7 +525,7 @@ def test_kernel_variants_agree_bit_for_bit(models):
     flat = rng.uniform(lo, hi, (n, 6))
     rec = _records(models.CemaneigeGR4J, flat)
     base = None
-    for v in (1, 2, 0):
+    for v in (1, 2, 3, 4, 0):
         with _lib.debug_option("fused_variant", v):
             out, _ = fmod._run(layers, (3.0, -0.2, 0.4, 0.5), rec, True, True,
                                None)
