@@ -94,6 +94,14 @@ def parse_args():
                          "(RR_OPT_GR4J_VARIANT: 1 one wave per 64 sets, "
                          "2 wave-specialised)")
     ap.add_argument("--no-parity-spot", action="store_true")
+    ap.add_argument("--score", default="mse", choices=["mse", "nse"],
+                    help="per-set score that is all-gathered: mse (the "
+                         "reference's monte_carlo) or nse (BASELINE "
+                         "configs[3])")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="N = 1 only: skip the short timings of the other "
+                         "BASELINE configurations after the headline")
+    ap.add_argument("--extra-steps", type=int, default=3)
     return ap.parse_args()
 
 
@@ -317,8 +325,16 @@ def parity_spot(args, f, params_host, qsim, sse, qobs, n_cols=16):
     import torch
     from oracle import pyoracle
     from rrmpg_amd.utils import synthetic as syn
-    if args.catchments > 0 or args.model not in ("hbvedu", "gr4j", "abc"):
+    if args.model not in ("hbvedu", "gr4j", "abc", "cemaneigegr4j"):
         return None
+    if args.catchments > 0:
+        # catchment 0 of the launch: its forcing is `f`, its parameter sets
+        # the first rows of the block
+        m = args.sets
+        params_host = params_host[:m]
+        sse = sse[0]
+        qobs = qobs[0]
+        qsim = qsim[0] if qsim is not None else None
     m = params_host.shape[0]
     cols = np.unique(np.linspace(0, m - 1, n_cols).astype(np.int64))
     flat = np.ascontiguousarray(params_host[cols])
@@ -332,6 +348,14 @@ def parity_spot(args, f, params_host, qsim, sse, qobs, n_cols=16):
         ref = pyoracle.simulate_gr4j(f["prec"], f["etp"],
                                      (syn.GR4J_INITS["s_init"],
                                       syn.GR4J_INITS["r_init"]), flat)
+    elif args.model == "cemaneigegr4j":
+        from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+        layers, _ = prepare_snow_inputs(
+            f["prec"], f["temp"], f["tmin"], f["tmax"], syn.STATION_HEIGHT, 0,
+            0, list(syn.ALTITUDES), etp=f["etp"])
+        ref = pyoracle.simulate_cemaneigegr4j(
+            layers[0], layers[1], layers[3], layers[2], (0., 0., 0.6, 0.7),
+            flat, nthreads=4)
     else:
         ref = pyoracle.simulate_abc(f["prec"], 2.5, flat)
     if isinstance(ref, tuple):
@@ -349,14 +373,177 @@ def parity_spot(args, f, params_host, qsim, sse, qobs, n_cols=16):
     return float(err.max())
 
 
+# fp64 VALU issue roof (profiles/README.md, profiles/ubench/valu_cost.hip): a
+# wave64 fp64 instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs;
+# 2.4 GHz nominal engine clock.
+VALU_CYCLES_PER_INSTR = 4
+SIMDS = 1024
+CLOCK_GHZ_NOMINAL = 2.4
+
+ALL_OUT_BYTES = {"hbvedu": 40, "abc": 16, "gr4j": 24, "cemaneigegr4j": 104,
+                 "cemaneige": 88, "cemaneigehystgr4j": 0,
+                 "cemaneigegr4jice": 0, "cemaneigehystgr4jice": 0}
+
+
+def traffic_record(args, n, t):
+    """HBM traffic and VALU instructions per model-timestep of this workload
+    from the committed counter passes (profiles/traffic.json, written by
+    profiles/summarize.py from separate rocprofv3 --pmc runs): NOT measured
+    in this run -- the line says so in "source"."""
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    key = "%s:%s:%d:%d" % (args.model, args.mode, n, t)
+    try:
+        with open(tpath) as fh:
+            pmc = json.load(fh)
+        return pmc.get(key), pmc.get(key + ":valu_instr_per_unit")
+    except Exception:
+        return None, None
+
+
+def run_workload(args, device, rank, world, on_host, steps, warmup,
+                 score="mse"):
+    """Build this rank's share of the workload `args` names, time `steps`
+    sweeps (barrier + synchronize on both sides) and return the measurements.
+    The sweep itself -- kernel launch, score, the one all-gather -- is
+    rrmpg_amd.sharding.ResidentSweep's."""
+    import torch
+    import torch.distributed as dist
+    from rrmpg_amd.sharding import ResidentSweep, shard_bounds
+
+    scaling = "weak" if args.catchments > 0 else args.scaling
+    if scaling == "strong":
+        total_sets = args.sets
+        first, stop = shard_bounds(total_sets, world, rank)
+        n_sets = stop - first
+    else:
+        n_sets = args.sets
+        total_sets = n_sets * world
+        first = rank * n_sets
+    (ens, params, params_host, qsim, storages, qobs, _sse, name,
+     f) = build_workload(args, device, rank, n_sets, first, total_sets)
+    cmul = max(1, args.catchments)
+    n, t = n_sets * cmul, args.days
+    total_units = total_sets * cmul
+    sweep = ResidentSweep(ens, params, qobs, total_units, score=score,
+                          qsim=qsim, storages=storages, on_host=on_host)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(warmup):
+        scores = sweep.step()
+    fence()
+    # kernel time: HIP events on the stream the kernel is launched on (torch's
+    # current stream), bracketing only the library call of each step; a third
+    # event closes the score exchange
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+          for _ in range(steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        sweep.launch()
+        ev[k][1].record()
+        scores = sweep.gather()
+        ev[k][2].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if hasattr(ens, "check"):
+        ens.check()       # GR4J family: an unusable x4 would have written nothing
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+    gather_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev]))
+    k_min = k_max = kernel_ms
+    if world > 1:
+        red = torch.tensor([elapsed, kernel_ms, -kernel_ms, gather_ms],
+                           dtype=torch.float64,
+                           device="cpu" if on_host else device)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        elapsed, k_max, k_min, gather_ms = (float(red[0]), float(red[1]),
+                                            -float(red[2]), float(red[3]))
+    assert scores.numel() == total_units
+    finite = bool(torch.isfinite(scores).all().item())
+    bytes_per_step = {"qsim": 8, "metric": 0,
+                      "storages": ALL_OUT_BYTES[args.model]}[args.mode]
+    return dict(ens=ens, sweep=sweep, params_host=params_host, qsim=qsim,
+                qobs=qobs, f=f, name=name, scaling=scaling, n=n, t=t,
+                total_units=total_units, elapsed=elapsed, kernel_ms=kernel_ms,
+                k_min=k_min, k_max=k_max, gather_ms=gather_ms, finite=finite,
+                bytes_per_step=bytes_per_step,
+                achieved=bytes_per_step * n * t / (kernel_ms * 1e-3) / 1e9)
+
+
+# The other BASELINE.json configurations (and the HBM-bound modes), timed in
+# the same driver run after the headline: label -> bench arguments.  One
+# GPU's share where the config names eight.
+EXTRA_CONFIGS = [
+    ("GR4J 1M sets, qsim + MSE (configs[2])",
+     dict(model="gr4j", mode="qsim", sets=1_000_000)),
+    ("CemaneigeGR4J 125k sets = one GPU's shard of 1M over 8, per-set NSE "
+     "(configs[3])",
+     dict(model="cemaneigegr4j", mode="metric", sets=125_000, score="nse")),
+    ("HBV-Edu 125 catchments x 10k sets = one GPU's share of 1000 x 10k, "
+     "per-set MSE (configs[4])",
+     dict(model="hbvedu", mode="metric", sets=10_000, catchments=125)),
+    ("HBV-Edu 100k sets, qsim + MSE (configs[1])",
+     dict(model="hbvedu", mode="qsim", sets=100_000)),
+    ("HBV-Edu 400k sets, all five outputs (40 B per model-timestep)",
+     dict(model="hbvedu", mode="storages", sets=400_000)),
+    ("ABC 1M sets, qsim + MSE (8 B per model-timestep)",
+     dict(model="abc", mode="qsim", sets=1_000_000)),
+]
+
+
+def extra_configs(args, device):
+    """Each of EXTRA_CONFIGS for a few sweeps on this GPU: kernel ms, rate,
+    fraction of the HBM peak (where the mode writes bytes) and the parity
+    spot against the oracle."""
+    import copy
+    import gc
+    import torch
+    out = []
+    for label, spec in EXTRA_CONFIGS:
+        a = copy.copy(args)
+        a.catchments, a.scaling, a.sampler = 0, "strong", args.sampler
+        score = spec.get("score", "mse")
+        for k, v in spec.items():
+            if k != "score":
+                setattr(a, k, v)
+        try:
+            r = run_workload(a, device, 0, 1, False, args.extra_steps, 1,
+                             score=score)
+            rec = {"workload": label, "kernel_ms": r["kernel_ms"],
+                   "model_timesteps_per_s": r["n"] * r["t"]
+                   / (r["kernel_ms"] * 1e-3),
+                   "bytes_per_unit": r["bytes_per_step"],
+                   "frac": (r["achieved"] / HBM_PEAK_GBPS
+                            if r["bytes_per_step"] else None),
+                   "score": score, "scores_finite": r["finite"],
+                   "parity_spot": (None if args.no_parity_spot else
+                                   parity_spot(a, r["f"], r["params_host"],
+                                               r["qsim"], r["sweep"].sse,
+                                               r["qobs"]))}
+        except Exception as exc:                # keep the headline line
+            rec = {"workload": label, "error": "%s: %s"
+                   % (type(exc).__name__, exc)}
+            r = None
+        out.append(rec)
+        del r
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    import gc
     import torch
     import torch.distributed as dist
     from rrmpg_amd import _lib
-    from rrmpg_amd.sharding import allgather_scores, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -377,115 +564,63 @@ def main():
         else:
             dist.init_process_group("gloo")
     on_host = world > 1 and args.backend == "gloo"
-    if args.hbv_variant >= 0:
-        _lib.check(_lib.load().rr_debug_set_option(
-            _lib.OPTIONS["hbv_variant"], args.hbv_variant),
-            "rr_debug_set_option")
-    if args.gr4j_variant > 0:
-        _lib.check(_lib.load().rr_debug_set_option(
-            _lib.OPTIONS["gr4j_variant"], args.gr4j_variant),
-            "rr_debug_set_option")
-    if args.fused_variant > 0:
-        _lib.check(_lib.load().rr_debug_set_option(
-            _lib.OPTIONS["fused_variant"], args.fused_variant),
-            "rr_debug_set_option")
+    for opt, val in (("hbv_variant", args.hbv_variant if args.hbv_variant >= 0
+                      else None),
+                     ("gr4j_variant", args.gr4j_variant or None),
+                     ("fused_variant", args.fused_variant or None)):
+        if val is not None:
+            _lib.check(_lib.load().rr_debug_set_option(_lib.OPTIONS[opt], val),
+                       "rr_debug_set_option")
 
-    # this rank's block of the parameter-set axis
-    scaling = "weak" if args.catchments > 0 else args.scaling
-    if scaling == "strong":
-        total_sets = args.sets
-        first, stop = shard_bounds(total_sets, world, rank)
-        n_sets = stop - first
-    else:
-        n_sets = args.sets
-        total_sets = n_sets * world
-        first = rank * n_sets
-    (ens, params, params_host, qsim, storages, qobs, sse, name,
-     f) = build_workload(args, device, rank, n_sets, first, total_sets)
-    cmul = max(1, args.catchments)
-    n, t = n_sets * cmul, args.days
-    total_units = total_sets * cmul
-
-    def launch():
-        if storages is None:
-            ens.run(params, qsim, qobs=qobs, sse=sse)
-        else:
-            ens.run(params, qsim, storages, qobs=qobs, sse=sse)
-
-    def gather():
-        # per-set MSE of this rank's block, then the one collective of the
-        # whole job: all-gather of the scores (8 B per set)
-        mse = sse.reshape(-1) / t
-        return allgather_scores(mse.cpu() if on_host else mse, total_units)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
-    for _ in range(args.warmup):
-        launch()
-        scores = gather()
-    fence()
-
-    # kernel time: HIP events on the stream the kernel is launched on (torch's
-    # current stream), bracketing only the library call of each step; a third
-    # event closes the score exchange
-    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
-          for _ in range(args.steps)]
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        launch()
-        ev[k][1].record()
-        scores = gather()
-        ev[k][2].record()
-    fence()
-    elapsed = time.perf_counter() - t0
-
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
-    gather_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev]))
-    k_min = k_max = kernel_ms
-    if world > 1:
-        red = torch.tensor([elapsed, kernel_ms, -kernel_ms, gather_ms],
-                           dtype=torch.float64,
-                           device="cpu" if on_host else device)
-        dist.all_reduce(red, op=dist.ReduceOp.MAX)
-        elapsed, k_max, k_min, gather_ms = (float(red[0]), float(red[1]),
-                                            -float(red[2]), float(red[3]))
-    assert scores.numel() == total_units
-    finite = bool(torch.isfinite(scores).all().item())
+    r = run_workload(args, device, rank, world, on_host, args.steps,
+                     args.warmup, score=args.score)
+    n, t, kernel_ms = r["n"], r["t"], r["kernel_ms"]
 
     if rank == 0:
-        value = total_units * t * args.steps / elapsed
-        all_out = {"hbvedu": 40, "abc": 16, "gr4j": 24, "cemaneigegr4j": 104,
-                   "cemaneige": 88,
-                   "cemaneigehystgr4j": 0, "cemaneigegr4jice": 0,
-                   "cemaneigehystgr4jice": 0}
-        bytes_per_step = {"qsim": 8, "metric": 0,
-                          "storages": all_out[args.model]}[args.mode]
-        achieved = bytes_per_step * n * t / (kernel_ms * 1e-3) / 1e9
-        traffic = valu = None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")
-        key = "%s:%s:%d:%d" % (args.model, args.mode, n, t)
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as fh:
-                    pmc = json.load(fh)
-                traffic = pmc.get(key)
-                valu = pmc.get(key + ":valu_instr_per_unit")
-            except Exception:
-                traffic = valu = None
+        value = r["total_units"] * t * args.steps / r["elapsed"]
+        traffic, valu = traffic_record(args, n, t)
         what = {"qsim": "qsim[T,N] written to HBM + fused per-set MSE",
                 "metric": "fused per-set MSE only",
                 "storages": "qsim and every state series written to HBM + "
                             "fused per-set MSE"}[args.mode]
-        if scaling == "strong":
+        if args.score == "nse":
+            what = what.replace("MSE", "NSE")
+        if r["scaling"] == "strong":
             size = ("%d parameter sets in total (contiguous shards of %d per "
-                    "GPU)" % (total_units, n))
+                    "GPU)" % (r["total_units"], n))
         else:
             size = "%d parameter sets per GPU" % n
+        roof = {
+            "bound": "hbm",
+            "achieved": r["achieved"],
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": r["achieved"] / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "kernel_ms": kernel_ms,
+            "kernel": "%s ensemble kernel, %d B/model-timestep "
+                      "algorithmic" % (r["name"], r["bytes_per_step"]),
+            # traffic and instruction count: committed counter passes of this
+            # workload, not measured in this run
+            "source": {"achieved": "HIP events, this run",
+                       "traffic": "profiles/traffic.json (rocprofv3 --pmc "
+                                  "passes, profiles/collect.sh)",
+                       "valu.instr_per_unit": "profiles/traffic.json "
+                                              "(SQ_INSTS_VALU pass)"},
+            "valu_instr_per_unit": valu,
+        }
+        if valu:
+            # the roof that actually binds the 8 B/unit mode: fp64 VALU issue.
+            # floor = instructions x 4 cycles on 1024 SIMDs at the nominal
+            # clock; frac = floor / this run's kernel time
+            floor_ms = (valu / 64.0 * n * t * VALU_CYCLES_PER_INSTR
+                        / SIMDS / (CLOCK_GHZ_NOMINAL * 1e9) * 1e3)
+            roof["valu"] = {"instr_per_unit": valu,
+                            "cycles_per_instr": VALU_CYCLES_PER_INSTR,
+                            "simds": SIMDS,
+                            "clock_ghz_nominal": CLOCK_GHZ_NOMINAL,
+                            "floor_ms": floor_ms,
+                            "frac": floor_ms / kernel_ms}
         out = {
             "metric": "model-timesteps/s",
             "value": value,
@@ -493,52 +628,46 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": r["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": scaling,
+            "scaling": r["scaling"],
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": "%s Monte-Carlo sweep, %s x %d daily steps, %s, "
-                            "RCCL all-gather of per-set MSE"
-                            % (name, size, t, what),
+                            "RCCL all-gather of per-set %s"
+                            % (r["name"], size, t, what, args.score.upper()),
                 "model": args.model,
-                "sets_total": total_units,
+                "sets_total": r["total_units"],
                 "sets_per_gpu": n,
                 "timesteps": t,
                 "mode": args.mode,
-                "sharding": "parameter sets, one contiguous block per GPU",
+                "score": args.score,
+                "sharding": "parameter sets, one contiguous block per GPU "
+                            "(rrmpg_amd.sharding.ResidentSweep)",
                 "sampler": args.sampler if args.catchments == 0 else "host",
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "kernel_ms": kernel_ms,
-                "kernel": "%s ensemble kernel, %d B/model-timestep "
-                          "algorithmic" % (name, bytes_per_step),
-                # what actually limits the 8 B/unit mode (profiles/README.md):
-                # fp64 VALU issue; instructions per model-timestep from the
-                # committed SQ_INSTS_VALU pass (null for other workloads)
-                "valu_instr_per_unit": valu,
-            },
+            "roofline": roof,
             # HIP-event time of the sweep kernel on the slowest / fastest
-            # rank, and of the score exchange (MSE division + all-gather)
-            "kernel_ms_per_rank": {"min": k_min, "max": k_max},
-            "allgather_ms": gather_ms,
-            "scores_finite": finite,
+            # rank, and of the score exchange (score + all-gather)
+            "kernel_ms_per_rank": {"min": r["k_min"], "max": r["k_max"]},
+            "allgather_ms": r["gather_ms"],
+            "scores_finite": r["finite"],
         }
         if not args.no_parity_spot:
             # columns of the resident result vs the CPU oracle, after timing
-            out["parity_spot"] = parity_spot(args, f, params_host, qsim, sse,
-                                             qobs)
+            out["parity_spot"] = parity_spot(args, r["f"], r["params_host"],
+                                             r["qsim"], r["sweep"].sse,
+                                             r["qobs"])
         if (not args.no_cpu_baseline and world == 1
                 and args.catchments == 0):
-            out["cpu_baseline"] = cpu_baseline(args, f, params_host)
+            out["cpu_baseline"] = cpu_baseline(args, r["f"], r["params_host"])
+        if world == 1 and not args.no_extra_configs:
+            r = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["extra_configs"] = extra_configs(args, device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -123,7 +123,17 @@ int rr_release_cached_memory(void);
                                   * workgroup); 3 gr4j_kernel in workgroups of
                                   * four waves; 4 optimistic (branch-free day,
                                   * redone if a vote failed)                 */
-#define RR_OPT_COUNT_          7
+#define RR_OPT_HOST_SHARDS     7 /* the host-pointer family (rr_<model>_simulate)
+                                  * over several GPUs inside ONE call: 0 / 1
+                                  * (default) the current device only; S > 1
+                                  * cuts the N sets into S contiguous shards,
+                                  * shard j on device (current + j) % count,
+                                  * each from its own host thread, filling its
+                                  * columns of the caller's [T][N] arrays; -1
+                                  * one shard per visible device.  No
+                                  * collective: sets are independent, the
+                                  * forcing is uploaded to every device.      */
+#define RR_OPT_COUNT_          8
 int rr_debug_set_option(int option, int64_t value);
 int64_t rr_debug_get_option(int option);
 

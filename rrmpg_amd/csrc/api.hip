@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -36,7 +37,7 @@ extern "C" int rr_version(void) { return 100; }
 
 // ---- measurement / test options (rrhip.h RR_OPT_*) ---------------------------
 static std::atomic<int64_t> g_options[RR_OPT_COUNT_] = {
-    {0}, {-1} /* HBV variant: heuristic */, {0}, {0}, {0}, {0}, {0}};
+    {0}, {-1} /* HBV variant: heuristic */, {0}, {0}, {0}, {0}, {0}, {0}};
 
 int64_t rr_option(int option)
 {
@@ -53,6 +54,7 @@ extern "C" int rr_debug_set_option(int option, int64_t value)
     case RR_OPT_GR4J_VARIANT: ok = value >= 0 && value <= 4; break;
     case RR_OPT_MAX_BLOCK_COLS: ok = value >= 0; break;
     case RR_OPT_GATHER_THREADS: ok = value >= 0 && value <= 256; break;
+    case RR_OPT_HOST_SHARDS: ok = value >= -1 && value <= 1024; break;
     default: break;
     }
     if (!ok) {
@@ -132,7 +134,7 @@ struct Slot {
     void *p = nullptr;
     size_t cap = 0;
     size_t bytes = 0;      // content (inputs only)
-    uint64_t hash = 0;
+    uint64_t hash = 0, hash2 = 0;
     bool valid = false;
     template <class T> T *as() const { return (T *)p; }
 };
@@ -177,19 +179,32 @@ void slot_free(Slot &s)
     s = Slot();
 }
 
-uint64_t hash_bytes(const void *src, size_t bytes)
+// 128 bits of content hash (two independent multiplicative streams over the
+// same words): an input is taken as unchanged only if its length and both
+// halves agree with what was uploaded last.
+struct Hash128 {
+    uint64_t a, b;
+    bool operator==(const Hash128 &o) const { return a == o.a && b == o.b; }
+};
+Hash128 hash_bytes(const void *src, size_t bytes)
 {
-    const unsigned char *b = (const unsigned char *)src;
+    const unsigned char *p = (const unsigned char *)src;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
+    uint64_t g = 0xC2B2AE3D27D4EB4Full + bytes;
     size_t k = 0;
     for (; k + 8 <= bytes; k += 8) {
         uint64_t w;
-        memcpy(&w, b + k, 8);
+        memcpy(&w, p + k, 8);
         h = (h ^ w) * 0xD6E8FEB86659FD93ull;
         h ^= h >> 32;
+        g = (g + w) * 0xFF51AFD7ED558CCDull;
+        g ^= g >> 29;
     }
-    for (; k < bytes; ++k) h = (h ^ b[k]) * 0x100000001B3ull;
-    return h;
+    for (; k < bytes; ++k) {
+        h = (h ^ p[k]) * 0x100000001B3ull;
+        g = (g + p[k]) * 0xC4CEB9FE1A85EC53ull;
+    }
+    return {h, g};
 }
 
 // One host-pointer call: holds the device's context for its duration.
@@ -234,15 +249,16 @@ struct HostCall {
     int input(const void *src, size_t bytes, const void **dev)
     {
         Slot &s = c->in[next_input++];
-        const uint64_t h = hash_bytes(src, bytes);
-        if (!(s.valid && s.bytes == bytes && s.hash == h)) {
+        const Hash128 h = hash_bytes(src, bytes);
+        if (!(s.valid && s.bytes == bytes && s.hash == h.a &&
+              s.hash2 == h.b)) {
             int rc = slot_reserve(s, bytes);
             if (rc != RR_OK) return rc;
             s.valid = false;
             if (bytes)
                 RR_HIP(hipMemcpyAsync(s.p, src, bytes, hipMemcpyHostToDevice,
                                       c->compute));
-            s.bytes = bytes; s.hash = h; s.valid = true;
+            s.bytes = bytes; s.hash = h.a; s.hash2 = h.b; s.valid = true;
         }
         *dev = s.p;
         return RR_OK;
@@ -328,7 +344,7 @@ struct Gatherer {
     struct Job { int slot; double *host; int64_t row0, rows, nc; };
     HostCtx &c;
     int device;
-    int64_t N;
+    int64_t N;             // row pitch of the caller's arrays, in doubles
     std::mutex m;
     std::condition_variable cv_job, cv_free;
     std::deque<Job> jobs;
@@ -340,14 +356,29 @@ struct Gatherer {
 
     Gatherer(HostCtx &ctx, int dev, int64_t n) : c(ctx), device(dev), N(n) {}
 
-    int start()
+    // false: the pinned ring cannot be had (the caller then takes the pitched
+    // copies, which need no staging memory)
+    bool start()
     {
         if (!c.ring) {
-            RR_HIP(hipHostMalloc(&c.ring, RING_SLOTS * RING_SLOT_BYTES,
-                                 hipHostMallocDefault));
+            if (hipHostMalloc(&c.ring, RING_SLOTS * RING_SLOT_BYTES,
+                              hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                c.ring = nullptr;
+                return false;
+            }
             for (int k = 0; k < RING_SLOTS; ++k)
-                RR_HIP(hipEventCreateWithFlags(&c.ring_ev[k],
-                                               hipEventDisableTiming));
+                if (hipEventCreateWithFlags(&c.ring_ev[k],
+                                            hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    for (int j = 0; j < k; ++j) {
+                        (void)hipEventDestroy(c.ring_ev[j]);
+                        c.ring_ev[j] = nullptr;
+                    }
+                    (void)hipHostFree(c.ring);
+                    c.ring = nullptr;
+                    return false;
+                }
         }
         for (int k = 0; k < RING_SLOTS; ++k) free_slots.push_back(k);
         unsigned nt = std::thread::hardware_concurrency();
@@ -357,7 +388,7 @@ struct Gatherer {
             nt = (unsigned)rr_option(RR_OPT_GATHER_THREADS);
         for (unsigned k = 0; k < nt; ++k)
             workers.emplace_back([this]() { work(); });
-        return RR_OK;
+        return true;
     }
 
     void work()
@@ -409,10 +440,22 @@ struct Gatherer {
             }
             // (chunks alternate between two copy streams: two DMA engines)
             hipStream_t st = (chunk_no++ & 1) ? c.copy2 : c.copy;
-            RR_HIP(hipMemcpyAsync((char *)c.ring + (size_t)slot * RING_SLOT_BYTES,
-                                  dev + r0 * nc, (size_t)n * seg,
-                                  hipMemcpyDeviceToHost, st));
-            RR_HIP(hipEventRecord(c.ring_ev[slot], st));
+            hipError_t e = hipMemcpyAsync(
+                (char *)c.ring + (size_t)slot * RING_SLOT_BYTES, dev + r0 * nc,
+                (size_t)n * seg, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipEventRecord(c.ring_ev[slot], st);
+            if (e != hipSuccess) {
+                // hand the slot back: finish() waits for in_flight == 0
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    free_slots.push_back(slot);
+                    --in_flight;
+                }
+                cv_free.notify_all();
+                rr_set_error("gather: staging copy failed: %s",
+                             hipGetErrorString(e));
+                return RR_E_HIP;
+            }
             {
                 std::lock_guard<std::mutex> lk(m);
                 jobs.push_back({slot, host, r0, n, nc});
@@ -442,10 +485,12 @@ struct Gatherer {
 // arrays (through the staging ring when the result is large, with pitched
 // copies otherwise).  gr4j_family: the deferred x4 check of
 // rr_gr4j_plan_status is made for every block.
+// ldh: row pitch (in doubles) of the caller's arrays -- N, or more when this
+// sweep fills a column block of a wider array (host_fan_out below).
 template <class Launch>
-int sweep_blocks(HostCall &call, int64_t T, int64_t N,
-                 const std::vector<OutSpec> &outs, double *sse_host,
-                 size_t ws_bytes, bool gr4j_family, Launch launch)
+int sweep_blocks_run(HostCall &call, int64_t T, int64_t N, int64_t ldh,
+                     const std::vector<OutSpec> &outs, double *sse_host,
+                     size_t ws_bytes, bool gr4j_family, Launch launch)
 {
     HostCtx &c = *call.c;
     const int64_t nc_max = pick_block(T, N, outs);
@@ -489,12 +534,12 @@ int sweep_blocks(HostCall &call, int64_t T, int64_t N,
 
     int dev = 0;
     RR_HIP(hipGetDevice(&dev));
-    Gatherer ring(c, dev, N);
-    const bool staged = out_bytes >= ((size_t)64 << 20) &&
-                        (size_t)nc_max * 8 <= RING_SLOT_BYTES;
+    Gatherer ring(c, dev, ldh);
+    bool staged = out_bytes >= ((size_t)64 << 20) &&
+                  (size_t)nc_max * 8 <= RING_SLOT_BYTES;
     int rc = enqueue(0);
     if (rc != RR_OK) return rc;
-    if (staged && (rc = ring.start()) != RR_OK) return rc;
+    if (staged && !ring.start()) staged = false;
     for (int64_t k = 0; k < nb; ++k) {
         int64_t i0, nc;
         block(k, i0, nc);
@@ -514,7 +559,7 @@ int sweep_blocks(HostCall &call, int64_t T, int64_t N,
                                       nc)) != RR_OK)
                     return rc;
             } else {
-                RR_HIP(hipMemcpy2DAsync(outs[o].host + i0, (size_t)N * 8,
+                RR_HIP(hipMemcpy2DAsync(outs[o].host + i0, (size_t)ldh * 8,
                                         ptrs[b][o], (size_t)nc * 8,
                                         (size_t)nc * 8, (size_t)rows,
                                         hipMemcpyDeviceToHost, c.copy));
@@ -540,6 +585,82 @@ int sweep_blocks(HostCall &call, int64_t T, int64_t N,
     if (staged) ring.finish();
     RR_HIP(hipStreamSynchronize(c.copy));
     RR_HIP(hipStreamSynchronize(c.copy2));
+    return RR_OK;
+}
+
+template <class Launch>
+int sweep_blocks(HostCall &call, int64_t T, int64_t N, int64_t ldh,
+                 const std::vector<OutSpec> &outs, double *sse_host,
+                 size_t ws_bytes, bool gr4j_family, Launch launch)
+{
+    const int rc = sweep_blocks_run(call, T, N, ldh, outs, sse_host, ws_bytes,
+                                    gr4j_family, launch);
+    if (rc != RR_OK) {
+        // an early exit may leave kernels and copies in flight that still
+        // use the slabs and the pinned bounce buffer the next call reuses:
+        // drain them (the error message of the failing step is kept)
+        HostCtx &c = *call.c;
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        (void)hipStreamSynchronize(c.compute);
+        (void)hipStreamSynchronize(c.copy);
+        (void)hipStreamSynchronize(c.copy2);
+        (void)hipGetLastError();
+        memcpy(g_err, keep, sizeof(keep));
+    }
+    return rc;
+}
+
+// ---- the parameter-set axis over several GPUs, inside one call ----------------
+// RR_OPT_HOST_SHARDS = S > 1 (or -1: one shard per visible device) cuts the N
+// sets of a host-pointer call into S contiguous shards (the partition of
+// rrmpg_amd/sharding.py: lengths differ by at most one, the longer ones
+// first); shard j runs on device (current + j) % device_count from a thread
+// of its own, with that device's context, and fills ITS columns of the
+// caller's [T][N] arrays (row pitch N).  No collective: the sets are
+// independent, the forcing is uploaded to every device (<= 1.4 MB), and the
+// scores land in the caller's vector.  body(first, n) runs sets
+// [first, first + n).  More shards than devices is allowed (they share a
+// device, serialised by its context): the path can be exercised on one GPU.
+static inline double *rr_col(double *a, int64_t first)
+{
+    return a ? a + first : nullptr;
+}
+
+template <class Body>
+int host_fan_out(int64_t N, Body body)
+{
+    int64_t shards = rr_option(RR_OPT_HOST_SHARDS);
+    const int ndev = rr_device_count();
+    if (shards < 0) shards = ndev;
+    if (shards > N) shards = N;
+    if (shards <= 1 || ndev < 1) return body((int64_t)0, N);
+    int cur = 0;
+    RR_HIP(hipGetDevice(&cur));
+    std::vector<int> rcs((size_t)shards, RR_OK);
+    std::vector<std::string> msgs((size_t)shards);
+    std::vector<std::thread> th;
+    const int64_t base = N / shards, extra = N % shards;
+    for (int64_t j = 0; j < shards; ++j) {
+        const int64_t first = j * base + (j < extra ? j : extra);
+        const int64_t n = base + (j < extra ? 1 : 0);
+        th.emplace_back([&, j, first, n]() {
+            if (hipSetDevice((cur + (int)j) % ndev) != hipSuccess) {
+                (void)hipGetLastError();
+                rcs[(size_t)j] = RR_E_HIP;
+                msgs[(size_t)j] = "hipSetDevice failed in a shard thread";
+                return;
+            }
+            rcs[(size_t)j] = body(first, n);
+            if (rcs[(size_t)j] != RR_OK) msgs[(size_t)j] = g_err;
+        });
+    }
+    for (std::thread &t : th) t.join();
+    for (int64_t j = 0; j < shards; ++j)
+        if (rcs[(size_t)j] != RR_OK) {
+            rr_set_error("%s", msgs[(size_t)j].c_str());
+            return rcs[(size_t)j];
+        }
     return RR_OK;
 }
 
@@ -579,24 +700,27 @@ extern "C" int rr_abc_simulate(const double *prec, int64_t T,
     if (rc != RR_OK) return rc;
     if (T == 0 || N == 0) return RR_OK;
     if (!prec) { rr_set_error("rr_abc_simulate: prec is NULL"); return RR_E_NULL; }
-    HostCall call;
-    if ((rc = call.open("rr_abc_simulate")) != RR_OK) return rc;
-    const void *d_prec, *d_qobs = nullptr;
-    const double *d_par;
-    if ((rc = call.input(prec, (size_t)T * 8, &d_prec)) != RR_OK) return rc;
-    if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
-        return rc;
-    if ((rc = call.params(params, (size_t)N * 3 * 8, &d_par)) != RR_OK) return rc;
-    const size_t wsb = rr_abc_workspace_bytes(T, N);
-    std::vector<OutSpec> outs = {{qsim, 1}, {storage, 1}};
-    return sweep_blocks(call, T, N, outs, sse, wsb, false,
-        [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-            void *st) {
-            return rr_abc_simulate_dev(
-                (const double *)d_prec, T, initial_state, d_par + i0 * 3, nc,
-                o[0], o[1], nc, qobs ? (const double *)d_qobs : nullptr,
-                qobs ? d_sse : nullptr, ws, wsb, st);
-        });
+    return host_fan_out(N, [&](int64_t first, int64_t n) -> int {
+        int rc;
+        HostCall call;
+        if ((rc = call.open("rr_abc_simulate")) != RR_OK) return rc;
+        const void *d_prec, *d_qobs = nullptr;
+        const double *d_par;
+        if ((rc = call.input(prec, (size_t)T * 8, &d_prec)) != RR_OK) return rc;
+        if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
+            return rc;
+        if ((rc = call.params(params + first * 3, (size_t)n * 3 * 8, &d_par)) != RR_OK) return rc;
+        const size_t wsb = rr_abc_workspace_bytes(T, n);
+        std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(storage, first), 1}};
+        return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, false,
+            [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
+                void *st) {
+                return rr_abc_simulate_dev(
+                    (const double *)d_prec, T, initial_state, d_par + i0 * 3, nc,
+                    o[0], o[1], nc, qobs ? (const double *)d_qobs : nullptr,
+                    qobs ? d_sse : nullptr, ws, wsb, st);
+            });
+    });
 }
 
 extern "C" int rr_hbvedu_simulate(
@@ -613,33 +737,36 @@ extern "C" int rr_hbvedu_simulate(
         rr_set_error("rr_hbvedu_simulate: NULL forcing pointer");
         return RR_E_NULL;
     }
-    HostCall call;
-    if ((rc = call.open("rr_hbvedu_simulate")) != RR_OK) return rc;
-    const void *d_temp, *d_prec, *d_month, *d_pe, *d_tm, *d_qobs = nullptr;
-    const double *d_par;
-    if ((rc = call.input(temp, (size_t)T * 8, &d_temp)) != RR_OK) return rc;
-    if ((rc = call.input(prec, (size_t)T * 8, &d_prec)) != RR_OK) return rc;
-    if ((rc = call.input(month, (size_t)T, &d_month)) != RR_OK) return rc;
-    if ((rc = call.input(PE_m, 12 * 8, &d_pe)) != RR_OK) return rc;
-    if ((rc = call.input(T_m, 12 * 8, &d_tm)) != RR_OK) return rc;
-    if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
-        return rc;
-    if ((rc = call.params(params, (size_t)N * 11 * 8, &d_par)) != RR_OK)
-        return rc;
-    const size_t wsb = rr_hbvedu_workspace_bytes(T, N);
-    std::vector<OutSpec> outs = {{qsim, 1}, {snow, 1}, {soil, 1}, {s1, 1},
-                                 {s2, 1}};
-    return sweep_blocks(call, T, N, outs, sse, wsb, false,
-        [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-            void *st) {
-            return rr_hbvedu_simulate_dev(
-                (const double *)d_temp, (const double *)d_prec,
-                (const int8_t *)d_month, (const double *)d_pe,
-                (const double *)d_tm, T, snow_init, soil_init, s1_init,
-                s2_init, d_par + i0 * 11, nc, o[0], o[1], o[2], o[3], o[4],
-                nc, qobs ? (const double *)d_qobs : nullptr,
-                qobs ? d_sse : nullptr, ws, wsb, st);
-        });
+    return host_fan_out(N, [&](int64_t first, int64_t n) -> int {
+        int rc;
+        HostCall call;
+        if ((rc = call.open("rr_hbvedu_simulate")) != RR_OK) return rc;
+        const void *d_temp, *d_prec, *d_month, *d_pe, *d_tm, *d_qobs = nullptr;
+        const double *d_par;
+        if ((rc = call.input(temp, (size_t)T * 8, &d_temp)) != RR_OK) return rc;
+        if ((rc = call.input(prec, (size_t)T * 8, &d_prec)) != RR_OK) return rc;
+        if ((rc = call.input(month, (size_t)T, &d_month)) != RR_OK) return rc;
+        if ((rc = call.input(PE_m, 12 * 8, &d_pe)) != RR_OK) return rc;
+        if ((rc = call.input(T_m, 12 * 8, &d_tm)) != RR_OK) return rc;
+        if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
+            return rc;
+        if ((rc = call.params(params + first * 11, (size_t)n * 11 * 8, &d_par)) != RR_OK)
+            return rc;
+        const size_t wsb = rr_hbvedu_workspace_bytes(T, n);
+        std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(snow, first), 1}, {rr_col(soil, first), 1}, {rr_col(s1, first), 1},
+                                     {rr_col(s2, first), 1}};
+        return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, false,
+            [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
+                void *st) {
+                return rr_hbvedu_simulate_dev(
+                    (const double *)d_temp, (const double *)d_prec,
+                    (const int8_t *)d_month, (const double *)d_pe,
+                    (const double *)d_tm, T, snow_init, soil_init, s1_init,
+                    s2_init, d_par + i0 * 11, nc, o[0], o[1], o[2], o[3], o[4],
+                    nc, qobs ? (const double *)d_qobs : nullptr,
+                    qobs ? d_sse : nullptr, ws, wsb, st);
+            });
+    });
 }
 
 extern "C" int rr_gr4j_simulate(const double *prec, const double *etp,
@@ -655,26 +782,29 @@ extern "C" int rr_gr4j_simulate(const double *prec, const double *etp,
         rr_set_error("rr_gr4j_simulate: NULL forcing pointer");
         return RR_E_NULL;
     }
-    HostCall call;
-    if ((rc = call.open("rr_gr4j_simulate")) != RR_OK) return rc;
-    const void *d_prec, *d_etp, *d_qobs = nullptr;
-    const double *d_par;
-    if ((rc = call.input(prec, (size_t)T * 8, &d_prec)) != RR_OK) return rc;
-    if ((rc = call.input(etp, (size_t)T * 8, &d_etp)) != RR_OK) return rc;
-    if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
-        return rc;
-    if ((rc = call.params(params, (size_t)N * 4 * 8, &d_par)) != RR_OK) return rc;
-    const size_t wsb = rr_gr4j_workspace_bytes(T, N);
-    std::vector<OutSpec> outs = {{qsim, 1}, {s_store, 1}, {r_store, 1}};
-    return sweep_blocks(call, T, N, outs, sse, wsb, true,
-        [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-            void *st) {
-            return rr_gr4j_simulate_dev(
-                (const double *)d_prec, (const double *)d_etp, T, s_init,
-                r_init, d_par + i0 * 4, nc, o[0], o[1], o[2], nc,
-                qobs ? (const double *)d_qobs : nullptr,
-                qobs ? d_sse : nullptr, ws, wsb, st);
-        });
+    return host_fan_out(N, [&](int64_t first, int64_t n) -> int {
+        int rc;
+        HostCall call;
+        if ((rc = call.open("rr_gr4j_simulate")) != RR_OK) return rc;
+        const void *d_prec, *d_etp, *d_qobs = nullptr;
+        const double *d_par;
+        if ((rc = call.input(prec, (size_t)T * 8, &d_prec)) != RR_OK) return rc;
+        if ((rc = call.input(etp, (size_t)T * 8, &d_etp)) != RR_OK) return rc;
+        if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
+            return rc;
+        if ((rc = call.params(params + first * 4, (size_t)n * 4 * 8, &d_par)) != RR_OK) return rc;
+        const size_t wsb = rr_gr4j_workspace_bytes(T, n);
+        std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(s_store, first), 1}, {rr_col(r_store, first), 1}};
+        return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, true,
+            [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
+                void *st) {
+                return rr_gr4j_simulate_dev(
+                    (const double *)d_prec, (const double *)d_etp, T, s_init,
+                    r_init, d_par + i0 * 4, nc, o[0], o[1], o[2], nc,
+                    qobs ? (const double *)d_qobs : nullptr,
+                    qobs ? d_sse : nullptr, ws, wsb, st);
+            });
+    });
 }
 
 extern "C" int rr_cemaneige_simulate(
@@ -692,29 +822,32 @@ extern "C" int rr_cemaneige_simulate(
         rr_set_error("rr_cemaneige_simulate: NULL forcing pointer");
         return RR_E_NULL;
     }
-    HostCall call;
-    if ((rc = call.open("rr_cemaneige_simulate")) != RR_OK) return rc;
-    const void *d_prec, *d_temp, *d_frac, *d_qobs = nullptr;
-    const double *d_par;
-    const size_t tl = (size_t)T * (size_t)L * 8;
-    if ((rc = call.input(prec, tl, &d_prec)) != RR_OK) return rc;
-    if ((rc = call.input(mean_temp, tl, &d_temp)) != RR_OK) return rc;
-    if ((rc = call.input(frac_solid_prec, tl, &d_frac)) != RR_OK) return rc;
-    if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
-        return rc;
-    if ((rc = call.params(params, (size_t)N * 2 * 8, &d_par)) != RR_OK) return rc;
-    const size_t wsb = rr_cemaneige_workspace_bytes(T, L, N);
-    std::vector<OutSpec> outs = {{outflow, 1}, {G, L}, {eTG, L}};
-    return sweep_blocks(call, T, N, outs, sse, wsb, false,
-        [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-            void *st) {
-            return rr_cemaneige_simulate_dev(
-                (const double *)d_prec, (const double *)d_temp,
-                (const double *)d_frac, T, L, snow_pack_init,
-                thermal_state_init, d_par + i0 * 2, nc, o[0], o[1], o[2], nc,
-                qobs ? (const double *)d_qobs : nullptr,
-                qobs ? d_sse : nullptr, ws, wsb, st);
-        });
+    return host_fan_out(N, [&](int64_t first, int64_t n) -> int {
+        int rc;
+        HostCall call;
+        if ((rc = call.open("rr_cemaneige_simulate")) != RR_OK) return rc;
+        const void *d_prec, *d_temp, *d_frac, *d_qobs = nullptr;
+        const double *d_par;
+        const size_t tl = (size_t)T * (size_t)L * 8;
+        if ((rc = call.input(prec, tl, &d_prec)) != RR_OK) return rc;
+        if ((rc = call.input(mean_temp, tl, &d_temp)) != RR_OK) return rc;
+        if ((rc = call.input(frac_solid_prec, tl, &d_frac)) != RR_OK) return rc;
+        if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
+            return rc;
+        if ((rc = call.params(params + first * 2, (size_t)n * 2 * 8, &d_par)) != RR_OK) return rc;
+        const size_t wsb = rr_cemaneige_workspace_bytes(T, L, n);
+        std::vector<OutSpec> outs = {{rr_col(outflow, first), 1}, {rr_col(G, first), L}, {rr_col(eTG, first), L}};
+        return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, false,
+            [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
+                void *st) {
+                return rr_cemaneige_simulate_dev(
+                    (const double *)d_prec, (const double *)d_temp,
+                    (const double *)d_frac, T, L, snow_pack_init,
+                    thermal_state_init, d_par + i0 * 2, nc, o[0], o[1], o[2], nc,
+                    qobs ? (const double *)d_qobs : nullptr,
+                    qobs ? d_sse : nullptr, ws, wsb, st);
+            });
+    });
 }
 
 extern "C" int rr_cemaneigegr4j_simulate(
@@ -734,32 +867,35 @@ extern "C" int rr_cemaneigegr4j_simulate(
         rr_set_error("rr_cemaneigegr4j_simulate: NULL forcing pointer");
         return RR_E_NULL;
     }
-    HostCall call;
-    if ((rc = call.open("rr_cemaneigegr4j_simulate")) != RR_OK) return rc;
-    const void *d_prec, *d_temp, *d_etp, *d_frac, *d_qobs = nullptr;
-    const double *d_par;
-    const size_t tl = (size_t)T * (size_t)L * 8;
-    if ((rc = call.input(prec, tl, &d_prec)) != RR_OK) return rc;
-    if ((rc = call.input(mean_temp, tl, &d_temp)) != RR_OK) return rc;
-    if ((rc = call.input(etp, (size_t)T * 8, &d_etp)) != RR_OK) return rc;
-    if ((rc = call.input(frac_solid_prec, tl, &d_frac)) != RR_OK) return rc;
-    if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
-        return rc;
-    if ((rc = call.params(params, (size_t)N * 6 * 8, &d_par)) != RR_OK) return rc;
-    const size_t wsb = rr_cemaneigegr4j_workspace_bytes(T, L, N);
-    std::vector<OutSpec> outs = {{qsim, 1}, {G, L}, {eTG, L}, {s_store, 1},
-                                 {r_store, 1}};
-    return sweep_blocks(call, T, N, outs, sse, wsb, true,
-        [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-            void *st) {
-            return rr_cemaneigegr4j_simulate_dev(
-                (const double *)d_prec, (const double *)d_temp,
-                (const double *)d_etp, (const double *)d_frac, T, L,
-                snow_pack_init, thermal_state_init, s_init, r_init,
-                d_par + i0 * 6, nc, o[0], o[1], o[2], o[3], o[4], nc,
-                qobs ? (const double *)d_qobs : nullptr,
-                qobs ? d_sse : nullptr, ws, wsb, st);
-        });
+    return host_fan_out(N, [&](int64_t first, int64_t n) -> int {
+        int rc;
+        HostCall call;
+        if ((rc = call.open("rr_cemaneigegr4j_simulate")) != RR_OK) return rc;
+        const void *d_prec, *d_temp, *d_etp, *d_frac, *d_qobs = nullptr;
+        const double *d_par;
+        const size_t tl = (size_t)T * (size_t)L * 8;
+        if ((rc = call.input(prec, tl, &d_prec)) != RR_OK) return rc;
+        if ((rc = call.input(mean_temp, tl, &d_temp)) != RR_OK) return rc;
+        if ((rc = call.input(etp, (size_t)T * 8, &d_etp)) != RR_OK) return rc;
+        if ((rc = call.input(frac_solid_prec, tl, &d_frac)) != RR_OK) return rc;
+        if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
+            return rc;
+        if ((rc = call.params(params + first * 6, (size_t)n * 6 * 8, &d_par)) != RR_OK) return rc;
+        const size_t wsb = rr_cemaneigegr4j_workspace_bytes(T, L, n);
+        std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(G, first), L}, {rr_col(eTG, first), L}, {rr_col(s_store, first), 1},
+                                     {rr_col(r_store, first), 1}};
+        return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, true,
+            [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
+                void *st) {
+                return rr_cemaneigegr4j_simulate_dev(
+                    (const double *)d_prec, (const double *)d_temp,
+                    (const double *)d_etp, (const double *)d_frac, T, L,
+                    snow_pack_init, thermal_state_init, s_init, r_init,
+                    d_par + i0 * 6, nc, o[0], o[1], o[2], o[3], o[4], nc,
+                    qobs ? (const double *)d_qobs : nullptr,
+                    qobs ? d_sse : nullptr, ws, wsb, st);
+            });
+    });
 }
 
 // ---- device self-test hook (not part of include/rrhip.h) -------------------
@@ -835,53 +971,56 @@ int snow_gr4j_host(const char *who, int variant, const double *prec,
         rr_set_error("%s: NULL forcing pointer", who);
         return RR_E_NULL;
     }
-    HostCall call;
-    if ((rc = call.open(who)) != RR_OK) return rc;
-    const void *d_prec, *d_temp, *d_etp, *d_frac, *d_fice = nullptr,
-               *d_qobs = nullptr;
-    const double *d_par;
-    const size_t tl = (size_t)T * (size_t)L * 8;
-    if ((rc = call.input(prec, tl, &d_prec)) != RR_OK) return rc;
-    if ((rc = call.input(mean_temp, tl, &d_temp)) != RR_OK) return rc;
-    if ((rc = call.input(etp, (size_t)T * 8, &d_etp)) != RR_OK) return rc;
-    if ((rc = call.input(frac_solid_prec, tl, &d_frac)) != RR_OK) return rc;
-    if ((rc = call.input(frac_ice, ice ? (size_t)L * 8 : 0, &d_fice)) != RR_OK)
-        return rc;
-    if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
-        return rc;
-    if ((rc = call.params(params, (size_t)N * npar * 8, &d_par)) != RR_OK)
-        return rc;
-    const size_t wsb = rr_snowgr4j_workspace_bytes(T, L, N);
-    std::vector<OutSpec> outs = {{qsim, 1}, {G, L}, {eTG, L}, {s_store, 1},
-                                 {r_store, 1}, {sca, L}, {icemelt, 1},
-                                 {snowmelt, 1}};
-    return sweep_blocks(call, T, N, outs, sse, wsb, true,
-        [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-            void *st) {
-            const double *p = d_par + i0 * npar;
-            const double *qo = qobs ? (const double *)d_qobs : nullptr;
-            double *so = qobs ? d_sse : nullptr;
-            const double *pr = (const double *)d_prec,
-                         *tm = (const double *)d_temp,
-                         *et = (const double *)d_etp,
-                         *fr = (const double *)d_frac,
-                         *fi = (const double *)d_fice;
-            if (hyst && ice)
-                return rr_cemaneigehystgr4jice_simulate_dev(
-                    pr, tm, et, fi, fr, T, L, snow_pack_init,
-                    thermal_state_init, sca_init, s_init, r_init, p, nc, o[0],
-                    o[1], o[2], o[3], o[4], o[5], o[6], o[7], nc, qo, so, ws,
-                    wsb, st);
-            if (hyst)
-                return rr_cemaneigehystgr4j_simulate_dev(
-                    pr, tm, et, fr, T, L, snow_pack_init, thermal_state_init,
-                    sca_init, s_init, r_init, p, nc, o[0], o[1], o[2], o[3],
-                    o[4], o[5], nc, qo, so, ws, wsb, st);
-            return rr_cemaneigegr4jice_simulate_dev(
-                pr, tm, et, fi, fr, T, L, snow_pack_init, thermal_state_init,
-                s_init, r_init, p, nc, o[0], o[1], o[2], o[3], o[4], o[6], nc,
-                qo, so, ws, wsb, st);
-        });
+    return host_fan_out(N, [&](int64_t first, int64_t n) -> int {
+        int rc;
+        HostCall call;
+        if ((rc = call.open(who)) != RR_OK) return rc;
+        const void *d_prec, *d_temp, *d_etp, *d_frac, *d_fice = nullptr,
+                   *d_qobs = nullptr;
+        const double *d_par;
+        const size_t tl = (size_t)T * (size_t)L * 8;
+        if ((rc = call.input(prec, tl, &d_prec)) != RR_OK) return rc;
+        if ((rc = call.input(mean_temp, tl, &d_temp)) != RR_OK) return rc;
+        if ((rc = call.input(etp, (size_t)T * 8, &d_etp)) != RR_OK) return rc;
+        if ((rc = call.input(frac_solid_prec, tl, &d_frac)) != RR_OK) return rc;
+        if ((rc = call.input(frac_ice, ice ? (size_t)L * 8 : 0, &d_fice)) != RR_OK)
+            return rc;
+        if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
+            return rc;
+        if ((rc = call.params(params + first * npar, (size_t)n * npar * 8, &d_par)) != RR_OK)
+            return rc;
+        const size_t wsb = rr_snowgr4j_workspace_bytes(T, L, n);
+        std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(G, first), L}, {rr_col(eTG, first), L}, {rr_col(s_store, first), 1},
+                                     {rr_col(r_store, first), 1}, {rr_col(sca, first), L}, {rr_col(icemelt, first), 1},
+                                     {rr_col(snowmelt, first), 1}};
+        return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, true,
+            [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
+                void *st) {
+                const double *p = d_par + i0 * npar;
+                const double *qo = qobs ? (const double *)d_qobs : nullptr;
+                double *so = qobs ? d_sse : nullptr;
+                const double *pr = (const double *)d_prec,
+                             *tm = (const double *)d_temp,
+                             *et = (const double *)d_etp,
+                             *fr = (const double *)d_frac,
+                             *fi = (const double *)d_fice;
+                if (hyst && ice)
+                    return rr_cemaneigehystgr4jice_simulate_dev(
+                        pr, tm, et, fi, fr, T, L, snow_pack_init,
+                        thermal_state_init, sca_init, s_init, r_init, p, nc, o[0],
+                        o[1], o[2], o[3], o[4], o[5], o[6], o[7], nc, qo, so, ws,
+                        wsb, st);
+                if (hyst)
+                    return rr_cemaneigehystgr4j_simulate_dev(
+                        pr, tm, et, fr, T, L, snow_pack_init, thermal_state_init,
+                        sca_init, s_init, r_init, p, nc, o[0], o[1], o[2], o[3],
+                        o[4], o[5], nc, qo, so, ws, wsb, st);
+                return rr_cemaneigegr4jice_simulate_dev(
+                    pr, tm, et, fi, fr, T, L, snow_pack_init, thermal_state_init,
+                    s_init, r_init, p, nc, o[0], o[1], o[2], o[3], o[4], o[6], nc,
+                    qo, so, ws, wsb, st);
+            });
+    });
 }
 
 }  // namespace

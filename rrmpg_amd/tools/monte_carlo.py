@@ -14,10 +14,12 @@ import numpy as np
 
 from ..models.basemodel import BaseModel
 from ..utils.array_checks import validate_array_input
-from ..utils.metrics import mse_from_sse
+from .. import _lib
+from ..utils.metrics import mse_from_sse, nse_from_sse
 
 
-def monte_carlo(model, num, qobs=None, return_qsim=True, **kwargs):
+def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
+                score="mse", **kwargs):
     """Perform Monte-Carlo-Simulation.
 
     Args:
@@ -28,13 +30,23 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, **kwargs):
             [timesteps, num] discharge array on neither host nor device and
             return the per-set scores only (needs qobs) -- the mode for
             million-set sweeps.
+        gpus: (optional, extension) spread the sweep over several GPUs of
+            this node inside the one call: an int, or 'all' (None: the
+            current device).  The parameter-set axis is cut into contiguous
+            shards, one per GPU, each filling its columns of the one
+            [timesteps, num] result (rrmpg_amd.sharding.sweep; a
+            one-process-per-GPU job under torchrun calls that function).
+        score: (optional, extension) 'mse' (default) or 'nse': with 'nse'
+            the result also carries the Nash-Sutcliffe efficiency of every
+            set (calc_nse's definition).
         **kwargs: Keyword arguments matching the inputs the model needs to
             perform a simulation; see help(model.simulate).
 
     Returns:
         A dictionary with the keys 'params' and 'qsim' (unless
         return_qsim=False) and, if qobs is given, 'mse': the
-        mean-squared-error of each simulation.
+        mean-squared-error of each simulation (the reference's key and
+        score, monte_carlo.py:66-71), plus 'nse' if score='nse'.
 
     Raises:
         ValueError: If any input contains invalid values.
@@ -58,11 +70,19 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, **kwargs):
         # a simulate() keyword the fused sweep does not take (return_storage
         # ...): go through simulate itself, as the reference does
         sweep = lambda *a, **kw: BaseModel._sweep(model, *a, **kw)  # noqa
-    qsim, sse = sweep(params, qobs, bool(return_qsim), **kwargs)
+    shards = 0 if gpus is None else (-1 if gpus == "all" else int(gpus))
+    if score not in ("mse", "nse"):
+        raise ValueError("score must be 'mse' or 'nse'")
+    if shards != -1 and shards < 0:
+        raise ValueError("gpus must be a positive int, 'all' or None")
+    with _lib.debug_option("host_shards", shards):
+        qsim, sse = sweep(params, qobs, bool(return_qsim), **kwargs)
 
     result = {'params': params}
     if return_qsim:
         result['qsim'] = qsim
     if qobs is not None:
         result['mse'] = mse_from_sse(sse, len(qobs))
+        if score == "nse":
+            result['nse'] = nse_from_sse(sse, qobs)
     return result

@@ -32,7 +32,8 @@ def _run(cmd, env=None):
 
 def test_single_gpu_line():
     d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3",
-              "--warmup", "1", "--sets", "20000", "--days", "800"])
+              "--warmup", "1", "--sets", "20000", "--days", "800",
+              "--no-extra-configs"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
                 "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -62,6 +63,38 @@ def test_single_gpu_line():
     c = d["cpu_baseline"]                # workload only
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert c["unit"] == "model-timesteps/s" and "sets" in c["sample"]
+
+
+def test_default_line_carries_every_config_and_the_valu_roof():
+    """The driver's command (default workload = BASELINE.json's metric
+    configuration): besides the headline fields the line holds the other
+    BASELINE configurations timed in the same run, each with its parity spot
+    against the oracle, and the fp64-issue roof computed from this run's
+    kernel time."""
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3",
+              "--warmup", "1", "--extra-steps", "2", "--no-cpu-baseline"])
+    assert d["config"]["sets_total"] == 1_000_000
+    assert d["config"]["timesteps"] == 10957 and d["config"]["mode"] == "qsim"
+    assert 0 <= d["parity_spot"] < 1e-10
+    r = d["roofline"]
+    assert r["traffic"] and r["valu_instr_per_unit"]
+    assert "profiles/traffic.json" in r["source"]["traffic"]
+    v = r["valu"]
+    assert v["cycles_per_instr"] == 4 and v["simds"] == 1024
+    assert abs(v["frac"] - v["floor_ms"] / r["kernel_ms"]) < 1e-12
+    assert 0.4 < v["frac"] < 1.0 and 0.3 < r["frac"] < 1.0
+    ex = d["extra_configs"]
+    assert len(ex) == 6
+    for e in ex:
+        assert "error" not in e, e
+        assert e["kernel_ms"] > 0 and e["scores_finite"] is True
+        assert e["parity_spot"] is None or 0 <= e["parity_spot"] < 1e-10, e
+        if e["bytes_per_unit"]:
+            assert 0 < e["frac"] < 1
+    by = {e["workload"].split(",")[0]: e for e in ex}
+    assert by["ABC 1M sets"]["frac"] > 0.6          # the HBM-bound kernels
+    assert by["HBV-Edu 400k sets"]["frac"] > 0.6
+    assert any(e["score"] == "nse" for e in ex)     # configs[3]
 
 
 def test_two_ranks_share_the_gpu_over_gloo():

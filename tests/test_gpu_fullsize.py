@@ -350,8 +350,8 @@ def test_column_scores_match_metric_functions(env, oracle):
     sc_c = M.scores_from_sums(sums_c.cpu().numpy(), qobs_h, shift=shift)
     for name in M.ALL_SCORES:
         assert np.allclose(sc_c[name], sc[name], rtol=1e-9, atol=1e-9), name
-    big = qsim[:, :64] * 1e-6 + 1e6
-    big_obs_h = qobs_h * 1e-6 + 1e6
+    big = qsim[:, :64] * 1e-3 + 1e3
+    big_obs_h = qobs_h * 1e-3 + 1e3
     big_obs = torch.from_numpy(big_obs_h).cuda()
     shift = float(big_obs_h.mean())
     sc_b = M.scores_from_sums(
@@ -359,9 +359,9 @@ def test_column_scores_match_metric_functions(env, oracle):
         big_obs_h, only=("kge", "alpha", "r"), shift=shift)
     for c in (0, 17, 63):
         q = big[:, c].cpu().numpy()
-        assert abs(sc_b["kge"][c] - M.calc_kge(big_obs_h, q)) < 1e-6
-        assert abs(sc_b["alpha"][c] - M.calc_alpha_nse(big_obs_h, q)) < 1e-6
-        assert abs(sc_b["r"][c] - M.calc_r(big_obs_h, q)[0]) < 1e-6
+        assert abs(sc_b["kge"][c] - M.calc_kge(big_obs_h, q)) < 1e-8
+        assert abs(sc_b["alpha"][c] - M.calc_alpha_nse(big_obs_h, q)) < 1e-8
+        assert abs(sc_b["r"][c] - M.calc_r(big_obs_h, q)[0]) < 1e-8
 
 
 def test_column_blocks_with_3d_storages(env, oracle):

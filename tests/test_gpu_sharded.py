@@ -1,0 +1,145 @@
+"""The parameter-set axis over several GPUs as a LIBRARY call: the in-process
+fan-out of the host-pointer family (RR_OPT_HOST_SHARDS: one host thread and
+one device context per shard, every shard filling its columns of the caller's
+[T, N] arrays) behind ``monte_carlo(..., gpus=...)`` / ``sharding.sweep``, and
+the HBM-resident form ``sharding.ResidentSweep`` that bench.py loops over.
+On this one-GPU box the shards share the device (more shards than devices is
+allowed exactly for that): what must hold is bit-equality with the single
+launch, for every output shape, ragged shard sizes included."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from rrmpg_amd import _lib, device, models, sharding
+    from rrmpg_amd.utils import synthetic as syn
+    _lib.load()
+    _lib.require_gpu()
+    return dict(torch=torch, lib=_lib, device=device, models=models, syn=syn,
+                sharding=sharding, f=syn.make_forcing(1500))
+
+
+def _same(a, b):
+    assert type(a) is type(b)
+    if isinstance(a, tuple):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    else:
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 7])
+def test_host_family_fans_out_bit_identically(env, shards):
+    m, f, lib = env["models"], env["f"], env["lib"]
+    np.random.seed(31)
+    n = 1001                                    # ragged shards
+    # HBV-Edu: qsim + four storages
+    p = m.HBVEdu().get_random_params(n)
+    args = (f["temp"], f["prec"], f["month"], f["PE_m"], f["T_m"])
+    one = m.HBVEdu().simulate(*args, return_storage=True, params=p,
+                              **env["syn"].HBV_INITS)
+    with lib.debug_option("host_shards", shards):
+        many = m.HBVEdu().simulate(*args, return_storage=True, params=p,
+                                   **env["syn"].HBV_INITS)
+    _same(one, many)
+    # GR4J (the deferred x4 check runs per shard) and ABC
+    p = m.GR4J().get_random_params(n)
+    one = m.GR4J().simulate(f["prec"], f["etp"], 0.6, 0.7,
+                            return_storage=True, params=p)
+    with lib.debug_option("host_shards", shards):
+        many = m.GR4J().simulate(f["prec"], f["etp"], 0.6, 0.7,
+                                 return_storage=True, params=p)
+        bad = p.copy()
+        bad["x4"][n - 2] = -1.0                 # lands in the last shard
+        with pytest.raises(RuntimeError, match="RR_E_PARAM"):
+            m.GR4J().simulate(f["prec"], f["etp"], params=bad)
+    _same(one, many)
+    p = m.ABCModel().get_random_params(n)
+    one = m.ABCModel().simulate(f["prec"], 2.0, return_storage=True, params=p)
+    with lib.debug_option("host_shards", shards):
+        many = m.ABCModel().simulate(f["prec"], 2.0, return_storage=True,
+                                     params=p)
+    _same(one, many)
+    # CemaneigeGR4J: [T, L, N] storages, column blocks inside every shard
+    p = m.CemaneigeGR4J().get_random_params(300)
+    kw = dict(prec=f["prec"], mean_temp=f["temp"], min_temp=f["tmin"],
+              max_temp=f["tmax"], etp=f["etp"],
+              met_station_height=env["syn"].STATION_HEIGHT,
+              altitudes=list(env["syn"].ALTITUDES), s_init=0.6, r_init=0.7,
+              return_storages=True, params=p)
+    one = m.CemaneigeGR4J().simulate(**kw)
+    with lib.debug_option("host_shards", shards), \
+            lib.debug_option("max_block_cols", 64):
+        many = m.CemaneigeGR4J().simulate(**kw)
+    _same(one, many)
+
+
+def test_monte_carlo_gpus_and_sharding_sweep(env):
+    from rrmpg_amd.tools import monte_carlo
+    from rrmpg_amd.utils.metrics import calc_mse, calc_nse
+    m, f, sh = env["models"], env["f"], env["sharding"]
+    kw = dict(temp=f["temp"], prec=f["prec"], month=f["month"],
+              PE_m=f["PE_m"], T_m=f["T_m"], **env["syn"].HBV_INITS)
+    np.random.seed(7)
+    base = monte_carlo(m.HBVEdu(), 500, qobs=None, **kw)
+    qobs = base["qsim"][:, 3] * 1.05 + 0.02
+    np.random.seed(7)
+    one = monte_carlo(m.HBVEdu(), 500, qobs=qobs, score="nse", **kw)
+    np.random.seed(7)
+    two = monte_carlo(m.HBVEdu(), 500, qobs=qobs, gpus=2, score="nse", **kw)
+    np.random.seed(7)
+    allg = monte_carlo(m.HBVEdu(), 500, qobs=qobs, gpus="all",
+                       return_qsim=False, **kw)
+    for key in ("qsim", "mse", "nse"):
+        assert np.array_equal(one[key], two[key]), key
+    assert np.array_equal(allg["mse"], one["mse"]) and "qsim" not in allg
+    for j in (0, 250, 499):
+        assert abs(one["mse"][j] - calc_mse(qobs, one["qsim"][:, j])) < 1e-12
+        assert abs(one["nse"][j] - calc_nse(qobs, one["qsim"][:, j])) < 1e-12
+    # the same through sharding.sweep (no process group: in-process fan-out)
+    out = sh.sweep(m.HBVEdu(), one["params"], qobs, score="nse", gpus=3, **kw)
+    assert out["bounds"] == (0, 500) and out["score"] == "nse"
+    assert np.array_equal(out["scores"], one["nse"])
+    with pytest.raises(ValueError):
+        monte_carlo(m.HBVEdu(), 10, qobs=qobs, score="kge", **kw)
+    with pytest.raises(ValueError):
+        monte_carlo(m.HBVEdu(), 10, qobs=qobs, gpus=-3, **kw)
+
+
+def test_resident_sweep_scores(env):
+    """sharding.ResidentSweep (what bench.py times): MSE and NSE of a resident
+    block equal the host-path scores; the device sampler gives every rank its
+    rows of ONE population (two 'ranks' drawn here by hand)."""
+    torch, dev, m, f, sh = (env["torch"], env["device"], env["models"],
+                            env["f"], env["sharding"])
+    from rrmpg_amd.utils.metrics import calc_mse, calc_nse
+    ens = dev.GR4JEnsemble(f["prec"], f["etp"], s_init=0.6, r_init=0.7)
+    total, key = 999, 1234
+    whole = dev.sample_params(m.GR4J(), total, key)
+    q = ens.new_output(total)
+    ens.run(whole, q)
+    torch.cuda.synchronize()
+    qobs_h = q[:, 5].cpu().numpy() * 0.9 + 0.05
+    qobs = torch.from_numpy(qobs_h).cuda()
+    got = {}
+    for score in ("mse", "nse"):
+        parts = []
+        for r in range(2):
+            a, b = sh.shard_bounds(total, 2, r)
+            rs = sh.ResidentSweep.from_sampler(ens, m.GR4J(), b - a, total, a,
+                                               key, qobs=qobs, score=score)
+            assert torch.equal(rs.params, whole[a:b])
+            parts.append(rs.step())        # no process group: this block's
+            assert parts[-1].numel() == b - a
+        got[score] = torch.cat(parts).cpu().numpy()
+    qh = q.cpu().numpy()
+    for j in (0, 499, 500, 998):
+        assert abs(got["mse"][j] - calc_mse(qobs_h, qh[:, j])) \
+            <= 1e-12 * max(1.0, calc_mse(qobs_h, qh[:, j]))
+        assert abs(got["nse"][j] - calc_nse(qobs_h, qh[:, j])) <= 1e-10
