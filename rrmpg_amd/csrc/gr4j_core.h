@@ -429,15 +429,17 @@ static inline void gr4j_for_each_tier(F &&f)
 // non-finite or v**4 overflowed; one class test instead of the clamp of
 // fastmath.h's inv_fourth_root (3 instructions).  +inf gives 0 (callers use
 // 1 - result), NaN propagates.
-// GUARD_BY_VOTE = false: the branch-free clamped form (UhRegs<10> kernels, see
-// pow_3_5 below).
+// (GUARD_BY_VOTE = false, the branch-free clamped form, and FAST_ROOT = false
+// below are measurement switches: until round 3 the UhRegs<10> kernels ran
+// them -- 2-3 % faster at their two waves per SIMD -- and a set's last bits
+// then depended on the tier its launch happened to run.  Every tier now runs
+// the voted forms.)
 // Percolation root as a polynomial (fastmath.h inv_fourth_root_1p_small):
 // where its eight coefficients live.  Plain GR4J kernels with the hydrographs
 // in 3+7 or 5+11 registers have VGPRs to spare (and no SGPRs: 104 of 106
 // taken): VGPR pairs; everything else -- the LDS tier, held to 80 VGPRs, and
 // the fused snow kernels, short of both -- fetches them from constant memory
-// at the point of use.  UhRegs<10> kernels keep the Newton form (measured: no
-// difference at two waves per SIMD).  A/B in profiles/README.md.
+// at the point of use.  A/B in profiles/README.md.
 // Where a step's polynomial constants live (fastmath.h fast_tanh_parts):
 // the plain GR4J kernels keep the tanh's in SGPRs; the fused snow kernels are
 // short of SGPRs and fetch them from constant memory at the point of use;
@@ -447,9 +449,9 @@ enum { GR4J_CONSTS_SGPR = 0, GR4J_CONSTS_VGPR = 1, GR4J_CONSTS_JIT = 2 };
 #ifndef RR_R4_POLY
 #define RR_R4_POLY 1        // measurement switch: 0 = Newton form everywhere
 #endif
+// (every tier: a set's bits must not depend on which tier its launch runs)
 template <class UH>
-constexpr bool RR_R4_POLY_ENABLED =
-    RR_R4_POLY != 0 && !std::is_same<UH, UhRegs<10>>::value;
+constexpr bool RR_R4_POLY_ENABLED = RR_R4_POLY != 0;
 template <class UH, int CONSTS>
 constexpr int gr4j_r4_consts()
 {
@@ -472,9 +474,8 @@ __device__ __forceinline__ double gr4j_inv_fourth_root(double b,
     return y;
 }
 
-// FAST_ROOT = false keeps the compiler's IEEE sqrt inline: measured faster in
-// the UhRegs<10> kernels (2 waves per SIMD, every register taken -- there the
-// extra branch costs more than the 7 instructions it saves: 233.7 vs 226.8 ms).
+// FAST_ROOT = false keeps the compiler's IEEE sqrt inline (measurement switch,
+// see above).
 template <bool FAST_ROOT = true, class V = CarefulVotes>
 __device__ __forceinline__ double pow_3_5(double x, V &&votes = V())
 {
@@ -611,7 +612,7 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     // percolation (:117); **4 is two squarings
     const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1, P.x1_m, votes);
     const double v2 = v * v;
-    constexpr bool by_vote = !std::is_same<UH, UhRegs<10>>::value;
+    constexpr bool by_vote = true;    // (the same forms in every tier)
     // v <= 4/9 while the store is within its capacity: the root of 1 + v**4
     // is then a degree-7 polynomial (fastmath.h); a wave with a lane beyond
     // that takes the general form for those lanes.  The polynomial's argument
@@ -650,7 +651,7 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
                                                typename UH::Slots &out,
                                                double p_r, V &&votes = V())
 {
-    constexpr bool by_vote = !std::is_same<UH, UhRegs<10>>::value;
+    constexpr bool by_vote = true;    // (the same forms in every tier)
     const double p_r_uh1 = 0.9 * p_r;                           // :126-127
     const double p_r_uh2 = 0.1 * p_r;
 
