@@ -64,8 +64,10 @@ extern "C" {
 /* Cemaneige: up to this many elevation layers keep their snow states in
  * registers; more layers run through an HBM scratch (slower, same results). */
 #define RR_CEMANEIGE_MAX_LAYERS 8
-/* GR4J: largest x4 the LDS unit-hydrograph tier holds (ceil(x4) ordinates
- * for UH1, ceil(2*x4+1) for UH2). */
+/* GR4J: largest x4 whose unit hydrographs (ceil(x4) ordinates for UH1,
+ * ceil(2*x4+1) for UH2) live on chip -- registers up to 10, LDS up to this.
+ * Longer ones run too, as in the reference, from a scratch in HBM behind the
+ * workspace: size it with the rr_*_workspace_bytes_x4 queries. */
 #define RR_GR4J_MAX_X4 20.0
 
 int rr_version(void);
@@ -202,8 +204,18 @@ int rr_hbvedu_simulate_catchments_dev(const double *temp, const double *prec,
  * s_init / r_init are fractions of x1 / x3 (gr4j_model.py:64-65); out[k] is
  * the state after day k (the reference's artificial step 0 is dropped,
  * gr4j_model.py:157).  RR_E_PARAM if any x4 gives no ordinates
- * (ceil(x4) < 1: the reference raises IndexError) or x4 > RR_GR4J_MAX_X4. */
+ * (ceil(x4) < 1: the reference raises IndexError).  Any other x4 runs, as in
+ * the reference (gr4j_model.py:68-79): up to RR_GR4J_MAX_X4 with the
+ * workspace of rr_gr4j_workspace_bytes, beyond it with the larger one of
+ * rr_gr4j_workspace_bytes_x4(T, N, largest x4 of the block) -- the bytes
+ * behind the base workspace are the unit-hydrograph scratch (N * (6*ceil(x4)
+ * + 2) * 8 B); a block whose x4 exceeds what its workspace holds writes
+ * nothing and reports RR_E_PARAM through rr_gr4j_plan_status.  The
+ * host-pointer family sizes the scratch itself (x4 <= 1e5).  Results do not
+ * depend on which storage a launch uses: every tier runs the same
+ * arithmetic. */
 size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N);
+size_t rr_gr4j_workspace_bytes_x4(int64_t T, int64_t N, double max_x4);
 int rr_gr4j_simulate_dev(const double *prec, const double *etp, int64_t T,
                          double s_init, double r_init,
                          const double *params, int64_t N,
@@ -217,7 +229,8 @@ int rr_gr4j_simulate_dev(const double *prec, const double *etp, int64_t T,
  * fully asynchronous: the scan of x4 that picks the unit-hydrograph storage
  * runs on the GPU and is never read back by the call.  A parameter block
  * with a set the kernels cannot run (ceil(x4) < 1 or NaN: the reference
- * raises IndexError; x4 > RR_GR4J_MAX_X4) makes that sweep write NOTHING;
+ * raises IndexError; x4 beyond what the workspace's unit-hydrograph scratch
+ * holds, see rr_gr4j_workspace_bytes_x4) makes that sweep write NOTHING;
  * this function, given the workspace of the call, waits for `stream` and
  * returns RR_E_PARAM (with rr_last_error() text) or RR_OK.  The host-pointer
  * family calls it itself and returns the error directly. */
@@ -278,6 +291,8 @@ int rr_cemaneige_layers_dev(const double *prec, const double *mean_temp,
  * params = {CTG, Kf, x1, x2, x3, x4}.  One fused pass: the snow routine's
  * outflow feeds GR4J's precipitation in registers, no [T] intermediate. */
 size_t rr_cemaneigegr4j_workspace_bytes(int64_t T, int64_t L, int64_t N);
+size_t rr_cemaneigegr4j_workspace_bytes_x4(int64_t T, int64_t L, int64_t N,
+                                           double max_x4);
 int rr_cemaneigegr4j_simulate_dev(const double *prec, const double *mean_temp,
                                   const double *etp,
                                   const double *frac_solid_prec, int64_t T,
@@ -348,6 +363,8 @@ int rr_sample_params_dev(uint64_t key, int k, const double *lo,
  * (snowmelt = the snow routine's layer-mean outflow before the ice melt is
  * added).  All variants share one workspace size. */
 size_t rr_snowgr4j_workspace_bytes(int64_t T, int64_t L, int64_t N);
+size_t rr_snowgr4j_workspace_bytes_x4(int64_t T, int64_t L, int64_t N,
+                                      double max_x4);
 
 /* replaces run_cemaneigehystgr4j(prec, mean_temp, etp, frac_solid_prec,
  *     snow_pack_init, thermal_state_init, sca_init, s_init, r_init, params)

@@ -63,6 +63,7 @@ _SIGNATURES = {
                                                        _i64] + [_vp] * 5
                                           + [_i64, _vp, _vp, _vp, _sz, _vp]),
     "rr_gr4j_workspace_bytes": (_sz, [_i64, _i64]),
+    "rr_gr4j_workspace_bytes_x4": (_sz, [_i64, _i64, _dbl]),
     "rr_gr4j_plan_status": (ctypes.c_int, [_vp, _vp]),
     "rr_gr4j_simulate_dev": (ctypes.c_int,
                              [_vp, _vp, _i64, _dbl, _dbl, _vp, _i64]
@@ -83,6 +84,7 @@ _SIGNATURES = {
                                 [_vp] * 4 + [_i64, _f64p, _i64, _dbl, _f64p]
                                 + [_vp] * 4 + [_sz, _vp]),
     "rr_cemaneigegr4j_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "rr_cemaneigegr4j_workspace_bytes_x4": (_sz, [_i64, _i64, _i64, _dbl]),
     "rr_cemaneigegr4j_simulate_dev": (ctypes.c_int,
                                       [_vp] * 4 + [_i64, _i64] + [_dbl] * 4
                                       + [_vp, _i64] + [_vp] * 5
@@ -91,6 +93,7 @@ _SIGNATURES = {
                                   [_f64p] * 4 + [_i64, _i64] + [_dbl] * 4
                                   + [_f64p, _i64] + [_f64p] * 7),
     "rr_snowgr4j_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "rr_snowgr4j_workspace_bytes_x4": (_sz, [_i64, _i64, _i64, _dbl]),
     "rr_cemaneigehystgr4j_simulate_dev": (
         ctypes.c_int, [_vp] * 4 + [_i64, _i64] + [_dbl] * 5 + [_vp, _i64]
         + [_vp] * 6 + [_i64, _vp, _vp, _vp, _sz, _vp]),

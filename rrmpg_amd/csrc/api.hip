@@ -622,6 +622,28 @@ int sweep_blocks(HostCall &call, int64_t T, int64_t N, int64_t ldh,
 // scores land in the caller's vector.  body(first, n) runs sets
 // [first, first + n).  More shards than devices is allowed (they share a
 // device, serialised by its context): the path can be exercised on one GPU.
+// Largest x4 of a host parameter block (NaN ignored: the device scan reports
+// it) -- sizes the unit-hydrograph scratch of the GR4J-family sweeps.
+static double host_max_x4(const double *params, int64_t n, int stride, int idx)
+{
+    double m = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double v = params[i * stride + idx];
+        if (v > m) m = v;
+    }
+    return m;
+}
+#define RR_HOST_X4_LIMIT 1e5
+static int check_host_x4(const char *who, double max_x4)
+{
+    if (max_x4 > RR_HOST_X4_LIMIT) {
+        rr_set_error("%s: x4 up to %g: unit hydrographs longer than %g days "
+                     "are not supported", who, max_x4, RR_HOST_X4_LIMIT);
+        return RR_E_PARAM;
+    }
+    return RR_OK;
+}
+
 static inline double *rr_col(double *a, int64_t first)
 {
     return a ? a + first : nullptr;
@@ -793,7 +815,10 @@ extern "C" int rr_gr4j_simulate(const double *prec, const double *etp,
         if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
             return rc;
         if ((rc = call.params(params + first * 4, (size_t)n * 4 * 8, &d_par)) != RR_OK) return rc;
-        const size_t wsb = rr_gr4j_workspace_bytes(T, n);
+        const double max_x4 = host_max_x4(params + first * 4, n, 4, 3);
+        if ((rc = check_host_x4("rr_gr4j_simulate", max_x4)) != RR_OK)
+            return rc;
+        const size_t wsb = rr_gr4j_workspace_bytes_x4(T, n, max_x4);
         std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(s_store, first), 1}, {rr_col(r_store, first), 1}};
         return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, true,
             [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
@@ -881,7 +906,10 @@ extern "C" int rr_cemaneigegr4j_simulate(
         if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
             return rc;
         if ((rc = call.params(params + first * 6, (size_t)n * 6 * 8, &d_par)) != RR_OK) return rc;
-        const size_t wsb = rr_cemaneigegr4j_workspace_bytes(T, L, n);
+        const double max_x4 = host_max_x4(params + first * 6, n, 6, 5);
+        if ((rc = check_host_x4("rr_cemaneigegr4j_simulate", max_x4)) != RR_OK)
+            return rc;
+        const size_t wsb = rr_cemaneigegr4j_workspace_bytes_x4(T, L, n, max_x4);
         std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(G, first), L}, {rr_col(eTG, first), L}, {rr_col(s_store, first), 1},
                                      {rr_col(r_store, first), 1}};
         return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, true,
@@ -989,7 +1017,10 @@ int snow_gr4j_host(const char *who, int variant, const double *prec,
             return rc;
         if ((rc = call.params(params + first * npar, (size_t)n * npar * 8, &d_par)) != RR_OK)
             return rc;
-        const size_t wsb = rr_snowgr4j_workspace_bytes(T, L, n);
+        const double max_x4 = host_max_x4(params + first * npar, n, npar,
+                                          (hyst ? 4 : 2) + 3);
+        if ((rc = check_host_x4(who, max_x4)) != RR_OK) return rc;
+        const size_t wsb = rr_snowgr4j_workspace_bytes_x4(T, L, n, max_x4);
         std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(G, first), L}, {rr_col(eTG, first), L}, {rr_col(s_store, first), 1},
                                      {rr_col(r_store, first), 1}, {rr_col(sca, first), L}, {rr_col(icemelt, first), 1},
                                      {rr_col(snowmelt, first), 1}};

@@ -197,7 +197,7 @@ template <int L, class UH, bool SMALL = false>
 constexpr int coupled_min_waves()
 {
     return (!SMALL && L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
-                                 std::is_same<UH, UhLds>::value)) ? 4 : 2;
+                                 uh_is_indexed<UH>)) ? 4 : 2;
 }
 
 // SMALL variant of the fused kernel, for sweeps of at most two waves per SIMD
@@ -234,7 +234,8 @@ cemaneigegr4j_kernel(
     int64_t T, double snow_pack_init, double thermal_state_init,
     double s_init, double r_init, const double *__restrict__ params,
     int64_t N, const int *__restrict__ plan, int force_lds, int wq, int ws,
-    const double *__restrict__ qobs, double *__restrict__ sse)
+    const double *__restrict__ qobs, double *__restrict__ sse,
+    double *__restrict__ uh_mem)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
@@ -252,8 +253,7 @@ cemaneigegr4j_kernel(
     const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
     const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
     UH uh;
-    if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
-    else uh.init(P.x4);
+    gr4j_uh_init(uh, lds, uh_mem, n1cap, n2cap, P.x4);
     double s = s_init * P.x1, r = r_init * P.x3;
     double acc = 0.0;
     const bool we = sse != nullptr;
@@ -533,7 +533,8 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
     double *__restrict__ qsim, double *__restrict__ G_out,
     double *__restrict__ eTG_out, double *__restrict__ s_store,
     double *__restrict__ r_store, int64_t ld,
-    const double *__restrict__ qobs, double *__restrict__ sse)
+    const double *__restrict__ qobs, double *__restrict__ sse,
+    double *__restrict__ uh_mem)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr bool coupled = !std::is_same<UH, void>::value;
@@ -555,10 +556,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
     double s = 0.0, r = 0.0;
     if constexpr (coupled) {
         P.set(p[2], p[3], p[4], p[5]);
-        if constexpr (std::is_same<UH, UhLds>::value)
-            uh.init(lds, n1cap, n2cap, P.x4);
-        else
-            uh.init(P.x4);
+        gr4j_uh_init(uh, lds, uh_mem, n1cap, n2cap, P.x4);
         s = s_init * P.x1;
         r = r_init * P.x3;
     }
@@ -598,6 +596,12 @@ extern "C" size_t rr_cemaneigegr4j_workspace_bytes(int64_t T, int64_t L,
                                                    int64_t N)
 {
     return cema_ws_bytes(T, L, true, N);
+}
+
+extern "C" size_t rr_cemaneigegr4j_workspace_bytes_x4(int64_t T, int64_t L,
+                                                      int64_t N, double max_x4)
+{
+    return cema_ws_bytes(T, L, true, N) + rr_gr4j_uh_scratch_bytes(N, max_x4);
 }
 
 int rr_cema_prepass(const double *prec, const double *mean_temp,
@@ -775,7 +779,7 @@ extern "C" int rr_cemaneige_simulate_dev(
         cemaneige_dyn_kernel<void><<<grid, block, 0, st>>>(
             days, gt, T, (int)L, cema_record_len((int)L, false), snow_pack_init,
             thermal_state_init, 0., 0., params, 2, N, nullptr, 0, state,
-            outflow, G, eTG, nullptr, nullptr, ld, qo, sse);
+            outflow, G, eTG, nullptr, nullptr, ld, qo, sse, nullptr);
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
@@ -820,7 +824,11 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
     }
     hipStream_t st = (hipStream_t)stream;
     const int *d_plan = (const int *)workspace;
-    rc = rr_gr4j_plan_async(params, N, 6, 5, (int *)workspace, st);
+    // whatever lies behind the base workspace is unit-hydrograph scratch
+    const size_t base_ws = cema_ws_bytes(T, L, true, N);
+    double *uh_mem = (double *)((char *)workspace + base_ws);
+    const int mem_cap = gr4j_mem_cap(workspace_bytes - base_ws, N);
+    rc = rr_gr4j_plan_async(params, N, 6, 5, (int *)workspace, mem_cap, st);
     if (rc != RR_OK) return rc;
     const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     double *days, *gt, *state;
@@ -842,7 +850,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                          snow_pack_init,
                          thermal_state_init, s_init, r_init, params, 6, N,
                          d_plan, force_lds, state, qsim, G, eTG, s_store,
-                         r_store, ld, qo, sse);
+                         r_store, ld, qo, sse, uh_mem);
         });
         RR_HIP(hipGetLastError());
         return RR_OK;
@@ -893,7 +901,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                             out, days, gt, T, snow_pack_init,
                             thermal_state_init, s_init, r_init, params, N,
                             d_plan, force_lds, qsim != nullptr, G != nullptr,
-                            qo, sse);
+                            qo, sse, uh_mem);
                     return;
                 }
             }
@@ -901,7 +909,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                 <<<grid, block, lds, st>>>(
                     out, days, gt, T, snow_pack_init, thermal_state_init,
                     s_init, r_init, params, N, d_plan, force_lds,
-                    qsim != nullptr, G != nullptr, qo, sse);
+                    qsim != nullptr, G != nullptr, qo, sse, uh_mem);
         });
     });
     RR_HIP(hipGetLastError());

@@ -47,8 +47,11 @@ __global__ void gr4j_pack_forcing(const double *__restrict__ prec,
 // scan[0] = max over sets of ceil(x4) (as int, saturated), scan[1] = number
 // of sets whose x4 gives no ordinates (ceil(x4) < 1 or NaN).
 __global__ void gr4j_scan_x4(const double *__restrict__ params, int64_t N,
-                             int stride, int x4_index, int *__restrict__ scan)
+                             int stride, int x4_index, int mem_cap,
+                             int *__restrict__ scan)
 {
+    // scan[2]: what the unit-hydrograph scratch of this launch can hold
+    if (blockIdx.x == 0 && threadIdx.x == 0) scan[2] = mem_cap;
     int mx = 0, bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -75,8 +78,7 @@ __global__ void gr4j_scan_x4(const double *__restrict__ params, int64_t N,
 template <class UH>
 constexpr int gr4j_min_waves()
 {
-    return std::is_same<UH, UhRegs<3>>::value ? 5
-           : std::is_same<UH, UhLds>::value   ? 6 : 2;
+    return std::is_same<UH, UhRegs<3>>::value ? 5 : uh_is_indexed<UH> ? 6 : 2;
 }
 
 // WPG: waves per workgroup, each with its own 64 sets.  The dispatcher
@@ -93,7 +95,8 @@ void gr4j_kernel(
     const int *__restrict__ plan, int force_lds,
     double *__restrict__ qsim, double *__restrict__ s_store,
     double *__restrict__ r_store, int64_t ld,
-    const double *__restrict__ qobs, double *__restrict__ sse)
+    const double *__restrict__ qobs, double *__restrict__ sse,
+    double *__restrict__ uh_mem)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
@@ -111,8 +114,7 @@ void gr4j_kernel(
     P.set(p[0], p[1], p[2], p[3]);
 
     UH uh;
-    if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
-    else uh.init(P.x4);
+    gr4j_uh_init(uh, lds, uh_mem, n1cap, n2cap, P.x4);
 
     double s = s_init * P.x1;   // gr4j_model.py:64
     double r = r_init * P.x3;   // gr4j_model.py:65
@@ -423,17 +425,39 @@ extern "C" size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N)
     return 256 + rr_align256((size_t)(T + 1) * sizeof(GrDay));
 }
 
+// ceil(x4) as the kernels count it, for sizing (host)
+static int64_t gr4j_host_n1(double max_x4)
+{
+    if (!(max_x4 > 0)) return 0;
+    const double c = ceil(max_x4);
+    return c > 1e6 ? 1000000 : (int64_t)c;
+}
+
+// bytes of unit-hydrograph scratch behind a workspace whose launch may hold
+// sets with x4 up to max_x4 (none up to RR_GR4J_MAX_X4: registers / LDS)
+size_t rr_gr4j_uh_scratch_bytes(int64_t N, double max_x4)
+{
+    const int64_t n1 = gr4j_host_n1(max_x4);
+    return n1 > (int64_t)RR_GR4J_MAX_X4 ? rr_align256(gr4j_mem_bytes(N, n1)) : 0;
+}
+
+extern "C" size_t rr_gr4j_workspace_bytes_x4(int64_t T, int64_t N,
+                                             double max_x4)
+{
+    return rr_gr4j_workspace_bytes(T, N) + rr_gr4j_uh_scratch_bytes(N, max_x4);
+}
+
 // Shared by gr4j.hip, cemaneige.hip and snownext.hip: enqueues the scan of
-// x4 that leaves the plan {max ceil(x4), #bad sets} in d_plan (gr4j_core.h).
-// Asynchronous: nothing is read back.
+// x4 that leaves the plan {max ceil(x4), #bad sets, scratch capacity} in
+// d_plan (gr4j_core.h).  Asynchronous: nothing is read back.
 int rr_gr4j_plan_async(const double *params, int64_t N, int stride,
-                       int x4_index, int *d_plan, hipStream_t st)
+                       int x4_index, int *d_plan, int mem_cap, hipStream_t st)
 {
     RR_HIP(hipMemsetAsync(d_plan, 0, GR4J_PLAN_INTS * sizeof(int), st));
     int blocks = (int)rr_ceil_div(N, 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(gr4j_scan_x4, dim3(blocks), dim3(256), 0, st, params, N,
-                       stride, x4_index, d_plan);
+                       stride, x4_index, mem_cap, d_plan);
     return RR_OK;
 }
 
@@ -444,7 +468,7 @@ extern "C" int rr_gr4j_plan_status(const void *workspace, void *stream)
         return RR_E_NULL;
     }
     hipStream_t st = (hipStream_t)stream;
-    int h[GR4J_PLAN_INTS] = {0, 0};
+    int h[GR4J_PLAN_INTS] = {0, 0, 0, 0};
     RR_HIP(hipMemcpyAsync(h, workspace, sizeof(h), hipMemcpyDeviceToHost, st));
     RR_HIP(hipStreamSynchronize(st));
     if (h[1] > 0) {
@@ -453,9 +477,11 @@ extern "C" int rr_gr4j_plan_status(const void *workspace, void *stream)
                      "reference raises IndexError there)", h[1]);
         return RR_E_PARAM;
     }
-    if ((double)h[0] > RR_GR4J_MAX_X4) {
-        rr_set_error("GR4J: x4 up to %d exceeds RR_GR4J_MAX_X4 = %g", h[0],
-                     (double)RR_GR4J_MAX_X4);
+    if ((double)h[0] > RR_GR4J_MAX_X4 && h[0] > h[2]) {
+        rr_set_error("GR4J: x4 up to %d needs a unit-hydrograph scratch behind "
+                     "the workspace (this one holds x4 <= %d): size the "
+                     "workspace with rr_*_workspace_bytes_x4", h[0],
+                     h[2] > (int)RR_GR4J_MAX_X4 ? h[2] : (int)RR_GR4J_MAX_X4);
         return RR_E_PARAM;
     }
     return RR_OK;
@@ -489,7 +515,11 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     hipStream_t st = (hipStream_t)stream;
     int *d_plan = (int *)workspace;
     GrDay *days = (GrDay *)((char *)workspace + 256);
-    rc = rr_gr4j_plan_async(params, N, 4, 3, d_plan, st);
+    // whatever lies behind the base workspace is unit-hydrograph scratch
+    const size_t base_ws = rr_gr4j_workspace_bytes(T, N);
+    double *uh_mem = (double *)((char *)workspace + base_ws);
+    const int mem_cap = gr4j_mem_cap(workspace_bytes - base_ws, N);
+    rc = rr_gr4j_plan_async(params, N, 4, 3, d_plan, mem_cap, st);
     if (rc != RR_OK) return rc;
     hipLaunchKernelGGL(gr4j_pack_forcing, dim3((unsigned)rr_ceil_div(T, 256)),
                        dim3(256), 0, st, prec, etp, qobs, T, days);
@@ -526,20 +556,21 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
                     return;
                 }
             }
-            if constexpr (!std::is_same<UH, UhLds>::value) {
+            if constexpr (!uh_is_indexed<UH>) {
                 if (variant == 3) {
                     gr4j_kernel<UH, Q.value, S.value, E.value, 4>
                         <<<dim3((unsigned)rr_ceil_div(waves, 4)),
                            dim3(4 * RR_BLOCK), 0, st>>>(
                             days, T, s_init, r_init, params, N, d_plan,
-                            force_lds, qsim, s_store, r_store, ld, qobs, sse);
+                            force_lds, qsim, s_store, r_store, ld, qobs, sse,
+                            uh_mem);
                     return;
                 }
             }
             gr4j_kernel<UH, Q.value, S.value, E.value>
                 <<<grid, block, lds, st>>>(
                     days, T, s_init, r_init, params, N, d_plan, force_lds,
-                    qsim, s_store, r_store, ld, qobs, sse);
+                    qsim, s_store, r_store, ld, qobs, sse, uh_mem);
         });
     });
     RR_HIP(hipGetLastError());

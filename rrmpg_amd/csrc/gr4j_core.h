@@ -16,6 +16,8 @@
 //              LDS as [slot][lane] (8-byte elements, lane-contiguous ->
 //              ds_read_b64 / ds_write_b64 are bank-conflict free) and the
 //              slot loop runs to the wave-uniform maximum length.
+//   UhMem      any x4 at all: the same [slot][lane] slab in HBM, behind the
+//              launch's workspace (rr_*_workspace_bytes_x4).
 //
 // In both, a slot j of a lane with n ordinates is updated as the reference
 // does (gr4j_model.py:130-136):  uh[j] = uh[j+1] + ord[j]*p  for j < n-1,
@@ -262,14 +264,24 @@ struct UhRegs {
     }
 };
 
-// ---- LDS tier ---------------------------------------------------------------
-// Layout inside the workgroup's dynamic LDS (doubles, RR_BLOCK lanes wide):
+// ---- indexed tiers: LDS (x4 <= 20) and global memory (any x4) -----------------
+// Layout inside the wave's slab (doubles, RR_BLOCK lanes wide) -- the
+// workgroup's dynamic LDS, or for UhMem the wave's part of the
+// unit-hydrograph scratch behind the workspace (HBM; every access a
+// coalesced 512-byte row per wave):
 //   [0,         n1cap)           uh1 slots
 //   [n1cap,     n1cap+n2cap)     uh2 slots
 //   then the same again for the ordinates.
-struct UhLds {
-    static constexpr int TIER = 0;
-    struct Slots {};     // (in place only: no second generation in LDS)
+// UhMem is what lets ANY x4 run, as in the reference, which simply builds
+// ceil(x4) and ceil(2 x4 + 1) ordinates (gr4j_model.py:68-79): slowly (three
+// memory accesses per slot and day), but with the same arithmetic and hence
+// the same bits as every other tier.
+#define GR4J_TIER_LDS 0
+#define GR4J_TIER_MEM 1000
+template <bool IN_LDS>
+struct UhIndexed {
+    static constexpr int TIER = IN_LDS ? GR4J_TIER_LDS : GR4J_TIER_MEM;
+    struct Slots {};     // (in place only: no second generation)
     double *base;        // this lane's column: base[slot * RR_BLOCK]
     int n1cap, n2cap;    // launch-wide capacities (host scan of max x4)
     int n1, n2;          // this lane's lengths
@@ -356,6 +368,36 @@ struct UhLds {
         }
     }
 };
+typedef UhIndexed<true> UhLds;
+typedef UhIndexed<false> UhMem;
+template <class UH>
+constexpr bool uh_is_indexed =
+    std::is_same<UH, UhLds>::value || std::is_same<UH, UhMem>::value;
+
+// doubles of one wave's slab for hydrographs of up to n1cap / n2cap ordinates
+static __host__ __device__ __forceinline__ size_t gr4j_slab_doubles(int n1cap,
+                                                                    int n2cap)
+{
+    return (size_t)2 * ((size_t)n1cap + (size_t)n2cap) * RR_BLOCK;
+}
+// bytes of unit-hydrograph scratch N sets need when the longest uh1 has n1
+// ordinates (uh2: 2 n1 + 1), and the longest n1 a scratch of `bytes` serves
+static inline size_t gr4j_mem_bytes(int64_t N, int64_t n1)
+{
+    if (N < 1 || n1 < 1) return 0;
+    return (size_t)rr_ceil_div(N, RR_BLOCK) *
+           gr4j_slab_doubles((int)n1, (int)(2 * n1 + 1)) * sizeof(double);
+}
+static inline int gr4j_mem_cap(size_t bytes, int64_t N)
+{
+    if (N < 1) return 0;
+    const size_t per_wave = bytes / (size_t)rr_ceil_div(N, RR_BLOCK);
+    // per wave: 2 * (n1 + 2 n1 + 1) * 64 * 8 = (6 n1 + 2) * 512 bytes
+    const size_t units = per_wave / 512;
+    if (units < 8) return 0;
+    const size_t n1 = (units - 2) / 6;
+    return n1 > 1000000 ? 1000000 : (int)n1;
+}
 
 
 // ---- which tier runs: decided ON THE DEVICE ----------------------------------
@@ -370,34 +412,58 @@ struct UhLds {
 // A parameter block the kernels cannot run (ceil(x4) < 1, NaN, or
 // x4 > RR_GR4J_MAX_X4) selects no tier: nothing is written, and
 // rr_gr4j_plan_status() reports it.
-#define GR4J_PLAN_INTS 2   // plan[0] = max ceil(x4), plan[1] = #bad sets
+// plan[0] = max ceil(x4), plan[1] = #bad sets, plan[2] = longest uh1 the
+// unit-hydrograph scratch behind this launch's workspace can hold (0: none)
+#define GR4J_PLAN_INTS 4
 // LDS-tier launches are sized for the longest hydrographs the tier holds
 #define GR4J_LDS_N1CAP ((int)RR_GR4J_MAX_X4)
 #define GR4J_LDS_N2CAP (2 * GR4J_LDS_N1CAP + 1)
 #define GR4J_LDS_BYTES \
     ((size_t)2 * (GR4J_LDS_N1CAP + GR4J_LDS_N2CAP) * RR_BLOCK * sizeof(double))
 
-// tier for a plan: 3 / 5 / 10 = UhRegs<3/5/10>, 0 = UhLds, -1 = none (error)
+// tier for a plan: 3 / 5 / 10 = UhRegs<3/5/10>, GR4J_TIER_LDS, GR4J_TIER_MEM,
+// -1 = none (error)
 static __host__ __device__ __forceinline__ int gr4j_plan_tier(int max_n1,
                                                               int bad,
-                                                              int force_lds)
+                                                              int force_lds,
+                                                              int mem_cap)
 {
-    if (bad > 0 || max_n1 < 1 || max_n1 > (int)RR_GR4J_MAX_X4) return -1;
-    if (force_lds || max_n1 > 10) return 0;
+    if (bad > 0 || max_n1 < 1) return -1;
+    if (max_n1 > (int)RR_GR4J_MAX_X4)
+        return max_n1 <= mem_cap ? GR4J_TIER_MEM : -1;
+    if (force_lds || max_n1 > 10) return GR4J_TIER_LDS;
     return max_n1 <= 3 ? 3 : (max_n1 <= 5 ? 5 : 10);
 }
 
 // true if this kernel instantiation (UH) is the one the plan selects; the
-// LDS tier also gets its capacities (the launch's longest hydrographs)
+// indexed tiers also get their capacities (the launch's longest hydrographs)
 template <class UH>
 __device__ __forceinline__ bool gr4j_plan_selects(const int *__restrict__ plan,
                                                   int force_lds, int &n1cap,
                                                   int &n2cap)
 {
     const int mx = plan[0], bad = plan[1];        // wave-uniform scalar loads
+    const int mem_cap = plan[2];
     n1cap = mx;
     n2cap = 2 * mx + 1;
-    return gr4j_plan_tier(mx, bad, force_lds) == UH::TIER;
+    return gr4j_plan_tier(mx, bad, force_lds, mem_cap) == UH::TIER;
+}
+
+// Hydrograph state of the lane, whichever tier: `lds` the workgroup's dynamic
+// LDS, `uh_mem` the launch's unit-hydrograph scratch (single-wave workgroups:
+// wave = blockIdx.x).
+template <class UH>
+__device__ __forceinline__ void gr4j_uh_init(UH &uh, double *lds,
+                                             double *uh_mem, int n1cap,
+                                             int n2cap, double x4)
+{
+    if constexpr (std::is_same<UH, UhLds>::value)
+        uh.init(lds, n1cap, n2cap, x4);
+    else if constexpr (std::is_same<UH, UhMem>::value)
+        uh.init(uh_mem + (size_t)blockIdx.x * gr4j_slab_doubles(n1cap, n2cap),
+                n1cap, n2cap, x4);
+    else
+        uh.init(x4);
 }
 
 // Calls f(UH{}) for every tier (the launch loop of the GR4J-family entries).
@@ -408,6 +474,7 @@ static inline void gr4j_for_each_tier(F &&f)
     f(UhRegs<5>{});
     f(UhRegs<10>{});
     f(UhLds{});
+    f(UhMem{});
 }
 
 // The transcendental calls of the daily step (reference: 1 tanh + 3 pow) are
@@ -656,7 +723,7 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
     const double p_r_uh2 = 0.1 * p_r;
 
     double head1, head2;
-    if constexpr (std::is_same<UH, UhLds>::value)
+    if constexpr (uh_is_indexed<UH>)
         uh.route(p_r_uh1, p_r_uh2, head1, head2);               // :130-136
     else
         uh.route(in, out, p_r_uh1, p_r_uh2, head1, head2, votes);
@@ -678,7 +745,7 @@ template <class UH>
 __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
                                                UH &uh, double p_r)
 {
-    if constexpr (std::is_same<UH, UhLds>::value) {
+    if constexpr (uh_is_indexed<UH>) {
         typename UH::Slots none;
         return gr4j_routing<UH>(P, r, uh, none, none, p_r);
     } else {

@@ -8,7 +8,10 @@
 // defined in gr4j.hip: enqueues the scan of x4 that leaves the plan
 // {max ceil(x4), #bad sets} at the start of the workspace (gr4j_core.h)
 int rr_gr4j_plan_async(const double *params, int64_t N, int stride,
-                       int x4_index, int *d_plan, hipStream_t st);
+                       int x4_index, int *d_plan, int mem_cap, hipStream_t st);
+// defined in gr4j.hip: bytes of unit-hydrograph scratch (UhMem, gr4j_core.h)
+// behind a workspace whose launch may hold x4 up to max_x4 (0 up to 20)
+size_t rr_gr4j_uh_scratch_bytes(int64_t N, double max_x4);
 
 // Day record of the snow kernels, D = cema_record_len(L, with_etp) doubles:
 //   [0, L) snow   [L, 2L) rain   [2L, 3L) mean temperature   [3L] etp (if any)

@@ -141,7 +141,7 @@ template <int L, class UH, bool HYST>
 constexpr int snow_min_waves()
 {
     return (L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
-                       std::is_same<UH, UhLds>::value)) ? (HYST ? 3 : 4) : 2;
+                       uh_is_indexed<UH>)) ? (HYST ? 3 : 4) : 2;
 }
 
 // Output pointers.  Passed as the FIRST kernel argument and never touched by
@@ -165,7 +165,8 @@ snow_gr4j_kernel(
     double thermal_state_init, double sca_init, double s_init, double r_init,
     const double *__restrict__ params, SnowParLayout lay, int64_t N,
     const int *__restrict__ plan, int force_lds, int wq, int ws,
-    const double *__restrict__ qobs, double *__restrict__ sse)
+    const double *__restrict__ qobs, double *__restrict__ sse,
+    double *__restrict__ uh_mem)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
@@ -191,8 +192,7 @@ snow_gr4j_kernel(
     const double *psol = gtresh + L;
     const double sca_prev0 = (T == 1) ? sca_init : 0.0;
     UH uh;
-    if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
-    else uh.init(P.x4);
+    gr4j_uh_init(uh, lds, uh_mem, n1cap, n2cap, P.x4);
     double s = s_init * P.x1, r = r_init * P.x3;
     double acc = 0.0;
     const bool we = sse != nullptr;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
     SnowParLayout lay, int64_t N, const int *__restrict__ plan,
     int force_lds, int wq, int ws,
     double *__restrict__ state, const double *__restrict__ qobs,
-    double *__restrict__ sse)
+    double *__restrict__ sse, double *__restrict__ uh_mem)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
@@ -319,8 +319,7 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
     const double *psol = gtresh + L;
     const double sca_prev0 = (T == 1) ? sca_init : 0.0;
     UH uh;
-    if constexpr (std::is_same<UH, UhLds>::value) uh.init(lds, n1cap, n2cap, P.x4);
-    else uh.init(P.x4);
+    gr4j_uh_init(uh, lds, uh_mem, n1cap, n2cap, P.x4);
     double s = s_init * P.x1, r = r_init * P.x3;
     double acc = 0.0;
     const bool we = sse != nullptr;
@@ -463,8 +462,12 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     lay.i_x1 = HYST ? 4 : 2;
     lay.i_ddf = lay.npar - 1;
     const int *d_plan = (const int *)workspace;
+    // whatever lies behind the base workspace is unit-hydrograph scratch
+    const size_t base_ws = cema_ws_bytes(T, L, true, N, 4);
+    double *uh_mem = (double *)((char *)workspace + base_ws);
+    const int mem_cap = gr4j_mem_cap(workspace_bytes - base_ws, N);
     rc = rr_gr4j_plan_async(params, N, lay.npar, lay.i_x1 + 3,
-                            (int *)workspace, st);
+                            (int *)workspace, mem_cap, st);
     if (rc != RR_OK) return rc;
     const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     double *days, *gt, *state;
@@ -487,7 +490,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
                    st>>>(out, days, gt, frac_ice, T, (int)L, snow_pack_init,
                          thermal_state_init, sca_init, s_init, r_init, params,
                          lay, N, d_plan, force_lds, qsim != nullptr,
-                         G != nullptr, state, qo, sse);
+                         G != nullptr, state, qo, sse, uh_mem);
         });
         RR_HIP(hipGetLastError());
         return RR_OK;
@@ -500,7 +503,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
                    st>>>(out, days, gt, frac_ice, T, snow_pack_init,
                          thermal_state_init, sca_init, s_init, r_init, params,
                          lay, N, d_plan, force_lds, qsim != nullptr,
-                         G != nullptr, qo, sse);
+                         G != nullptr, qo, sse, uh_mem);
         });
     });
     RR_HIP(hipGetLastError());
@@ -510,6 +513,13 @@ static int snow_gr4j_dev(const char *who, const double *prec,
 extern "C" size_t rr_snowgr4j_workspace_bytes(int64_t T, int64_t L, int64_t N)
 {
     return cema_ws_bytes(T, L, true, N, 4);   // N only matters for L > 8
+}
+
+extern "C" size_t rr_snowgr4j_workspace_bytes_x4(int64_t T, int64_t L,
+                                                 int64_t N, double max_x4)
+{
+    return cema_ws_bytes(T, L, true, N, 4) +
+           rr_gr4j_uh_scratch_bytes(N, max_x4);
 }
 
 extern "C" int rr_cemaneigehystgr4j_simulate_dev(

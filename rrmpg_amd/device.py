@@ -35,6 +35,12 @@ class _Ensemble:
     """Common plumbing: resident forcing, workspace, stream, launch."""
 
     NUM_PARAMS = 0
+    # GR4J-family ensembles: the largest x4 the parameter blocks of ``run``
+    # may hold.  Up to 20 the unit hydrographs live on chip; set a larger
+    # value and the workspace grows by the unit-hydrograph scratch the longer
+    # ones run from (N * (6 ceil(x4) + 2) * 8 B; rr_*_workspace_bytes_x4).  A
+    # block beyond it writes nothing and ``check()`` raises.
+    max_x4 = 20.0
 
     def __init__(self, device):
         self.lib = _lib.load()
@@ -260,11 +266,12 @@ class GR4JEnsemble(_Ensemble):
     def run(self, params, qsim=None, storages=None, qobs=None, sse=None):
         """Enqueue one sweep on the current stream; never synchronises.  The
         unit-hydrograph storage (registers for ceil(x4) <= 3 / 5 / 10, LDS up
-        to x4 = 20) is chosen on the GPU; a block with an unusable x4 leaves
-        the outputs untouched -- ``check()`` reports it."""
+        to x4 = 20, an HBM scratch up to ``self.max_x4`` beyond) is chosen on
+        the GPU; a block with an unusable x4 leaves the outputs untouched --
+        ``check()`` reports it."""
         n, sse = self._common(params, qobs, sse)
         t = self.num_timesteps
-        wsb = self.lib.rr_gr4j_workspace_bytes(t, n)
+        wsb = self.lib.rr_gr4j_workspace_bytes_x4(t, n, float(self.max_x4))
         ws = self._workspace(wsb)
         st = tuple(storages) if storages else (None,) * 2
         ld = self._check_outputs(n, (qsim,) + st)
@@ -335,7 +342,8 @@ class CemaneigeGR4JEnsemble(_Ensemble):
         GR4JEnsemble.run for the x4 rule and ``check()``."""
         n, sse = self._common(params, qobs, sse)
         t, nl = self.num_timesteps, self.num_layers
-        wsb = self.lib.rr_cemaneigegr4j_workspace_bytes(t, nl, n)
+        wsb = self.lib.rr_cemaneigegr4j_workspace_bytes_x4(
+            t, nl, n, float(self.max_x4))
         ws = self._workspace(wsb)
         st = tuple(storages) if storages else (None,) * 4
         ld = self._check_outputs(n, (qsim, st[2], st[3]), st[:2], nl)
@@ -478,7 +486,8 @@ class SnowGR4JEnsemble(_Ensemble):
         Asynchronous; see GR4JEnsemble.run for the x4 rule and ``check()``."""
         n, sse = self._common(params, qobs, sse)
         t, nl = self.num_timesteps, self.num_layers
-        wsb = self.lib.rr_snowgr4j_workspace_bytes(t, nl, n)
+        wsb = self.lib.rr_snowgr4j_workspace_bytes_x4(t, nl, n,
+                                                      float(self.max_x4))
         ws = self._workspace(wsb)
         st = storages or {}
         if st and sorted(st) != sorted(self.storage_names()):

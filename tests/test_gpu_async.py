@@ -116,7 +116,7 @@ def test_unusable_x4_is_reported_by_check(env, oracle):
     ref = oracle.simulate_gr4j(f["prec"][:t], f["etp"][:t], (.6, .7), flat)
     assert rel_err(q.cpu().numpy(), ref) < 1e-10
     for bad_x4, msg in ((-0.5, "ceil"), (float("nan"), "ceil"),
-                        (25.0, "exceeds")):
+                        (25.0, "unit-hydrograph scratch")):
         bad = flat.copy()
         bad[1, 3] = bad_x4
         q.fill_(-7.0)
@@ -128,6 +128,21 @@ def test_unusable_x4_is_reported_by_check(env, oracle):
     ens.run(good, q)                                  # and it recovers
     ens.check()
     assert rel_err(q.cpu().numpy(), ref) < 1e-10
+    # with a workspace sized for it (ens.max_x4) the long hydrograph runs,
+    # as in the reference
+    ens.max_x4 = 30.0
+    long = flat.copy()
+    long[1, 3] = 25.0
+    ens.run(ens.upload_params(long), q)
+    ens.check()
+    ref = oracle.simulate_gr4j(f["prec"][:t], f["etp"][:t], (.6, .7), long)
+    assert rel_err(q.cpu().numpy(), ref) < 1e-10
+    long[2, 3] = 31.0                                 # beyond THIS workspace
+    q.fill_(-7.0)
+    ens.run(ens.upload_params(long), q)
+    with pytest.raises(RuntimeError, match="unit-hydrograph scratch"):
+        ens.check()
+    assert bool((q == -7.0).all())
 
 
 def test_resident_ensembles_validate_their_tensors(env):

@@ -204,9 +204,10 @@ def test_next_tier_many_layers_vs_oracle(models, oracle):
             n = 77
             p = cls().get_random_params(n)
             flat = np.stack([p[k] for k in cls._param_list], 1)
-            if nl == 13:            # long unit hydrographs: LDS tier
+            if nl == 13:            # long unit hydrographs: LDS tier, or
+                # (x4 beyond 20) the HBM scratch the host path sizes itself
                 flat[:, cls._param_list.index("x4")] = \
-                    np.random.uniform(0.6, 14.0, n)
+                    np.random.uniform(0.6, 33.0 if hyst and ice else 14.0, n)
                 for j, k in enumerate(cls._param_list):
                     p[k] = flat[:, j]
             out, _ = core.run(hyst, ice, layers, fice if ice else None, inits,

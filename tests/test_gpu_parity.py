@@ -243,10 +243,79 @@ def test_gr4j_random_vs_oracle_and_limits(models, oracle, gr4j_variant):
     with pytest.raises(RuntimeError, match="RR_E_PARAM"):
         models.GR4J().simulate(g["prec"][:50], g["etp"][:50],
                                params=_records(models.GR4J, bad))
-    bad[1, 3] = 25.0
+    # any other x4 runs, as in the reference (gr4j_model.py:68-79): beyond 20
+    # from a unit-hydrograph scratch in HBM the host path sizes itself
+    flat[:, 3] = rng.uniform(0.5, 60.0, 257)
+    flat[5, 3] = 137.2
+    ref = oracle.simulate_gr4j(g["prec"][:t], g["etp"][:t], (0.3, 0.5), flat,
+                               return_storage=True)
+    out = models.GR4J().simulate(g["prec"][:t], g["etp"][:t], 0.3, 0.5,
+                                 return_storage=True,
+                                 params=_records(models.GR4J, flat))
+    for a, b in zip(out, ref):
+        assert rel_err(a, b) < RTOL
+    bad[1, 3] = 2.5e5
     with pytest.raises(RuntimeError, match="RR_E_PARAM"):
         models.GR4J().simulate(g["prec"][:50], g["etp"][:50],
                                params=_records(models.GR4J, bad))
+
+
+def test_a_sets_bits_do_not_depend_on_its_launch(models, oracle):
+    """One arithmetic per model whatever the unit-hydrograph storage: the
+    same parameter set alone, inside a default-bounds block (3+7 registers),
+    inside an x4 <= 5 / x4 <= 10 block (wider register tiers), an x4 <= 20
+    block (LDS) and an x4 = 35 block (HBM scratch) gives the same discharge
+    and stores, bit for bit -- GR4J and the fused CemaneigeGR4J."""
+    from rrmpg_amd.models import cemaneigegr4j as fmod
+    from rrmpg_amd.models import gr4j as gmod
+    g = golden("syn_gr4j")
+    h = golden("syn_cemaneigehystgr4j")
+    rng = np.random.default_rng(77)
+    t = 700
+    lo, hi = np.array([100, -5, 20, 1.1]), np.array([1200, 3, 300, 2.9])
+    probe = np.array([[350.0, 0.7, 90.0, 1.9], [800.0, -2.0, 40.0, 2.7]])
+    qobs = rng.uniform(0, 3, t)
+
+    def block(max_x4, n=130):
+        flat = lo + (hi - lo) * rng.random((n, 4))
+        flat[:, 3] = rng.uniform(1.1, max_x4, n)
+        flat[n // 2, 3] = max_x4               # the launch's longest
+        flat[7], flat[n - 3] = probe[0], probe[1]
+        return flat
+
+    def gr4j(flat):
+        out, sse = gmod._run(g["prec"][:t], g["etp"][:t], 0.3, 0.5,
+                             _records(models.GR4J, flat), True, True, qobs)
+        return out, sse
+
+    alone, sse_alone = gr4j(probe)
+    for max_x4 in (2.9, 4.6, 9.3, 18.0, 35.0):
+        out, sse = gr4j(block(max_x4))
+        for a, b in zip(out, alone):
+            assert np.array_equal(a[:, 7], b[:, 0]), max_x4
+            assert np.array_equal(a[:, 127], b[:, 1]), max_x4
+        assert sse[7] == sse_alone[0] and sse[127] == sse_alone[1]
+    # fused kernel: {CTG, Kf, x1, x2, x3, x4}
+    layers = tuple(h[k][:t] for k in ("layer_prec", "layer_mean",
+                                      "frac_solid", "etp"))
+    probe6 = np.array([[0.4, 4.0, 350.0, 0.7, 90.0, 1.9],
+                       [0.9, 2.0, 800.0, -2.0, 40.0, 2.7]])
+
+    def fused(flat):
+        out, _ = fmod._run(layers, (3.0, -0.2, 0.4, 0.5),
+                           _records(models.CemaneigeGR4J, flat), True, True,
+                           None)
+        return out
+
+    alone = fused(probe6)
+    for max_x4 in (2.9, 4.6, 9.3, 18.0, 35.0):
+        flat = np.column_stack([rng.uniform(0, 1, 130), rng.uniform(0, 10, 130),
+                                block(max_x4)])
+        flat[7], flat[127] = probe6[0], probe6[1]
+        out = fused(flat)
+        for a, b in zip(out, alone):
+            assert np.array_equal(a[..., 7], b[..., 0]), max_x4
+            assert np.array_equal(a[..., 127], b[..., 1]), max_x4
 
 
 def test_gr4j_zero_rain(models, gr4j_variant):
