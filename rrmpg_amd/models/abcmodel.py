@@ -96,9 +96,11 @@ class ABCModel(BaseModel):
         (abcmodel.py:188-232); every candidate is one GPU call that returns
         only its squared-error sum.
 
-        batched (default True): one GPU sweep per generation;
-        batched=False: one candidate per call, the reference's own optimiser
-        trajectory (BaseModel._differential_evolution).
+        batched (default True): one GPU sweep per generation -- a DIFFERENT
+        optimiser trajectory than the reference's (a seeded fit ends in other,
+        equally good parameters); batched=False: one candidate per call, the
+        reference's own call, which reproduces its seeded runs evaluation by
+        evaluation (tests/test_gpu_fit_reference.py).
 
         Returns:
             res: A scipy OptimizeResult class object.

@@ -95,6 +95,15 @@ class CemaneigeGR4JIce(BaseModel):
         """Fit the model to an observed discharge series (scipy differential
         evolution on the MSE; reference: cemaneigegr4jice.py:290-417).
 
+        batched: (extension) True (default): scipy gets a vectorised loss and
+            every generation's population is ONE GPU sweep
+            (updating='deferred') -- about a hundred times faster, but a
+            DIFFERENT optimiser trajectory than the reference's: a seeded fit
+            ends in other (equally good) parameters.  batched=False is the
+            reference's own call -- one candidate per loss evaluation,
+            immediate updating -- and reproduces its seeded runs evaluation
+            by evaluation (tests/test_gpu_fit_reference.py).
+
         Returns:
             res: A scipy OptimizeResult class object.
         """

@@ -105,6 +105,15 @@ class CemaneigeHystGR4J(BaseModel):
         evolution; loss_metric 'mse' or 'kge'; reference:
         cemaneigehystgr4j.py:292-424).
 
+        batched: (extension) True (default): scipy gets a vectorised loss and
+            every generation's population is ONE GPU sweep
+            (updating='deferred') -- about a hundred times faster, but a
+            DIFFERENT optimiser trajectory than the reference's: a seeded fit
+            ends in other (equally good) parameters.  batched=False is the
+            reference's own call -- one candidate per loss evaluation,
+            immediate updating -- and reproduces its seeded runs evaluation
+            by evaluation (tests/test_gpu_fit_reference.py).
+
         Returns:
             res: A SciPy OptimizeResult object.
         """
@@ -125,6 +134,15 @@ class CemaneigeHystGR4J(BaseModel):
         """Fit to discharge AND the snow-covered area of five elevation bands
         (NDSI1..NDSI5, in percent); 75 % / 5 x 5 % weighting (reference:
         cemaneigehystgr4j.py:427-570).
+
+        batched: (extension) True (default): scipy gets a vectorised loss and
+            every generation's population is ONE GPU sweep
+            (updating='deferred') -- about a hundred times faster, but a
+            DIFFERENT optimiser trajectory than the reference's: a seeded fit
+            ends in other (equally good) parameters.  batched=False is the
+            reference's own call -- one candidate per loss evaluation,
+            immediate updating -- and reproduces its seeded runs evaluation
+            by evaluation (tests/test_gpu_fit_reference.py).
 
         Returns:
             res: A SciPy OptimizeResult object.

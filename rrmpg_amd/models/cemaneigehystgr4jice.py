@@ -92,6 +92,15 @@ class CemaneigeHystGR4JIce(BaseModel):
         evolution; loss_metric 'mse' or 'kge'; reference:
         cemaneigehystgr4jice.py:308-445).
 
+        batched: (extension) True (default): scipy gets a vectorised loss and
+            every generation's population is ONE GPU sweep
+            (updating='deferred') -- about a hundred times faster, but a
+            DIFFERENT optimiser trajectory than the reference's: a seeded fit
+            ends in other (equally good) parameters.  batched=False is the
+            reference's own call -- one candidate per loss evaluation,
+            immediate updating -- and reproduces its seeded runs evaluation
+            by evaluation (tests/test_gpu_fit_reference.py).
+
         Returns:
             res: A SciPy OptimizeResult object.
         """
@@ -111,6 +120,15 @@ class CemaneigeHystGR4JIce(BaseModel):
                   altitudes=[], batched=True):
         """Fit to discharge AND the snow-covered area of five elevation bands
         (reference: cemaneigehystgr4jice.py:447-593).
+
+        batched: (extension) True (default): scipy gets a vectorised loss and
+            every generation's population is ONE GPU sweep
+            (updating='deferred') -- about a hundred times faster, but a
+            DIFFERENT optimiser trajectory than the reference's: a seeded fit
+            ends in other (equally good) parameters.  batched=False is the
+            reference's own call -- one candidate per loss evaluation,
+            immediate updating -- and reproduces its seeded runs evaluation
+            by evaluation (tests/test_gpu_fit_reference.py).
 
         Returns:
             res: A SciPy OptimizeResult object.
