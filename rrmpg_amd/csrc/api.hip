@@ -82,6 +82,27 @@ extern "C" int rr_device_count(void)
     return n;
 }
 
+int rr_simd_count()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return 1024;
+    }
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
+                              dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    v = 4 * cus;
+    cached[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
+
 int rr_check_common(const char *who, int64_t T, int64_t N, int64_t ld,
                     const void *params, const void *qobs, const void *sse)
 {

@@ -830,6 +830,10 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
     const int mem_cap = gr4j_mem_cap(workspace_bytes - base_ws, N);
     rc = rr_gr4j_plan_async(params, N, 6, 5, (int *)workspace, mem_cap, st);
     if (rc != RR_OK) return rc;
+    // a block the plan cannot run (no tier selected) writes nothing: its
+    // scores then read NaN, not whatever the buffer held
+    if (qobs && sse)
+        RR_HIP(hipMemsetAsync(sse, 0xFF, (size_t)N * sizeof(double), st));
     const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     double *days, *gt, *state;
     rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp,
@@ -857,8 +861,8 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
     }
     const CoupledOut out = {qsim, G, eTG, s_store, r_store, ld};
     // at most two waves per SIMD: the small-sweep variant where there is one
-    // (1024 SIMDs on an MI355X)
-    const bool small = (int64_t)grid.x <= 2048 &&
+    // (1024 SIMDs on a whole MI355X)
+    const bool small = (int64_t)grid.x <= 2 * (int64_t)rr_simd_count() &&
                        rr_option(RR_OPT_FUSED_VARIANT) != 1;
     const int fv = (int)rr_option(RR_OPT_FUSED_VARIANT);
     dispatch_layers((int)L, [&](auto LL) {

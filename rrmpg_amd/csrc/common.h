@@ -245,6 +245,11 @@ static inline int64_t rr_ceil_div(int64_t a, int64_t b) {
 }
 static inline size_t rr_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// SIMDs of the current device (4 per compute unit of what the process sees --
+// 1024 on a whole MI355X, fewer in a partitioned mode): the kernel-variant
+// choices by sweep size count waves per SIMD with it.  Cached per device.
+int rr_simd_count();
+
 // Common argument checks of the *_simulate_dev entry points.
 int rr_check_common(const char *who, int64_t T, int64_t N, int64_t ld,
                     const void *params, const void *qobs, const void *sse);

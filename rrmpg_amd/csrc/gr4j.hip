@@ -521,6 +521,10 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     const int mem_cap = gr4j_mem_cap(workspace_bytes - base_ws, N);
     rc = rr_gr4j_plan_async(params, N, 4, 3, d_plan, mem_cap, st);
     if (rc != RR_OK) return rc;
+    // a block the plan cannot run (no tier selected) writes nothing: its
+    // scores then read NaN, not whatever the buffer held
+    if (qobs && sse)
+        RR_HIP(hipMemsetAsync(sse, 0xFF, (size_t)N * sizeof(double), st));
     hipLaunchKernelGGL(gr4j_pack_forcing, dim3((unsigned)rr_ceil_div(T, 256)),
                        dim3(256), 0, st, prec, etp, qobs, T, days);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);

@@ -437,7 +437,11 @@ static int hbv_launch(const double *temp, const double *prec,
     // ties from about twelve on, where the plain loop (one wave per SIMD
     // more) is kept.  rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one.
     const int64_t waves = rr_ceil_div(N, RR_BLOCK) * C;
-    int variant = ((waves > 1024 && waves <= 2048) || waves > 10240) ? 0 : 2;
+    // (waves per SIMD of the device the process sees: 1024 SIMDs on a whole
+    // MI355X)
+    const int64_t simds = rr_simd_count();
+    const bool two_per_simd = waves > simds && waves <= 2 * simds;
+    int variant = (two_per_simd || waves > 10 * simds) ? 0 : 2;
     const int64_t pinned = rr_option(RR_OPT_HBV_VARIANT);
     if (pinned >= 0) variant = (int)pinned;
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
@@ -451,7 +455,6 @@ static int hbv_launch(const double *temp, const double *prec,
         };
         // (measured, kernel ms with / without the second loop copy: 65k sets
         // 3.14 / 3.22, 125k 3.76 / 3.70, 250k 7.45 / 7.62, 1M 27.4 / 27.8)
-        const bool two_per_simd = waves > 1024 && waves <= 2048;
         if (variant == 1) go(std::integral_constant<int, 1>{}, std::false_type{});
         else if (variant == 2) go(std::integral_constant<int, 2>{}, std::true_type{});
         else if (two_per_simd) go(std::integral_constant<int, 0>{}, std::false_type{});

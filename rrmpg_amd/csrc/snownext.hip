@@ -469,6 +469,10 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     rc = rr_gr4j_plan_async(params, N, lay.npar, lay.i_x1 + 3,
                             (int *)workspace, mem_cap, st);
     if (rc != RR_OK) return rc;
+    // a block the plan cannot run (no tier selected) writes nothing: its
+    // scores then read NaN, not whatever the buffer held
+    if (qobs && sse)
+        RR_HIP(hipMemsetAsync(sse, 0xFF, (size_t)N * sizeof(double), st));
     const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     double *days, *gt, *state;
     rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp,

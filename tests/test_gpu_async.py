@@ -120,11 +120,13 @@ def test_unusable_x4_is_reported_by_check(env, oracle):
         bad = flat.copy()
         bad[1, 3] = bad_x4
         q.fill_(-7.0)
-        ens.run(ens.upload_params(bad), q)            # returns, no error yet
+        sse = ens.run(ens.upload_params(bad), q,      # returns, no error yet
+                      qobs=torch.zeros(t, dtype=torch.float64, device="cuda"))
         with pytest.raises(RuntimeError, match="RR_E_PARAM") as ei:
             ens.check()
         assert msg in str(ei.value)
         assert bool((q == -7.0).all())                # nothing was written
+        assert bool(torch.isnan(sse).all())           # and the scores say so
     ens.run(good, q)                                  # and it recovers
     ens.check()
     assert rel_err(q.cpu().numpy(), ref) < 1e-10
