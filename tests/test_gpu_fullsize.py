@@ -216,6 +216,30 @@ def test_config2_gr4j_1m_scores(env, oracle):
     q = ens.new_output(32)
     ens.run(ens.upload_params(flat[cols]), q)
     assert rel_err(q.cpu().numpy(), ref) < RTOL
+    # the 1M-set qsim mode (what the bench's extra config and the profiles
+    # time): 64 columns of the resident 87.7-GB array, first and last
+    # included, against the oracle; its fused sums equal the score-only
+    # sweep's bit for bit; and the kernel variants agree on them
+    from rrmpg_amd import _lib
+    qsim = ens.new_output(n)
+    sse_q = ens.run(params, qsim, qobs=qobs)
+    ens.check()
+    assert torch.equal(sse_q, sse)
+    cols = np.unique(np.concatenate([[0, n - 1], rng.choice(n, 62,
+                                                            replace=False)]))
+    ref = oracle.simulate_gr4j(f["prec"], f["etp"], (0.6, 0.7), flat[cols],
+                               nthreads=8)
+    tcols = torch.from_numpy(cols).cuda()
+    got = qsim[:, tcols].cpu().numpy()
+    assert rel_err(got, ref) < RTOL
+    for v in (1, 3):
+        with _lib.debug_option("gr4j_variant", v):
+            qsim.fill_(-1.0)
+            sse_v = ens.run(params, qsim, qobs=qobs)
+            torch.cuda.synchronize()
+        assert torch.equal(sse_v, sse), v
+        assert np.array_equal(qsim[:, tcols].cpu().numpy(), got), v
+    del qsim
 
 
 def test_config3_cemaneigegr4j_shard_nse(env, oracle, fused_variant):
