@@ -101,24 +101,55 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 // qualify for it (see day_step); without it the kernel is the general loop
 // alone -- what hbv_launch picks for sweeps of exactly two waves per SIMD,
 // where the second copy's register pressure costs more than it saves.
+//
+// TILED: the time axis in PIECES, the waves persistent.  A million-set sweep
+// is 15,625 waves of equal duration on 1,024 SIMDs: 15.26 per SIMD, so 265
+// SIMDs run a sixteenth wave while the others idle -- the kernel takes 16
+// wave slots for 15.26 slots of work (4.6 %).  Here exactly as many waves
+// are launched as are resident at once, and each pulls work items (piece p
+// of the 64 sets of job j: days [t_p, t_p+1)) from one atomic counter, in
+// piece-major order; the states (four stores + the score sum) travel from
+// piece to piece through a small HBM scratch, handed over with a release /
+// acquire pair at agent scope and a per-job flag.  Items are a quarter as
+// long, slots refill as they free, and the SIMDs finish within a fraction
+// of a wave of each other.  No deadlock: a wave waits only for an item with
+// a smaller index, which a resident wave took before it.  Bit-identical to
+// the untiled loop (same operations in the same order, the score summed in
+// time order across the pieces).
+#ifndef HBV_TILED_MINWAVES
+#define HBV_TILED_MINWAVES 1
+#endif
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
-          bool TAME = true>
-__global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
+          bool TAME = true, bool TILED = false>
+__global__ __launch_bounds__(RR_BLOCK, (TILED ? HBV_TILED_MINWAVES : 1)) void
+hbvedu_kernel(
     const HbvDay *__restrict__ days, int64_t T, double snow_init,
     double soil_init, double s1_init, double s2_init,
     const double *__restrict__ inits, const double *__restrict__ params,
     int64_t N, double *__restrict__ qsim, double *__restrict__ snow_out,
     double *__restrict__ soil_out, double *__restrict__ s1_out,
     double *__restrict__ s2_out, int64_t ld, const double *__restrict__ qobs,
-    double *__restrict__ sse, const int *__restrict__ odd_prec)
+    double *__restrict__ sse, const int *__restrict__ odd_prec,
+    int *__restrict__ queue, double *__restrict__ tile_state, int pieces)
 {
     __shared__ FpPowLogEntry powlog[FP_POWLOG_N];
     for (int j = threadIdx.x; j < FP_POWLOG_N; j += RR_BLOCK)
         powlog[j] = HBV_POWLOG_TABLE[j];
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
+  for (;;) {           // TILED: one work item per trip; otherwise one trip
+    int job = blockIdx.x, piece = 0;
+    if constexpr (TILED) {
+        int item = 0;
+        if (threadIdx.x == 0) item = atomicAdd(queue, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= pieces * njobs) break;
+        piece = item / njobs;
+        job = item - piece * njobs;
+    }
+    const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
-    {
+    if constexpr (!TILED) {
         const int64_t c = blockIdx.y;          // wave-uniform
         days += c * T;
         params += c * N * 11;
@@ -162,21 +193,49 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     // with scalar adds) + (this lane's fixed column inside the wave's 512-byte
     // segment): no vector address arithmetic inside the time loop.
     const int lane_off = threadIdx.x * 8;
-    const int64_t first = (int64_t)blockIdx.x * RR_BLOCK;
+    const int64_t first = (int64_t)job * RR_BLOCK;
     const unsigned row_bytes = rr_row_bytes(first, N);
     int64_t row = first;                            // t * ld + first column
-
-    // t = 0: qsim[0] = 0, state[0] = init (hbvedu_model.py:71-81)
-    if (WRITE_Q) rr_store_row(qsim + row, row_bytes, lane_off, 0.0);
-    if (WRITE_S) {
-        rr_store_row(snow_out + row, row_bytes, lane_off, snow);
-        rr_store_row(soil_out + row, row_bytes, lane_off, soil);
-        rr_store_row(s1_out + row, row_bytes, lane_off, s1);
-        rr_store_row(s2_out + row, row_bytes, lane_off, s2);
+    // this trip's days [t_begin, t_end)
+    const int Ti = (int)T;
+    int t_begin = 1, t_end = Ti;
+    // a piece's states in the scratch: [5][njobs * 64], lane-contiguous
+    double *const hand = TILED ? tile_state + ((int64_t)job * RR_BLOCK +
+                                               threadIdx.x) : nullptr;
+    const int64_t hand_stride = (int64_t)njobs * RR_BLOCK;
+    if constexpr (TILED) {
+        const int len = (Ti - 1 + pieces - 1) / pieces;
+        t_begin = 1 + piece * len;
+        t_end = t_begin + len < Ti ? t_begin + len : Ti;
+        if (t_begin > Ti) t_begin = Ti;
+        row = first + (int64_t)(t_begin - 1) * ld;
     }
-    if (WITH_SSE) {
-        const double d = qobs[0] - 0.0;
-        acc = d * d;
+    if (TILED && piece > 0) {
+        // the piece before this one (a smaller item, taken earlier by a
+        // resident wave) publishes flag = piece when its states are out
+        int *flag = queue + 1 + job;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT) < piece)
+            __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        snow = hand[0];
+        soil = hand[hand_stride];
+        s1 = hand[2 * hand_stride];
+        s2 = hand[3 * hand_stride];
+        acc = hand[4 * hand_stride];
+    } else {
+        // t = 0: qsim[0] = 0, state[0] = init (hbvedu_model.py:71-81)
+        if (WRITE_Q) rr_store_row(qsim + row, row_bytes, lane_off, 0.0);
+        if (WRITE_S) {
+            rr_store_row(snow_out + row, row_bytes, lane_off, snow);
+            rr_store_row(soil_out + row, row_bytes, lane_off, soil);
+            rr_store_row(s1_out + row, row_bytes, lane_off, s1);
+            rr_store_row(s2_out + row, row_bytes, lane_off, s2);
+        }
+        if (WITH_SSE) {
+            const double d = qobs[0] - 0.0;
+            acc = d * d;
+        }
     }
 
     // (the record is taken BY VALUE: one s_load_dwordx8 per day up front; a
@@ -187,7 +246,6 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
     // (32-bit day counters: hbv_launch rejects T >= 2^31; a 64-bit count
     // costs a second scalar add per day and, in the unrolled loop, a VALU
     // compare -- there is no 64-bit signed scalar compare)
-    const int Ti = (int)T;
     // `tame` (a std::bool_constant): the wave runs the copy of the time loop
     // in which `min(snow, melt)` (:94) is one v_min_f64.  numba's min(a, b) is
     // `b if b < a else a`: a compare and a 64-bit select, because the
@@ -355,14 +413,14 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
             // (two days per trip, written out -- the votes are convergent
             // operations, which keeps hipcc from unrolling a loop with a
             // remainder on its own: one taken branch per two days)
-            int t = 1;
-            for (; t + 1 < Ti; t += 2) {
+            int t = t_begin;
+            for (; t + 1 < t_end; t += 2) {
                 const HbvDay f0 = days[t];     // wave-uniform -> s_load_dwordx8
                 day_step(f0, t, [] {}, tame);
                 const HbvDay f1 = days[t + 1];
                 day_step(f1, t + 1, [] {}, tame);
             }
-            if (t < Ti) {
+            if (t < t_end) {
                 const HbvDay f = days[t];
                 day_step(f, t, [] {}, tame);
             }
@@ -388,19 +446,56 @@ __global__ __launch_bounds__(RR_BLOCK) void hbvedu_kernel(
         (void)tame_wave;
         time_loop(std::false_type{});
     }
-    if (WITH_SSE && active) sse[i] = acc;
+    if (TILED && piece + 1 < pieces) {
+        // hand the states to the next piece: stores, release at agent scope
+        // (the next piece may run on another XCD), then the flag
+        hand[0] = snow;
+        hand[hand_stride] = soil;
+        hand[2 * hand_stride] = s1;
+        hand[3 * hand_stride] = s2;
+        hand[4 * hand_stride] = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (threadIdx.x == 0)
+            __hip_atomic_store(queue + 1 + job, piece + 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (WITH_SSE && active) sse[i] = acc;
+    }
+    if constexpr (!TILED) break;
+  }
+}
+
+// forcing records (+ 1: the spare record the prefetching variant may touch)
+// and the pre-pass's flags of odd precipitation values (one int per 256 days)
+static size_t hbv_forcing_bytes(int64_t T, int64_t C)
+{
+    if (T < 1) T = 1;
+    if (C < 1) C = 1;
+    return rr_align256((size_t)(T * C + 1) * sizeof(HbvDay) +
+                       (size_t)rr_ceil_div(T, 256) * (size_t)C * sizeof(int));
+}
+// the tiled kernel's work queue {counter, flag per job} and its hand-over
+// scratch [5][jobs * 64]
+static size_t hbv_queue_bytes(int64_t N)
+{
+    return rr_align256((size_t)(rr_ceil_div(N > 0 ? N : 1, RR_BLOCK) + 1) *
+                       sizeof(int));
+}
+static size_t hbv_tile_bytes(int64_t N)
+{
+    return hbv_queue_bytes(N) +
+           rr_align256((size_t)5 * (size_t)rr_ceil_div(N > 0 ? N : 1, RR_BLOCK) *
+                       RR_BLOCK * sizeof(double));
 }
 
 extern "C" size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N)
 {
-    (void)N;
     if (T < 0) T = 0;
     // + 1: the spare record the prefetching kernel variant may touch; + the
     // pre-pass's flags of odd precipitation values (one int per 256 days)
     // behind it
     if (T < 1) T = 1;
-    return rr_align256((size_t)(T + 1) * sizeof(HbvDay) +
-                       (size_t)rr_ceil_div(T, 256) * sizeof(int));
+    return hbv_forcing_bytes(T, 1) + hbv_tile_bytes(N);
 }
 
 // Shared by the single- and multi-catchment entry points.
@@ -444,14 +539,56 @@ static int hbv_launch(const double *temp, const double *prec,
     int variant = (two_per_simd || waves > 10 * simds) ? 0 : 2;
     const int64_t pinned = rr_option(RR_OPT_HBV_VARIANT);
     if (pinned >= 0) variant = (int)pinned;
+    // time-tiled persistent form (hbvedu_kernel's TILED): for sweeps of many
+    // rounds of waves, where equal-length waves quantise the kernel time to
+    // whole wave slots (1M sets: 16 slots for 15.26 slots of work).
+    // RR_OPT_HBV_TILES: -1 by sweep size (4 pieces from ten waves per SIMD
+    // on), 0 never, k > 1 pieces.
+    int pieces = 0;
+    {
+        const int64_t opt = rr_option(RR_OPT_HBV_TILES);
+        if (C == 1 && variant == 0 && !two_per_simd && T > 16) {
+            if (opt > 1) pieces = (int)opt;
+            else if (opt < 0 && waves > 10 * simds) pieces = 4;
+        }
+    }
+    int *queue = nullptr;
+    double *tile_state = nullptr;
+    if (pieces > 1) {
+        queue = (int *)((char *)workspace + hbv_forcing_bytes(T, 1));
+        tile_state = (double *)((char *)queue + hbv_queue_bytes(N));
+        RR_HIP(hipMemsetAsync(queue, 0, hbv_queue_bytes(N), st));
+    }
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
                  [&](auto Q, auto S, auto E) {
         auto go = [&](auto V, auto tame) {
+            if constexpr (V.value == 0 && tame.value) {
+                if (pieces > 1) {
+                    auto kern = hbvedu_kernel<Q.value, S.value, E.value, 0,
+                                              true, true>;
+                    // as many waves as are resident at once, no more
+                    int per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                            &per_cu, kern, RR_BLOCK, 0) != hipSuccess ||
+                        per_cu < 1) {
+                        (void)hipGetLastError();
+                        per_cu = 16;
+                    }
+                    int64_t resident = (int64_t)per_cu * (simds / 4);
+                    const int64_t items = (int64_t)pieces * waves;
+                    if (resident > items) resident = items;
+                    kern<<<dim3((unsigned)resident), dim3(RR_BLOCK), 0, st>>>(
+                        days, T, snow_init, soil_init, s1_init, s2_init, inits,
+                        params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
+                        odd_prec, queue, tile_state, pieces);
+                    return;
+                }
+            }
             hbvedu_kernel<Q.value, S.value, E.value, V.value, tame.value>
                 <<<grid, dim3(RR_BLOCK), 0, st>>>(
                     days, T, snow_init, soil_init, s1_init, s2_init, inits,
                     params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
-                    odd_prec);
+                    odd_prec, nullptr, nullptr, 0);
         };
         // (measured, kernel ms with / without the second loop copy: 65k sets
         // 3.14 / 3.22, 125k 3.76 / 3.70, 250k 7.45 / 7.62, 1M 27.4 / 27.8)

@@ -574,6 +574,19 @@ def test_kernel_variants_agree_bit_for_bit(models):
             base = out
         for a, b in zip(out, base):
             assert np.array_equal(a, b), "HBV variant %d" % v
+    # the time-tiled persistent form of the plain loop (million-set sweeps):
+    # pieces of the time axis pulled from a work queue, states handed from
+    # piece to piece through HBM -- every output and the score sum bit for bit
+    qobs = rng.uniform(0, 5, t)
+    with _lib.debug_option("hbv_variant", 0):
+        ref_out, ref_sse = hmod._run(forcing, inits, rec, True, True, qobs)
+        for tiles in (2, 3, 4, 7, 64):
+            with _lib.debug_option("hbv_tiles", tiles):
+                out, sse = hmod._run(forcing, inits, rec, True, True, qobs)
+                only, sse2 = hmod._run(forcing, inits, rec, False, False, qobs)
+            for a, b in zip(out, ref_out):
+                assert np.array_equal(a, b), "HBV tiles %d" % tiles
+            assert np.array_equal(sse, ref_sse) and np.array_equal(sse2, ref_sse)
     # the same sets inside a launch of two waves per SIMD (no TAME copy)
     big = np.tile(flat, (300, 1))[:90_000]
     outb, _ = hmod._run(forcing, inits, _records(models.HBVEdu, big), True,
