@@ -85,8 +85,8 @@ def parse_args():
     ap.add_argument("--hbv-variant", type=int, default=-1,
                     help="measurement hook: pin the HBV-Edu kernel variant "
                          "(rr_debug_set_option RR_OPT_HBV_VARIANT)")
-    ap.add_argument("--hbv-tiles", type=int, default=-1,
-                    help="measurement hook: RR_OPT_HBV_TILES (0 untiled, k > 1 "
+    ap.add_argument("--time-tiles", type=int, default=-1,
+                    help="measurement hook: RR_OPT_TIME_TILES (0 untiled, k > 1 "
                          "pieces of the time axis; default by sweep size)")
     ap.add_argument("--fused-variant", type=int, default=0,
                     help="measurement hook: pin the CemaneigeGR4J kernel "
@@ -569,7 +569,7 @@ def main():
     on_host = world > 1 and args.backend == "gloo"
     for opt, val in (("hbv_variant", args.hbv_variant if args.hbv_variant >= 0
                       else None),
-                     ("hbv_tiles", args.hbv_tiles if args.hbv_tiles >= 0
+                     ("time_tiles", args.time_tiles if args.time_tiles >= 0
                       else None),
                      ("gr4j_variant", args.gr4j_variant or None),
                      ("fused_variant", args.fused_variant or None)):

@@ -135,11 +135,12 @@ int rr_release_cached_memory(void);
                                   * one shard per visible device.  No
                                   * collective: sets are independent, the
                                   * forcing is uploaded to every device.      */
-#define RR_OPT_HBV_TILES       8 /* HBV-Edu, million-set sweeps: the time axis
-                                  * in pieces pulled from a work queue by
-                                  * persistent waves (evens out the last round
-                                  * of equal-length waves): -1 by sweep size
-                                  * (default), 0 never, k > 1 pieces          */
+#define RR_OPT_TIME_TILES      8 /* million-set sweeps (HBV-Edu, GR4J): the time
+                                  * axis in pieces pulled from a work queue by
+                                  * persistent waves, which evens out the last
+                                  * round of equal-length waves: -1 by sweep
+                                  * size (default: 4 pieces from ten waves per
+                                  * SIMD on), 0 never, k > 1 pieces           */
 #define RR_OPT_COUNT_          9
 int rr_debug_set_option(int option, int64_t value);
 int64_t rr_debug_get_option(int option);

@@ -56,7 +56,7 @@ extern "C" int rr_debug_set_option(int option, int64_t value)
     case RR_OPT_MAX_BLOCK_COLS: ok = value >= 0; break;
     case RR_OPT_GATHER_THREADS: ok = value >= 0 && value <= 256; break;
     case RR_OPT_HOST_SHARDS: ok = value >= -1 && value <= 1024; break;
-    case RR_OPT_HBV_TILES: ok = value >= -1 && value <= 64 && value != 1; break;
+    case RR_OPT_TIME_TILES: ok = value >= -1 && value <= 64 && value != 1; break;
     default: break;
     }
     if (!ok) {

@@ -14,6 +14,7 @@
 // through the scalar cache), so single-wave workgroups give the
 // dispatcher the finest granule to spread over 256 CUs x 4 SIMDs.
 #define RR_BLOCK 64
+static inline size_t rr_align256_(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // numba's max(a, b) / min(a, b): select(b > a, b, a) / select(b < a, b, a)
 // (numba/cpython/builtins.py do_minmax) -- so max(0, NaN) == 0.
@@ -221,6 +222,86 @@ __device__ __forceinline__ unsigned rr_row_bytes(int64_t first, int64_t N)
 {
     const int64_t rem = N - first;
     return rem >= RR_BLOCK ? 8u * RR_BLOCK : (rem > 0 ? (unsigned)rem * 8u : 0u);
+}
+
+// ---- the time axis in pieces ------------------------------------------------
+// A million-set sweep is 15,625 waves of equal duration on 1,024 SIMDs: 15.26
+// per SIMD, so 265 SIMDs run a sixteenth wave while the others idle -- the
+// kernel takes 16 wave slots for 15.26 slots of work -- and the dispatcher's
+// wave placement is not even either.  The tiled kernels cut every wave's 30
+// years into PIECES: workgroup b runs piece b / jobs of job b % jobs (the 64
+// sets of a wave), piece-major, and the model states travel from piece to
+// piece through a small HBM scratch [nstate][jobs * 64], handed over with a
+// release / acquire pair at agent scope (the next piece may run on another
+// XCD) and a per-job flag.  Items are a quarter as long, slots refill as
+// they free, and the SIMDs finish within a fraction of a wave of each other
+// (HBV-Edu 1M sets: 27.1 -> 25.3 ms, scores 21.8 -> 19.6; GR4J scores 46.8 ->
+// 44.4).  A piece waits only for a workgroup with a SMALLER index: no
+// deadlock as long as every XCD dispatches its workgroups in increasing
+// order -- the smallest unfinished item then never waits for a slot held by
+// a waiting one.  (The robust form, persistent waves pulling items from an
+// atomic counter -- rr_tile_take --, was built first and measured the same;
+// the loop around the whole kernel body did not survive hipcc's control-flow
+// structurizer reliably: it hung after semantically neutral edits.)
+// Results are bit-identical to the untiled loops: the same operations in the
+// same order.
+struct RrTiles {
+    int *queue;        // [0] the item counter, [1 + job] pieces done
+    double *state;     // hand-over scratch
+    int pieces;        // 0 / 1: untiled
+};
+// next work item of this wave; false when the queue is empty
+__device__ __forceinline__ bool rr_tile_take(const RrTiles &q, int njobs,
+                                             int &job, int &piece)
+{
+    int item = 0;
+    if ((threadIdx.x & (RR_BLOCK - 1)) == 0) item = atomicAdd(q.queue, 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= q.pieces * njobs) return false;
+    piece = item / njobs;
+    job = item - piece * njobs;
+    return true;
+}
+// days [b, e) of piece `piece` of the days [t0, t1); piece lengths are
+// multiples of `even` (2 for the loops that run two days per trip)
+__device__ __forceinline__ void rr_tile_range(int t0, int t1, int pieces,
+                                              int piece, int even, int &b,
+                                              int &e)
+{
+    int len = (t1 - t0 + pieces - 1) / pieces;
+    len = (len + even - 1) / even * even;
+    b = t0 + piece * len;
+    if (b > t1) b = t1;
+    e = (b + len < t1) ? b + len : t1;
+}
+// wait until piece - 1 of this job has published its states
+__device__ __forceinline__ void rr_tile_wait(const RrTiles &q, int job,
+                                             int piece)
+{
+    int *flag = q.queue + 1 + job;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT) < piece)
+        __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// after the states of `piece` have been stored
+__device__ __forceinline__ void rr_tile_publish(const RrTiles &q, int job,
+                                                int piece)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if ((threadIdx.x & (RR_BLOCK - 1)) == 0)
+        __hip_atomic_store(q.queue + 1 + job, piece + 1, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+static inline size_t rr_tile_queue_bytes(int64_t N)
+{
+    return rr_align256_((size_t)((N > 0 ? N : 1) / RR_BLOCK + 2) * sizeof(int));
+}
+static inline size_t rr_tile_bytes(int64_t N, int nstate)
+{
+    const size_t jobs = (size_t)((N > 0 ? N : 1) + RR_BLOCK - 1) / RR_BLOCK;
+    return rr_tile_queue_bytes(N) +
+           rr_align256_((size_t)nstate * jobs * RR_BLOCK * sizeof(double));
 }
 
 // ---- error plumbing (host) ------------------------------------------------

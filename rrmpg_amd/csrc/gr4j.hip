@@ -191,7 +191,17 @@ constexpr bool gr4j_has_optimistic()
 #ifndef GR4J_OPT_MINWAVES
 #define GR4J_OPT_MINWAVES (std::is_same<UH, UhRegs<3>>::value ? 4 : 3)
 #endif
-template <class UH, bool Q, bool S, bool E>
+// TILED: the time axis in pieces pulled from a work queue by persistent waves
+// (common.h RrTiles: million-set sweeps); handed over: both stores, the
+// hydrograph slots, the score sum.  Pieces hold an even number of days, so
+// every piece starts in the same state generation.
+template <class UH>
+constexpr int gr4j_tile_states()
+{
+    return 3 + UH::TIER + (2 * UH::TIER + 1);       // s, r, acc + slots
+}
+
+template <class UH, bool Q, bool S, bool E, bool TILED = false>
 __global__ __launch_bounds__(RR_BLOCK, GR4J_OPT_MINWAVES)
 void gr4j_opt_kernel(
     const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
@@ -199,11 +209,26 @@ void gr4j_opt_kernel(
     const int *__restrict__ plan, int force_lds,
     double *__restrict__ qsim, double *__restrict__ s_store,
     double *__restrict__ r_store, int64_t ld,
-    const double *__restrict__ qobs, double *__restrict__ sse)
+    const double *__restrict__ qobs, double *__restrict__ sse, RrTiles tiles)
 {
     int n1cap, n2cap;
     if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
-    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
+    typedef const GrDay __attribute__((address_space(4))) *day_ptr_t;
+    const day_ptr_t dp = (day_ptr_t)days;
+    // (TILED here takes its items in GRID order, workgroup b = piece
+    // b / jobs of job b % jobs, instead of from rr_tile_take's counter: the
+    // persistent loop around this kernel's two-generation day did not
+    // survive hipcc's control-flow structurizer.  Safe as long as every XCD
+    // dispatches its workgroups in increasing order: the smallest unfinished
+    // item then never waits for a slot held by a waiting one.)
+    int job = blockIdx.x, piece = 0;
+    if constexpr (TILED) {
+        piece = (int)blockIdx.x / njobs;
+        job = (int)blockIdx.x - piece * njobs;
+    }
+    {
+    const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 4;
     Gr4jPar P;
@@ -215,17 +240,33 @@ void gr4j_opt_kernel(
     double ra = r_init * P.x3, rb;   // gr4j_model.py:65
     double acc = 0.0;
     const int lane_off = threadIdx.x * 8;
-    const int64_t first = (int64_t)blockIdx.x * RR_BLOCK;
+    const int64_t first = (int64_t)job * RR_BLOCK;
     const unsigned row_bytes = rr_row_bytes(first, N);
-    int64_t row = first;
-    typedef const GrDay __attribute__((address_space(4))) *day_ptr_t;
-    const day_ptr_t dp = (day_ptr_t)days;
+    int k_begin = 0, k_end = (int)T;
+    double *const hand = TILED ? tiles.state + ((int64_t)job * RR_BLOCK +
+                                                threadIdx.x) : nullptr;
+    const int64_t hs = (int64_t)njobs * RR_BLOCK;
+    if constexpr (TILED) {
+        rr_tile_range(0, (int)T, tiles.pieces, piece, 2, k_begin, k_end);
+        if (piece > 0) {
+            rr_tile_wait(tiles, job, piece);
+            sa = hand[0];
+            ra = hand[hs];
+            acc = hand[2 * hs];
+#pragma unroll
+            for (int j = 0; j < UH::TIER; ++j) ua.u1[j] = hand[(3 + j) * hs];
+#pragma unroll
+            for (int j = 0; j < UH::N2MAX; ++j)
+                ua.u2[j] = hand[(3 + UH::TIER + j) * hs];
+        }
+    }
+    int64_t row = first + (int64_t)k_begin * ld;
     GrDay f;
-    f.net = dp[0].net; f.qobs = dp[0].qobs; f.wet = dp[0].wet;
-    f.net_ok = dp[0].net_ok;
+    f.net = dp[k_begin].net; f.qobs = dp[k_begin].qobs;
+    f.wet = dp[k_begin].wet; f.net_ok = dp[k_begin].net_ok;
     auto day = [&](const double s_in, const double r_in,
                    const typename UH::Slots &u_in, double &s_out,
-                   double &r_out, typename UH::Slots &u_out, int64_t k)
+                   double &r_out, typename UH::Slots &u_out, int k)
         __attribute__((always_inline)) {
         const double net = f.net, qobs_k = f.qobs;
         const bool wet = f.wet != 0;
@@ -263,11 +304,25 @@ void gr4j_opt_kernel(
         }
         row += ld;
     };
-    for (int64_t k = 0; k < T; k += 2) {
+    for (int k = k_begin; k < k_end; k += 2) {
         day(sa, ra, ua, sb, rb, ub, k);
-        if (k + 1 < T) day(sb, rb, ub, sa, ra, ua, k + 1);
+        if (k + 1 < k_end) day(sb, rb, ub, sa, ra, ua, k + 1);
     }
-    if (E && active) sse[i] = acc;
+    if (TILED && piece + 1 < tiles.pieces) {
+        // (an even number of days: the states are back in generation a)
+        hand[0] = sa;
+        hand[hs] = ra;
+        hand[2 * hs] = acc;
+#pragma unroll
+        for (int j = 0; j < UH::TIER; ++j) hand[(3 + j) * hs] = ua.u1[j];
+#pragma unroll
+        for (int j = 0; j < UH::N2MAX; ++j)
+            hand[(3 + UH::TIER + j) * hs] = ua.u2[j];
+        rr_tile_publish(tiles, job, piece);
+    } else {
+        if (E && active) sse[i] = acc;
+    }
+    }
 }
 
 // ---- wave-specialised variant: the day's two halves in two waves ------------
@@ -417,12 +472,18 @@ gr4j_pipe_kernel(
     }
 }
 
+// plan + day records (+ one spare record: the kernel requests day k+1's in
+// the middle of day k)
+static size_t gr4j_days_bytes(int64_t T)
+{
+    if (T < 1) T = 1;
+    return 256 + rr_align256((size_t)(T + 1) * sizeof(GrDay));
+}
+// ... + the tiled kernels' work queue and hand-over scratch (common.h RrTiles)
+#define GR4J_TILE_STATES (gr4j_tile_states<UhRegs<5>>())
 extern "C" size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N)
 {
-    (void)N;
-    if (T < 1) T = 1;
-    // (+ one spare record: the kernel requests day k+1's in the middle of day k)
-    return 256 + rr_align256((size_t)(T + 1) * sizeof(GrDay));
+    return gr4j_days_bytes(T) + rr_tile_bytes(N, GR4J_TILE_STATES);
 }
 
 // ceil(x4) as the kernels count it, for sizing (host)
@@ -512,6 +573,11 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
         rr_set_error("rr_gr4j_simulate_dev: workspace too small");
         return RR_E_WORKSPACE;
     }
+    if (T > 2000000000) {
+        rr_set_error("rr_gr4j_simulate_dev: T = %lld exceeds 2e9 timesteps",
+                     (long long)T);
+        return RR_E_SIZE;
+    }
     hipStream_t st = (hipStream_t)stream;
     int *d_plan = (int *)workspace;
     GrDay *days = (GrDay *)((char *)workspace + 256);
@@ -533,6 +599,23 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     // every tier is enqueued; the kernels pick the one the plan selects
     const int variant = (int)rr_option(RR_OPT_GR4J_VARIANT);
     const int64_t waves = rr_ceil_div(N, RR_BLOCK);
+    // time-tiled persistent form of the optimistic kernel (common.h RrTiles)
+    RrTiles tiles = {nullptr, nullptr, 0};
+    {
+        const int64_t opt = rr_option(RR_OPT_TIME_TILES);
+        int pieces = 0;
+        if ((variant == 0 || variant == 4) && T > 16) {
+            if (opt > 1) pieces = (int)opt;
+            else if (opt < 0 && waves > 6 * (int64_t)rr_simd_count()) pieces = 4;
+        }
+        if (pieces > 1) {
+            tiles.queue = (int *)((char *)workspace + gr4j_days_bytes(T));
+            tiles.state = (double *)((char *)tiles.queue +
+                                     rr_tile_queue_bytes(N));
+            tiles.pieces = pieces;
+            RR_HIP(hipMemsetAsync(tiles.queue, 0, rr_tile_queue_bytes(N), st));
+        }
+    }
     rr_dispatch3(q, s, e, [&](auto Q, auto S, auto E) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
@@ -553,10 +636,21 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
                 // size, by 1-2 % at a million sets and 8-15 % at one or two
                 // waves per SIMD)
                 if (variant == 4 || variant == 0) {
+                    if (tiles.pieces > 1) {
+                        auto kern = gr4j_opt_kernel<UH, Q.value, S.value,
+                                                    E.value, true>;
+                        kern<<<dim3((unsigned)(tiles.pieces * waves)), block,
+                               0, st>>>(
+                            days, T, s_init, r_init, params, N, d_plan,
+                            force_lds, qsim, s_store, r_store, ld, qobs, sse,
+                            tiles);
+                        return;
+                    }
                     gr4j_opt_kernel<UH, Q.value, S.value, E.value>
                         <<<grid, block, 0, st>>>(
                             days, T, s_init, r_init, params, N, d_plan,
-                            force_lds, qsim, s_store, r_store, ld, qobs, sse);
+                            force_lds, qsim, s_store, r_store, ld, qobs, sse,
+                            tiles);
                     return;
                 }
             }

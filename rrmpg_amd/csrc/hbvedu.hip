@@ -102,7 +102,9 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 // alone -- what hbv_launch picks for sweeps of exactly two waves per SIMD,
 // where the second copy's register pressure costs more than it saves.
 //
-// TILED: the time axis in PIECES, the waves persistent.  A million-set sweep
+// TILED: the time axis in PIECES (common.h "the time axis in pieces"), here
+// in the PERSISTENT form -- measured faster than grid-order items in the
+// qsim mode (25.3 vs 27.0 ms; scores 19.6 vs 19.9) --: the waves persistent.  A million-set sweep
 // is 15,625 waves of equal duration on 1,024 SIMDs: 15.26 per SIMD, so 265
 // SIMDs run a sixteenth wave while the others idle -- the kernel takes 16
 // wave slots for 15.26 slots of work (4.6 %).  Here exactly as many waves
@@ -144,8 +146,8 @@ hbvedu_kernel(
         if (threadIdx.x == 0) item = atomicAdd(queue, 1);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= pieces * njobs) break;
-        piece = item / njobs;
-        job = item - piece * njobs;
+        piece = __builtin_amdgcn_readfirstlane(item / njobs);
+        job = __builtin_amdgcn_readfirstlane(item - piece * njobs);
     }
     const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
@@ -542,11 +544,11 @@ static int hbv_launch(const double *temp, const double *prec,
     // time-tiled persistent form (hbvedu_kernel's TILED): for sweeps of many
     // rounds of waves, where equal-length waves quantise the kernel time to
     // whole wave slots (1M sets: 16 slots for 15.26 slots of work).
-    // RR_OPT_HBV_TILES: -1 by sweep size (4 pieces from ten waves per SIMD
+    // RR_OPT_TIME_TILES: -1 by sweep size (4 pieces from ten waves per SIMD
     // on), 0 never, k > 1 pieces.
     int pieces = 0;
     {
-        const int64_t opt = rr_option(RR_OPT_HBV_TILES);
+        const int64_t opt = rr_option(RR_OPT_TIME_TILES);
         if (C == 1 && variant == 0 && !two_per_simd && T > 16) {
             if (opt > 1) pieces = (int)opt;
             else if (opt < 0 && waves > 10 * simds) pieces = 4;

@@ -581,7 +581,7 @@ def test_kernel_variants_agree_bit_for_bit(models):
     with _lib.debug_option("hbv_variant", 0):
         ref_out, ref_sse = hmod._run(forcing, inits, rec, True, True, qobs)
         for tiles in (2, 3, 4, 7, 64):
-            with _lib.debug_option("hbv_tiles", tiles):
+            with _lib.debug_option("time_tiles", tiles):
                 out, sse = hmod._run(forcing, inits, rec, True, True, qobs)
                 only, sse2 = hmod._run(forcing, inits, rec, False, False, qobs)
             for a, b in zip(out, ref_out):
@@ -628,3 +628,12 @@ def test_kernel_variants_agree_bit_for_bit(models):
                 base = list(out) + [sse]
             for a, b in zip(list(out) + [sse], base):
                 assert np.array_equal(a, b), "GR4J variant %d" % v
+        # the time-tiled persistent form of the optimistic kernel
+        for tiles in (2, 3, 4, 9):
+            with _lib.debug_option("time_tiles", tiles):
+                out, sse = gmod._run(h["layer_prec"][:t, 0], h["etp"][:t], 0.4,
+                                     0.5, rec, True, True, qobs)
+                _, sse2 = gmod._run(h["layer_prec"][:t, 0], h["etp"][:t], 0.4,
+                                    0.5, rec, False, False, qobs)
+            for a, b in zip(list(out) + [sse, sse2], base + [base[-1]]):
+                assert np.array_equal(a, b), "GR4J tiles %d" % tiles
