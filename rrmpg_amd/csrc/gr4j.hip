@@ -201,7 +201,9 @@ constexpr int gr4j_tile_states()
     return 3 + UH::TIER + (2 * UH::TIER + 1);       // s, r, acc + slots
 }
 
-template <class UH, bool Q, bool S, bool E, bool TILED = false>
+// TILED: 0 no, 1 items in grid order, 2 persistent waves pulling items from the
+// queue's counter (the job / piece of an item kept explicitly scalar).
+template <class UH, bool Q, bool S, bool E, int TILED = 0>
 __global__ __launch_bounds__(RR_BLOCK, GR4J_OPT_MINWAVES)
 void gr4j_opt_kernel(
     const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
@@ -222,10 +224,18 @@ void gr4j_opt_kernel(
     // survive hipcc's control-flow structurizer.  Safe as long as every XCD
     // dispatches its workgroups in increasing order: the smallest unfinished
     // item then never waits for a slot held by a waiting one.)
+  for (;;) {
     int job = blockIdx.x, piece = 0;
-    if constexpr (TILED) {
+    if constexpr (TILED == 1) {
         piece = (int)blockIdx.x / njobs;
         job = (int)blockIdx.x - piece * njobs;
+    } else if constexpr (TILED == 2) {
+        int item = 0;
+        if (threadIdx.x == 0) item = atomicAdd(tiles.queue, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= tiles.pieces * njobs) break;
+        piece = __builtin_amdgcn_readfirstlane(item / njobs);
+        job = __builtin_amdgcn_readfirstlane(item - piece * njobs);
     }
     {
     const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
@@ -243,10 +253,10 @@ void gr4j_opt_kernel(
     const int64_t first = (int64_t)job * RR_BLOCK;
     const unsigned row_bytes = rr_row_bytes(first, N);
     int k_begin = 0, k_end = (int)T;
-    double *const hand = TILED ? tiles.state + ((int64_t)job * RR_BLOCK +
+    double *const hand = TILED != 0 ? tiles.state + ((int64_t)job * RR_BLOCK +
                                                 threadIdx.x) : nullptr;
     const int64_t hs = (int64_t)njobs * RR_BLOCK;
-    if constexpr (TILED) {
+    if constexpr (TILED != 0) {
         rr_tile_range(0, (int)T, tiles.pieces, piece, 2, k_begin, k_end);
         if (piece > 0) {
             rr_tile_wait(tiles, job, piece);
@@ -308,7 +318,7 @@ void gr4j_opt_kernel(
         day(sa, ra, ua, sb, rb, ub, k);
         if (k + 1 < k_end) day(sb, rb, ub, sa, ra, ua, k + 1);
     }
-    if (TILED && piece + 1 < tiles.pieces) {
+    if (TILED != 0 && piece + 1 < tiles.pieces) {
         // (an even number of days: the states are back in generation a)
         hand[0] = sa;
         hand[hs] = ra;
@@ -323,6 +333,8 @@ void gr4j_opt_kernel(
         if (E && active) sse[i] = acc;
     }
     }
+    if constexpr (TILED != 2) break;
+  }
 }
 
 // ---- wave-specialised variant: the day's two halves in two waves ------------
@@ -481,6 +493,9 @@ static size_t gr4j_days_bytes(int64_t T)
 }
 // ... + the tiled kernels' work queue and hand-over scratch (common.h RrTiles)
 #define GR4J_TILE_STATES (gr4j_tile_states<UhRegs<5>>())
+#ifndef GR4J_TILE_MODE
+#define GR4J_TILE_MODE 1   // 1 grid-order items, 2 persistent waves
+#endif
 extern "C" size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N)
 {
     return gr4j_days_bytes(T) + rr_tile_bytes(N, GR4J_TILE_STATES);
@@ -636,9 +651,29 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
                 // size, by 1-2 % at a million sets and 8-15 % at one or two
                 // waves per SIMD)
                 if (variant == 4 || variant == 0) {
+                    if (tiles.pieces > 1 && GR4J_TILE_MODE == 2) {
+                        auto kern = gr4j_opt_kernel<UH, Q.value, S.value,
+                                                    E.value, 2>;
+                        int per_cu = 0;
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                                &per_cu, kern, RR_BLOCK, 0) != hipSuccess ||
+                            per_cu < 1) {
+                            (void)hipGetLastError();
+                            per_cu = 12;
+                        }
+                        int64_t resident =
+                            (int64_t)per_cu * (rr_simd_count() / 4);
+                        if (resident > tiles.pieces * waves)
+                            resident = tiles.pieces * waves;
+                        kern<<<dim3((unsigned)resident), block, 0, st>>>(
+                            days, T, s_init, r_init, params, N, d_plan,
+                            force_lds, qsim, s_store, r_store, ld, qobs, sse,
+                            tiles);
+                        return;
+                    }
                     if (tiles.pieces > 1) {
                         auto kern = gr4j_opt_kernel<UH, Q.value, S.value,
-                                                    E.value, true>;
+                                                    E.value, 1>;
                         kern<<<dim3((unsigned)(tiles.pieces * waves)), block,
                                0, st>>>(
                             days, T, s_init, r_init, params, N, d_plan,

@@ -16,6 +16,17 @@ def pytest_configure(config):
         "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Every GPU test gets a time limit (pytest-timeout, where installed): the
+    tiled kernels wait on flags in HBM, and a test that ever hung there should
+    fail, not sit on the GPU box."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if "gpu" in item.keywords and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(600))
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
