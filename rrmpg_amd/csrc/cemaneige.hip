@@ -111,16 +111,25 @@ __global__ void cema_gt_table(double *__restrict__ gtresh, int L, int nreg)
     gtresh[4 * L] = all_ok ? 1.0 : 0.0;
 }
 
-template <int L>
+// TILED: the time axis in pieces, items in grid order (common.h RrTiles:
+// million-set sweeps); handed over: both snow states of every layer and the
+// score sum.
+template <int L, bool TILED = false>
 __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const double *__restrict__ days, const double *__restrict__ gtresh,
     int64_t T, double snow_pack_init, double thermal_state_init,
     const double *__restrict__ params, int64_t N,
     double *__restrict__ outflow, double *__restrict__ G_out,
     double *__restrict__ eTG_out, int64_t ld,
-    const double *__restrict__ qobs, double *__restrict__ sse)
+    const double *__restrict__ qobs, double *__restrict__ sse, RrTiles tiles)
 {
-    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
+    int job = blockIdx.x, piece = 0;
+    if constexpr (TILED) {
+        piece = (int)blockIdx.x / njobs;
+        job = (int)blockIdx.x - piece * njobs;
+    }
+    const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 2;
     const double CTG = p[0], Kf = p[1];
@@ -134,8 +143,24 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const bool wq = outflow != nullptr, ws = G_out != nullptr,
                we = sse != nullptr;
     const int lane_off = threadIdx.x * 8;
-    const int64_t first = (int64_t)blockIdx.x * RR_BLOCK;
+    const int64_t first = (int64_t)job * RR_BLOCK;
     const unsigned row_bytes = rr_row_bytes(first, N);
+    int t_begin = 0, t_end = (int)T;
+    double *const hand = TILED ? tiles.state + ((int64_t)job * RR_BLOCK +
+                                                threadIdx.x) : nullptr;
+    const int64_t hs = (int64_t)njobs * RR_BLOCK;
+    if constexpr (TILED) {
+        rr_tile_range(0, (int)T, tiles.pieces, piece, 1, t_begin, t_end);
+        if (piece > 0) {
+            rr_tile_wait(tiles, job, piece);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                G[l] = hand[(2 * l) * hs];
+                eTG[l] = hand[(2 * l + 1) * hs];
+            }
+            acc = hand[(2 * L) * hs];
+        }
+    }
     // one day; `is_first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
     auto one_day = [&](auto is_first, auto sane, int64_t t) {
@@ -177,17 +202,29 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     };
     // the time loop exists twice: for waves that may use the SANE form of
     // the snow routine (any sane run) and for the rest
+    // (a piece that starts at day 0 peels it; the others start mid-run)
+    const bool from_start = t_begin == 0 && t_begin < t_end;
     if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
                           thermal_state_init)) {
-        one_day(std::true_type{}, std::true_type{}, 0);
-        for (int64_t t = 1; t < T; ++t)
+        if (from_start) one_day(std::true_type{}, std::true_type{}, 0);
+        for (int64_t t = t_begin + (from_start ? 1 : 0); t < t_end; ++t)
             one_day(std::false_type{}, std::true_type{}, t);
     } else {
-        one_day(std::true_type{}, std::false_type{}, 0);
-        for (int64_t t = 1; t < T; ++t)
+        if (from_start) one_day(std::true_type{}, std::false_type{}, 0);
+        for (int64_t t = t_begin + (from_start ? 1 : 0); t < t_end; ++t)
             one_day(std::false_type{}, std::false_type{}, t);
     }
-    if (we && active) sse[i] = acc;
+    if (TILED && piece + 1 < tiles.pieces) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            hand[(2 * l) * hs] = G[l];
+            hand[(2 * l + 1) * hs] = eTG[l];
+        }
+        hand[(2 * L) * hs] = acc;
+        rr_tile_publish(tiles, job, piece);
+    } else {
+        if (we && active) sse[i] = acc;
+    }
 }
 
 // Small configurations (<= 5 layers, unit hydrographs in 3+7 registers or in
@@ -783,10 +820,35 @@ extern "C" int rr_cemaneige_simulate_dev(
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
+    // time tiles (common.h RrTiles) for sweeps of many rounds of waves
+    RrTiles tiles = {nullptr, nullptr, 0};
+    {
+        const int64_t opt = rr_option(RR_OPT_TIME_TILES);
+        int pieces = 0;
+        if (T > 16 && T < 2000000000) {
+            if (opt > 1) pieces = (int)opt;
+            else if (opt < 0 && (int64_t)grid.x > 6 * (int64_t)rr_simd_count())
+                pieces = 4;
+        }
+        if (pieces > 1) {
+            tiles.queue = (int *)((char *)workspace +
+                                  cema_tile_offset(T, L, false));
+            tiles.state = (double *)((char *)tiles.queue +
+                                     rr_tile_queue_bytes(N));
+            tiles.pieces = pieces;
+            RR_HIP(hipMemsetAsync(tiles.queue, 0, rr_tile_queue_bytes(N), st));
+        }
+    }
     dispatch_layers((int)L, [&](auto LL) {
-        cemaneige_kernel<LL.value><<<grid, block, 0, st>>>(
-            days, gt, T, snow_pack_init, thermal_state_init, params, N,
-            outflow, G, eTG, ld, qo, sse);
+        if (tiles.pieces > 1)
+            cemaneige_kernel<LL.value, true>
+                <<<dim3((unsigned)((int64_t)tiles.pieces * grid.x)), block, 0,
+                   st>>>(days, gt, T, snow_pack_init, thermal_state_init,
+                         params, N, outflow, G, eTG, ld, qo, sse, tiles);
+        else
+            cemaneige_kernel<LL.value><<<grid, block, 0, st>>>(
+                days, gt, T, snow_pack_init, thermal_state_init, params, N,
+                outflow, G, eTG, ld, qo, sse, tiles);
     });
     RR_HIP(hipGetLastError());
     return RR_OK;

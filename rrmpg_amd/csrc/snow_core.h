@@ -64,12 +64,22 @@ static inline size_t cema_gt_bytes(int64_t L)
 
 // + the [nstate][L][N] snow-state scratch when the layers do not fit in
 // registers (nstate = 2: G, eTG; 4 with the hysteresis' sca and SWE maximum)
+// ... or, for the register kernels, the tiled kernels' work queue and
+// hand-over scratch (common.h RrTiles): both snow states per layer, both
+// GR4J stores, up to 5 + 11 hydrograph slots, the score sum
+static inline int cema_tile_states(int64_t L) { return (int)(2 * L + 20); }
+static inline size_t cema_tile_offset(int64_t T, int64_t L, bool with_etp)
+{
+    return 512 + cema_gt_bytes(L) + cema_days_bytes(T, L, with_etp);
+}
 static inline size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp,
                                    int64_t N, int nstate = 2)
 {
-    size_t b = 512 + cema_gt_bytes(L) + cema_days_bytes(T, L, with_etp);
+    size_t b = cema_tile_offset(T, L, with_etp);
     if (L > RR_CEMANEIGE_MAX_LAYERS && N > 0)
         b += rr_align256((size_t)nstate * (size_t)L * (size_t)N * 8);
+    else if (N > 0)
+        b += rr_tile_bytes(N, cema_tile_states(L));
     return b;
 }
 

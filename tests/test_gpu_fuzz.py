@@ -610,6 +610,22 @@ def test_kernel_variants_agree_bit_for_bit(models):
             base = out
         for a, b in zip(out, base):
             assert np.array_equal(a, b), "fused variant %d" % v
+    # Cemaneige: the time-tiled form (million-set sweeps) against the plain loop
+    cm = models.Cemaneige()
+    crec = _records(models.Cemaneige, rng.uniform([0, 0], [1, 10], (n, 2)))
+    ckw = dict(prec=h["prec"][:t] if "prec" in h else h["layer_prec"][:t, 0],
+               mean_temp=h["layer_mean"][:t, 0] + 2,
+               min_temp=h["layer_mean"][:t, 0] - 3,
+               max_temp=h["layer_mean"][:t, 0] + 6, met_station_height=500,
+               altitudes=[550, 620, 700, 785, 920], snow_pack_init=2.0,
+               thermal_state_init=-0.3, return_storages=True, params=crec)
+    with _lib.debug_option("time_tiles", 0):
+        cbase = cm.simulate(**ckw)
+    for tiles in (2, 3, 5):
+        with _lib.debug_option("time_tiles", tiles):
+            cout = cm.simulate(**ckw)
+        for a, b in zip(cout, cbase):
+            assert np.array_equal(a, b), "Cemaneige tiles %d" % tiles
     # GR4J: one wave per 64 sets / production and routing in two waves
     from rrmpg_amd.models import gr4j as gmod
     lo = np.array([10, -5, 20, 0.5])
