@@ -263,8 +263,16 @@ struct CoupledOut {
 typedef const CoupledOut __attribute__((address_space(4))) *coupled_out_ptr_t;
 
 typedef const double __attribute__((address_space(4))) *cema_rec_ptr_t;
-template <int L, class UH, bool SMALL = false>
-__global__ __launch_bounds__(RR_BLOCK, (coupled_min_waves<L, UH, SMALL>())) void
+// TILED (register hydrograph tiers 3 and 5 only): the time axis in pieces,
+// items in grid order (common.h RrTiles: million-set sweeps); handed over:
+// the snow states, both stores, the hydrograph slots, the score sum.
+#ifndef COUPLED_TILED_MINWAVES
+#define COUPLED_TILED_MINWAVES 3
+#endif
+template <int L, class UH, bool SMALL = false, bool TILED = false>
+__global__ __launch_bounds__(
+    RR_BLOCK, (TILED ? COUPLED_TILED_MINWAVES
+                     : coupled_min_waves<L, UH, SMALL>())) void
 cemaneigegr4j_kernel(
     CoupledOut /* read through the kernarg segment, see above */,
     const double *__restrict__ days, const double *__restrict__ gtresh,
@@ -272,12 +280,18 @@ cemaneigegr4j_kernel(
     double s_init, double r_init, const double *__restrict__ params,
     int64_t N, const int *__restrict__ plan, int force_lds, int wq, int ws,
     const double *__restrict__ qobs, double *__restrict__ sse,
-    double *__restrict__ uh_mem)
+    double *__restrict__ uh_mem, RrTiles tiles)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
     if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
-    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    int job = blockIdx.x, piece = 0;
+    const int njobs = TILED ? (int)((N + RR_BLOCK - 1) / RR_BLOCK) : 0;
+    if constexpr (TILED) {
+        piece = (int)blockIdx.x / njobs;
+        job = (int)blockIdx.x - piece * njobs;
+    }
+    const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 6;
     const double CTG = p[0], Kf = p[1];
@@ -309,9 +323,36 @@ cemaneigegr4j_kernel(
     if constexpr (SMALL) cema_gt_to_regs<L>(gt_tab, gt_regs);
     constexpr int CONSTS = SMALL ? GR4J_CONSTS_VGPR : GR4J_CONSTS_JIT;
     const cema_rec_ptr_t drec = (cema_rec_ptr_t)days;
+    int64_t t_begin = 0, t_end = T;
+    double *const hand = TILED ? tiles.state + ((int64_t)job * RR_BLOCK +
+                                                threadIdx.x) : nullptr;
+    const int64_t hs = (int64_t)njobs * RR_BLOCK;
+    if constexpr (TILED) {
+        int b, e;
+        rr_tile_range(0, (int)T, tiles.pieces, piece, 1, b, e);
+        t_begin = b;
+        t_end = e;
+        if (piece > 0) {
+            rr_tile_wait(tiles, job, piece);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                G[l] = hand[(2 * l) * hs];
+                eTG[l] = hand[(2 * l + 1) * hs];
+            }
+            s = hand[(2 * L) * hs];
+            r = hand[(2 * L + 1) * hs];
+            acc = hand[(2 * L + 2) * hs];
+#pragma unroll
+            for (int j = 0; j < UH::TIER; ++j)
+                uh.z.u1[j] = hand[(2 * L + 3 + j) * hs];
+#pragma unroll
+            for (int j = 0; j < UH::N2MAX; ++j)
+                uh.z.u2[j] = hand[(2 * L + 3 + UH::TIER + j) * hs];
+        }
+    }
     double day[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) day[k] = drec[k];
+    for (int k = 0; k < D; ++k) day[k] = drec[t_begin * D + k];
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
     auto one_day = [&](auto first, auto sane, int64_t t) {
@@ -359,17 +400,52 @@ cemaneigegr4j_kernel(
         }
     };
     // (two copies of the time loop, see cemaneige_kernel)
-    if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
-                          thermal_state_init)) {
-        one_day(std::true_type{}, std::true_type{}, 0);
-        for (int64_t t = 1; t < T; ++t)
-            one_day(std::false_type{}, std::true_type{}, t);
+    if constexpr (!TILED) {
+        if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
+                              thermal_state_init)) {
+            one_day(std::true_type{}, std::true_type{}, 0);
+            for (int64_t t = 1; t < T; ++t)
+                one_day(std::false_type{}, std::true_type{}, t);
+        } else {
+            one_day(std::true_type{}, std::false_type{}, 0);
+            for (int64_t t = 1; t < T; ++t)
+                one_day(std::false_type{}, std::false_type{}, t);
+        }
+        if (we && active) sse[i] = acc;
     } else {
-        one_day(std::true_type{}, std::false_type{}, 0);
-        for (int64_t t = 1; t < T; ++t)
-            one_day(std::false_type{}, std::false_type{}, t);
+        // (a piece that starts at day 0 peels it; the others start mid-run)
+        const bool from_start = t_begin == 0 && t_begin < t_end;
+        const int64_t t1 = t_begin + (from_start ? 1 : 0);
+        if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
+                              thermal_state_init)) {
+            if (from_start) one_day(std::true_type{}, std::true_type{}, 0);
+            for (int64_t t = t1; t < t_end; ++t)
+                one_day(std::false_type{}, std::true_type{}, t);
+        } else {
+            if (from_start) one_day(std::true_type{}, std::false_type{}, 0);
+            for (int64_t t = t1; t < t_end; ++t)
+                one_day(std::false_type{}, std::false_type{}, t);
+        }
+        if (piece + 1 < tiles.pieces) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                hand[(2 * l) * hs] = G[l];
+                hand[(2 * l + 1) * hs] = eTG[l];
+            }
+            hand[(2 * L) * hs] = s;
+            hand[(2 * L + 1) * hs] = r;
+            hand[(2 * L + 2) * hs] = acc;
+#pragma unroll
+            for (int j = 0; j < UH::TIER; ++j)
+                hand[(2 * L + 3 + j) * hs] = uh.z.u1[j];
+#pragma unroll
+            for (int j = 0; j < UH::N2MAX; ++j)
+                hand[(2 * L + 3 + UH::TIER + j) * hs] = uh.z.u2[j];
+            rr_tile_publish(tiles, job, piece);
+        } else {
+            if (we && active) sse[i] = acc;
+        }
     }
-    if (we && active) sse[i] = acc;
 }
 
 // ---- optimistic variant of the fused kernel -----------------------------------
@@ -927,6 +1003,26 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
     const bool small = (int64_t)grid.x <= 2 * (int64_t)rr_simd_count() &&
                        rr_option(RR_OPT_FUSED_VARIANT) != 1;
     const int fv = (int)rr_option(RR_OPT_FUSED_VARIANT);
+    // time tiles (common.h RrTiles) for the many-waves kernel
+    RrTiles tiles = {nullptr, nullptr, 0};
+    {
+        const int64_t opt = rr_option(RR_OPT_TIME_TILES);
+        int pieces = 0;
+        // (only on request: measured SLOWER here, 1M sets 89.8 -> 99.9 ms --
+        // the tiled instantiation needs 168 VGPRs, three waves per SIMD, and
+        // 434 lane moves where the plain one has 125 / 270; held to four
+        // waves it spills to scratch, 136 ms)
+        if (T > 16 && !small && (fv == 0 || fv == 1) && opt > 1)
+            pieces = (int)opt;
+        if (pieces > 1) {
+            tiles.queue = (int *)((char *)workspace +
+                                  cema_tile_offset(T, L, true));
+            tiles.state = (double *)((char *)tiles.queue +
+                                     rr_tile_queue_bytes(N));
+            tiles.pieces = pieces;
+            RR_HIP(hipMemsetAsync(tiles.queue, 0, rr_tile_queue_bytes(N), st));
+        }
+    }
     dispatch_layers((int)L, [&](auto LL) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
@@ -967,7 +1063,20 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                             out, days, gt, T, snow_pack_init,
                             thermal_state_init, s_init, r_init, params, N,
                             d_plan, force_lds, qsim != nullptr, G != nullptr,
-                            qo, sse, uh_mem);
+                            qo, sse, uh_mem, RrTiles{nullptr, nullptr, 0});
+                    return;
+                }
+            }
+            if constexpr (std::is_same<UH, UhRegs<3>>::value ||
+                          std::is_same<UH, UhRegs<5>>::value) {
+                if (tiles.pieces > 1) {
+                    cemaneigegr4j_kernel<LL.value, UH, false, true>
+                        <<<dim3((unsigned)((int64_t)tiles.pieces * grid.x)),
+                           block, 0, st>>>(
+                            out, days, gt, T, snow_pack_init,
+                            thermal_state_init, s_init, r_init, params, N,
+                            d_plan, force_lds, qsim != nullptr, G != nullptr,
+                            qo, sse, uh_mem, tiles);
                     return;
                 }
             }
@@ -975,7 +1084,8 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                 <<<grid, block, lds, st>>>(
                     out, days, gt, T, snow_pack_init, thermal_state_init,
                     s_init, r_init, params, N, d_plan, force_lds,
-                    qsim != nullptr, G != nullptr, qo, sse, uh_mem);
+                    qsim != nullptr, G != nullptr, qo, sse, uh_mem,
+                    RrTiles{nullptr, nullptr, 0});
         });
     });
     RR_HIP(hipGetLastError());

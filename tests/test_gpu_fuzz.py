@@ -610,6 +610,18 @@ def test_kernel_variants_agree_bit_for_bit(models):
             base = out
         for a, b in zip(out, base):
             assert np.array_equal(a, b), "fused variant %d" % v
+    # ... and the many-waves kernel in time tiles (million-set sweeps)
+    fq = rng.uniform(0, 3, t)
+    with _lib.debug_option("fused_variant", 1):
+        _, fsse = fmod._run(layers, (3.0, -0.2, 0.4, 0.5), rec, False, False,
+                            fq)
+        for tiles in (2, 3, 5):
+            with _lib.debug_option("time_tiles", tiles):
+                out, sse_t = fmod._run(layers, (3.0, -0.2, 0.4, 0.5), rec,
+                                       True, True, fq)
+            for a, b in zip(out, base):
+                assert np.array_equal(a, b), "fused tiles %d" % tiles
+            assert np.array_equal(sse_t, fsse)
     # Cemaneige: the time-tiled form (million-set sweeps) against the plain loop
     cm = models.Cemaneige()
     crec = _records(models.Cemaneige, rng.uniform([0, 0], [1, 10], (n, 2)))
