@@ -239,29 +239,19 @@ __device__ __forceinline__ unsigned rr_row_bytes(int64_t first, int64_t N)
 // 44.4).  A piece waits only for a workgroup with a SMALLER index: no
 // deadlock as long as every XCD dispatches its workgroups in increasing
 // order -- the smallest unfinished item then never waits for a slot held by
-// a waiting one.  (The robust form, persistent waves pulling items from an
-// atomic counter -- rr_tile_take --, was built first and measured the same;
-// the loop around the whole kernel body did not survive hipcc's control-flow
-// structurizer reliably: it hung after semantically neutral edits.)
+// a waiting one.  (The robust form -- persistent waves pulling items from an
+// atomic counter, free of any assumption about the dispatcher -- is what
+// hbvedu.hip runs, where it is also the faster one; for GR4J and Cemaneige
+// the loop around the whole kernel body cost registers and time, and it did
+// not survive hipcc's control-flow structurizer reliably unless job and
+// piece were forced scalar with readfirstlane.)
 // Results are bit-identical to the untiled loops: the same operations in the
 // same order.
 struct RrTiles {
-    int *queue;        // [0] the item counter, [1 + job] pieces done
+    int *queue;        // [1 + job] pieces done ([0]: the persistent form's item counter)
     double *state;     // hand-over scratch
     int pieces;        // 0 / 1: untiled
 };
-// next work item of this wave; false when the queue is empty
-__device__ __forceinline__ bool rr_tile_take(const RrTiles &q, int njobs,
-                                             int &job, int &piece)
-{
-    int item = 0;
-    if ((threadIdx.x & (RR_BLOCK - 1)) == 0) item = atomicAdd(q.queue, 1);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= q.pieces * njobs) return false;
-    piece = item / njobs;
-    job = item - piece * njobs;
-    return true;
-}
 // days [b, e) of piece `piece` of the days [t0, t1); piece lengths are
 // multiples of `even` (2 for the loops that run two days per trip)
 __device__ __forceinline__ void rr_tile_range(int t0, int t1, int pieces,
@@ -279,9 +269,15 @@ __device__ __forceinline__ void rr_tile_wait(const RrTiles &q, int job,
                                              int piece)
 {
     int *flag = q.queue + 1 + job;
+    // (the wait is at most one piece long; the count turns a dispatch order
+    // this scheme does not expect into a failed launch after about a minute
+    // of polling, instead of a hang)
+    int polls = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT) < piece)
+                             __HIP_MEMORY_SCOPE_AGENT) < piece) {
         __builtin_amdgcn_s_sleep(8);
+        if (++polls == (1 << 26)) __builtin_trap();
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // after the states of `piece` have been stored

@@ -219,7 +219,7 @@ void gr4j_opt_kernel(
     typedef const GrDay __attribute__((address_space(4))) *day_ptr_t;
     const day_ptr_t dp = (day_ptr_t)days;
     // (TILED here takes its items in GRID order, workgroup b = piece
-    // b / jobs of job b % jobs, instead of from rr_tile_take's counter: the
+    // b / jobs of job b % jobs, instead of from an atomic item counter: the
     // persistent loop around this kernel's two-generation day did not
     // survive hipcc's control-flow structurizer.  Safe as long as every XCD
     // dispatches its workgroups in increasing order: the smallest unfinished

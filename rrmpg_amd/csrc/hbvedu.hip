@@ -122,7 +122,7 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 #define HBV_TILED_MINWAVES 1
 #endif
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
-          bool TAME = true, bool TILED = false>
+          bool TAME = true, int TILED = 0>
 __global__ __launch_bounds__(RR_BLOCK, (TILED ? HBV_TILED_MINWAVES : 1)) void
 hbvedu_kernel(
     const HbvDay *__restrict__ days, int64_t T, double snow_init,
@@ -132,27 +132,45 @@ hbvedu_kernel(
     double *__restrict__ soil_out, double *__restrict__ s1_out,
     double *__restrict__ s2_out, int64_t ld, const double *__restrict__ qobs,
     double *__restrict__ sse, const int *__restrict__ odd_prec,
-    int *__restrict__ queue, double *__restrict__ tile_state, int pieces)
+    int *__restrict__ queue, double *__restrict__ tile_state, int pieces,
+    int ncatch)
 {
     __shared__ FpPowLogEntry powlog[FP_POWLOG_N];
     for (int j = threadIdx.x; j < FP_POWLOG_N; j += RR_BLOCK)
         powlog[j] = HBV_POWLOG_TABLE[j];
     __syncthreads();
     const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
+    // TILED == 2: several catchments (the jobs of catchment c are the slots
+    // [c * njobs, (c + 1) * njobs) of the queue); every trip starts from the
+    // arguments as they were passed
+    const int nslots = TILED == 2 ? njobs * ncatch : njobs;
+    const HbvDay *const days0 = days;
+    const double *const params0 = params, *const qobs0 = qobs;
+    double *const qsim0 = qsim, *const snow0 = snow_out, *const soil0 = soil_out,
+                 *const s10 = s1_out, *const s20 = s2_out, *const sse0 = sse;
   for (;;) {           // TILED: one work item per trip; otherwise one trip
-    int job = blockIdx.x, piece = 0;
+    int job = blockIdx.x, piece = 0, slot = 0, catchment = blockIdx.y;
     if constexpr (TILED) {
         int item = 0;
         if (threadIdx.x == 0) item = atomicAdd(queue, 1);
         item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= pieces * njobs) break;
-        piece = __builtin_amdgcn_readfirstlane(item / njobs);
-        job = __builtin_amdgcn_readfirstlane(item - piece * njobs);
+        if (item >= pieces * nslots) break;
+        piece = __builtin_amdgcn_readfirstlane(item / nslots);
+        slot = __builtin_amdgcn_readfirstlane(item - piece * nslots);
+        job = slot;
+        catchment = 0;
+        if constexpr (TILED == 2) {
+            catchment = __builtin_amdgcn_readfirstlane(slot / njobs);
+            job = __builtin_amdgcn_readfirstlane(slot - catchment * njobs);
+            days = days0; params = params0; qobs = qobs0; qsim = qsim0;
+            snow_out = snow0; soil_out = soil0; s1_out = s10; s2_out = s20;
+            sse = sse0;
+        }
     }
     const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
-    if constexpr (!TILED) {
-        const int64_t c = blockIdx.y;          // wave-uniform
+    if constexpr (TILED != 1) {
+        const int64_t c = catchment;           // wave-uniform
         days += c * T;
         params += c * N * 11;
         const int64_t out_off = c * T * ld;
@@ -202,9 +220,9 @@ hbvedu_kernel(
     const int Ti = (int)T;
     int t_begin = 1, t_end = Ti;
     // a piece's states in the scratch: [5][njobs * 64], lane-contiguous
-    double *const hand = TILED ? tile_state + ((int64_t)job * RR_BLOCK +
+    double *const hand = TILED ? tile_state + ((int64_t)slot * RR_BLOCK +
                                                threadIdx.x) : nullptr;
-    const int64_t hand_stride = (int64_t)njobs * RR_BLOCK;
+    const int64_t hand_stride = (int64_t)nslots * RR_BLOCK;
     if constexpr (TILED) {
         const int len = (Ti - 1 + pieces - 1) / pieces;
         t_begin = 1 + piece * len;
@@ -215,7 +233,7 @@ hbvedu_kernel(
     if (TILED && piece > 0) {
         // the piece before this one (a smaller item, taken earlier by a
         // resident wave) publishes flag = piece when its states are out
-        int *flag = queue + 1 + job;
+        int *flag = queue + 1 + slot;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT) < piece)
             __builtin_amdgcn_s_sleep(8);
@@ -433,7 +451,7 @@ hbvedu_kernel(
     if constexpr (TAME) {
         // any flag of this catchment's pre-pass blocks set?
         const int nb = (int)((T + 255) / 256);
-        const int *flags = odd_prec + (int64_t)blockIdx.y * nb;
+        const int *flags = odd_prec + (int64_t)catchment * nb;
         lanemask_t odd = 0;
         for (int k = threadIdx.x; k - (int)threadIdx.x < nb; k += RR_BLOCK)
             odd |= RR_LANES(k < nb && flags[k] != 0);
@@ -458,7 +476,7 @@ hbvedu_kernel(
         hand[4 * hand_stride] = acc;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (threadIdx.x == 0)
-            __hip_atomic_store(queue + 1 + job, piece + 1, __ATOMIC_RELAXED,
+            __hip_atomic_store(queue + 1 + slot, piece + 1, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     } else {
         if (WITH_SSE && active) sse[i] = acc;
@@ -478,16 +496,18 @@ static size_t hbv_forcing_bytes(int64_t T, int64_t C)
 }
 // the tiled kernel's work queue {counter, flag per job} and its hand-over
 // scratch [5][jobs * 64]
-static size_t hbv_queue_bytes(int64_t N)
+static size_t hbv_queue_bytes(int64_t N, int64_t C)
 {
-    return rr_align256((size_t)(rr_ceil_div(N > 0 ? N : 1, RR_BLOCK) + 1) *
+    if (C < 1) C = 1;
+    return rr_align256((size_t)(rr_ceil_div(N > 0 ? N : 1, RR_BLOCK) * C + 1) *
                        sizeof(int));
 }
-static size_t hbv_tile_bytes(int64_t N)
+static size_t hbv_tile_bytes(int64_t N, int64_t C)
 {
-    return hbv_queue_bytes(N) +
+    if (C < 1) C = 1;
+    return hbv_queue_bytes(N, C) +
            rr_align256((size_t)5 * (size_t)rr_ceil_div(N > 0 ? N : 1, RR_BLOCK) *
-                       RR_BLOCK * sizeof(double));
+                       (size_t)C * RR_BLOCK * sizeof(double));
 }
 
 extern "C" size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N)
@@ -497,7 +517,7 @@ extern "C" size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N)
     // pre-pass's flags of odd precipitation values (one int per 256 days)
     // behind it
     if (T < 1) T = 1;
-    return hbv_forcing_bytes(T, 1) + hbv_tile_bytes(N);
+    return hbv_forcing_bytes(T, 1) + hbv_tile_bytes(N, 1);
 }
 
 // Shared by the single- and multi-catchment entry points.
@@ -549,7 +569,8 @@ static int hbv_launch(const double *temp, const double *prec,
     int pieces = 0;
     {
         const int64_t opt = rr_option(RR_OPT_TIME_TILES);
-        if (C == 1 && variant == 0 && !two_per_simd && T > 16) {
+        if (variant == 0 && !two_per_simd && T > 16 &&
+            waves * (opt > 1 ? opt : 4) < 0x7fffffff) {
             if (opt > 1) pieces = (int)opt;
             else if (opt < 0 && waves > 10 * simds) pieces = 4;
         }
@@ -557,17 +578,19 @@ static int hbv_launch(const double *temp, const double *prec,
     int *queue = nullptr;
     double *tile_state = nullptr;
     if (pieces > 1) {
-        queue = (int *)((char *)workspace + hbv_forcing_bytes(T, 1));
-        tile_state = (double *)((char *)queue + hbv_queue_bytes(N));
-        RR_HIP(hipMemsetAsync(queue, 0, hbv_queue_bytes(N), st));
+        queue = (int *)((char *)workspace + hbv_forcing_bytes(T, C));
+        tile_state = (double *)((char *)queue + hbv_queue_bytes(N, C));
+        RR_HIP(hipMemsetAsync(queue, 0, hbv_queue_bytes(N, C), st));
     }
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
                  [&](auto Q, auto S, auto E) {
         auto go = [&](auto V, auto tame) {
             if constexpr (V.value == 0 && tame.value) {
                 if (pieces > 1) {
-                    auto kern = hbvedu_kernel<Q.value, S.value, E.value, 0,
-                                              true, true>;
+                    auto kern = C == 1 ? hbvedu_kernel<Q.value, S.value,
+                                                       E.value, 0, true, 1>
+                                       : hbvedu_kernel<Q.value, S.value,
+                                                       E.value, 0, true, 2>;
                     // as many waves as are resident at once, no more
                     int per_cu = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
@@ -582,7 +605,7 @@ static int hbv_launch(const double *temp, const double *prec,
                     kern<<<dim3((unsigned)resident), dim3(RR_BLOCK), 0, st>>>(
                         days, T, snow_init, soil_init, s1_init, s2_init, inits,
                         params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
-                        odd_prec, queue, tile_state, pieces);
+                        odd_prec, queue, tile_state, pieces, (int)C);
                     return;
                 }
             }
@@ -590,7 +613,7 @@ static int hbv_launch(const double *temp, const double *prec,
                 <<<grid, dim3(RR_BLOCK), 0, st>>>(
                     days, T, snow_init, soil_init, s1_init, s2_init, inits,
                     params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
-                    odd_prec, nullptr, nullptr, 0);
+                    odd_prec, nullptr, nullptr, 0, (int)C);
         };
         // (measured, kernel ms with / without the second loop copy: 65k sets
         // 3.14 / 3.22, 125k 3.76 / 3.70, 250k 7.45 / 7.62, 1M 27.4 / 27.8)
@@ -647,11 +670,9 @@ extern "C" int rr_hbvedu_simulate_dev(
 extern "C" size_t rr_hbvedu_catchments_workspace_bytes(int64_t T, int64_t C,
                                                        int64_t N)
 {
-    (void)N;
     if (T < 1) T = 1;
     if (C < 1) C = 1;
-    return rr_align256(((size_t)T * (size_t)C + 1) * sizeof(HbvDay) +
-                       (size_t)C * (size_t)rr_ceil_div(T, 256) * sizeof(int));
+    return hbv_forcing_bytes(T, C) + hbv_tile_bytes(N, C);
 }
 
 extern "C" int rr_hbvedu_simulate_catchments_dev(

@@ -587,6 +587,36 @@ def test_kernel_variants_agree_bit_for_bit(models):
             for a, b in zip(out, ref_out):
                 assert np.array_equal(a, b), "HBV tiles %d" % tiles
             assert np.array_equal(sse, ref_sse) and np.array_equal(sse2, ref_sse)
+    # ... and of the multi-catchment launch (the queue's slots run over
+    # catchments x waves): three catchments with their own forcing and inits
+    import torch
+    from rrmpg_amd import device as dev
+    C = 3
+    ctemp = np.stack([forcing[0] + c for c in range(C)])
+    cprec = np.stack([forcing[1] * (1 + 0.3 * c) for c in range(C)])
+    cmonth = np.stack([g["month"][:t]] * C)
+    cinits = np.array([[0., 100., 3., 10.], [5., 80., 1., 2.], [0., 150., 0., 0.]])
+    cens = dev.HBVEduCatchments(ctemp, cprec, cmonth, np.stack([g["PE_m"]] * C),
+                                np.stack([g["T_m"]] * C), cinits)
+    cpar = torch.from_numpy(np.stack([flat[::-1], flat, flat * 1.01])
+                            .copy()).cuda()
+    cq = torch.from_numpy(np.stack([qobs, qobs * 2, qobs + 1])).cuda()
+    with _lib.debug_option("hbv_variant", 0):
+        with _lib.debug_option("time_tiles", 0):
+            q0 = cens.new_output(n)
+            s0 = cens.run(cpar, q0, qobs=cq).clone()
+        for tiles in (2, 5):
+            with _lib.debug_option("time_tiles", tiles):
+                q1 = cens.new_output(n)
+                st1 = [cens.new_output(n) for _ in range(4)]
+                s1 = cens.run(cpar, q1, storages=st1, qobs=cq).clone()
+                s2 = cens.run(cpar, None, qobs=cq).clone()
+            torch.cuda.synchronize()
+            # (bit patterns: the third catchment's sets produce NaNs)
+            bits = lambda x: x.view(torch.int64)
+            assert torch.equal(bits(q0), bits(q1)), tiles
+            assert torch.equal(bits(s0), bits(s1)), tiles
+            assert torch.equal(bits(s0), bits(s2)), tiles
     # the same sets inside a launch of two waves per SIMD (no TAME copy)
     big = np.tile(flat, (300, 1))[:90_000]
     outb, _ = hmod._run(forcing, inits, _records(models.HBVEdu, big), True,
