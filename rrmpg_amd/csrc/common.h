@@ -193,6 +193,26 @@ __device__ __forceinline__ double div_by_invariant_m(double a, lanemask_t a_ok,
     return q;
 }
 
+// a / d.b in its faithful form (invdiv.h inv_mul_core: a * RN(1 / b), within
+// 1.5 ulp for every numerator): the only thing to vote on is the divisor, a
+// loop invariant -- no compare per day.  Lanes whose divisor is outside
+// [2^-100, 2^100] take the IEEE division.
+#ifndef RR_FAITHFUL_QUOTIENTS
+#define RR_FAITHFUL_QUOTIENTS 1
+#endif
+template <class V = CarefulVotes>
+__device__ __forceinline__ double mul_by_inverse_m(double a,
+                                                   const InvDivisor &d,
+                                                   lanemask_t d_ok,
+                                                   V &&votes = V()) {
+    double q = inv_mul_core(a, d);
+    if (RR_VOTE(votes, d_ok)) {
+        const double exact = a / d.b;
+        q = d.ok ? q : exact;
+    }
+    return q;
+}
+
 // ---- one output row of a wave: 64 adjacent columns ---------------------------
 // Every output is [T][ld] row-major and a wave owns 64 adjacent columns, so a
 // day's store is (wave-uniform row base) + (lane * 8 bytes).  Issued as a raw

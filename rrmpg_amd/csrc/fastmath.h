@@ -228,7 +228,7 @@ FP_FN bool fastpow_ok(double x, double z)
 // (y2hi + y2lo = y / ln 2, computed once per lane outside the time loop), so
 // z = y log2 x needs four FMAs and the exp2 stage of fastpow_core is reused.
 // `tab` points at FP_POWLOG_N entries of 4 doubles (LDS on the device).
-struct FpPowLogEntry { double invc, logc, logctail, pad; };
+struct FpPowLogEntry { double invc, logc, logctail, lnc; };
 
 FP_FN void fastpow_tab_exponent(double y, double *y2hi, double *y2lo)
 {
@@ -293,6 +293,60 @@ FP_FN double fastpow_tab_core(double x, double y2hi, double y2lo,
     // [-1/2, 1/2] (csrc/tools/gen_exp_poly.py; 0.18 x 2^-53, the same as the
     // degree-12 Taylor polynomial this replaces: both are at the rounding of
     // their coefficients)
+    double q = 4.4549605981865186e-10;
+    q = FP_FMA_K(q, q0, 7.072585949269223e-09);
+    q = FP_FMA_K(q, q0, 1.0178062445845774e-07);
+    q = FP_FMA_K(q, q0, 1.321544258792169e-06);
+    q = FP_FMA_K(q, q0, 1.525273382983612e-05);
+    q = FP_FMA_K(q, q0, 0.0001540353044173605);
+    q = FP_FMA_K(q, q0, 0.0013333558146416936);
+    q = FP_FMA_K(q, q0, 0.009618129107606888);
+    q = FP_FMA_K(q, q0, 0.0555041086648216);
+    q = FP_FMA_K(q, q0, 0.24022650695910097);
+    q = FP_FMA_K(q, q0, 0.6931471805599453);
+    q = FP_FMA(q, q0, 1.0);                           // inline constant
+    return FP_LDEXP(q, (int)n);
+}
+
+// The same power in PLAIN double arithmetic -- no double-double anywhere: ln x
+// = k ln2 + ln c + r - r^2/2 + ... + r^7/7 (truncation r^8/8 <= 2^-59), one
+// rounded product with y / ln 2, then the exp2 stage above.  16 instructions
+// fewer (34 instead of 50).  The price: the absolute error of ln x (a few
+// 2^-53 |ln x|) is multiplied by y, so the relative error of the result is
+// at most (4 + 3 |z| + |y| / 4) 2^-53 with z = y log2 x -- a few ulp for the
+// HBV-Edu box of a sane run (Beta 1..6, soil/FC 0.3..1), 70 ulp at its
+// corners, at most 2e-13 at the far corners of the guard box (|z| = 576) --
+// against the 1e-10 the discharge has to meet.  Measured: tests/native/fastmath_harness.cpp ("lite_*");
+// HBV-Edu's deviation from the reference semantics over 30 years: DESIGN.md section 4.
+// Same domain and guard as fastpow_tab_core (fastpow_tab_ok).
+#define FP_LN2 0x1.62e42fefa39efp-1
+template <bool VCONST = false>
+FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,
+                              double *z_out)
+{
+    const int hi = FP_HI32(x);
+    const int tmp = hi - FP_POWLOG_OFF_HI;
+    const int i = (tmp >> 13) & (FP_POWLOG_N - 1);
+    const int k = tmp >> 20;                          // arithmetic shift
+    const double z = FP_FROM_HILO(hi - (tmp & (int)0xFFF00000), FP_LO32(x));
+    const double kd = (double)k;
+    const double invc = tab[i].invc, lnc = tab[i].lnc;
+
+    const double r = FP_FMA(z, invc, -1.0);
+    const double t = FP_FMA(kd, FP_LN2, lnc);
+    // ln(1 + r) = r + r^2 (-1/2 + r/3 - r^2/4 + r^3/5 - r^4/6 + r^5/7)
+    double h = 1.0 / 7.0;
+    h = FP_FMA_K(h, r, -1.0 / 6.0);
+    h = FP_FMA_K(h, r, 0.2);
+    h = FP_FMA_K(h, r, -0.25);
+    h = FP_FMA_K(h, r, 1.0 / 3.0);
+    h = FP_FMA(h, r, -0.5);                           // inline constant
+    const double l = t + FP_FMA(r * r, h, r);
+    const double zz = y2 * l;
+    *z_out = zz;
+
+    const double n = FP_RINT(zz);
+    const double q0 = zz - n;                         // |.| <= 0.5
     double q = 4.4549605981865186e-10;
     q = FP_FMA_K(q, q0, 7.072585949269223e-09);
     q = FP_FMA_K(q, q0, 1.0178062445845774e-07);

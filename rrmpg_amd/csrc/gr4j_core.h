@@ -63,23 +63,31 @@ __device__ __forceinline__ lanemask_t gr4j_num_mask(double a)
 }
 
 // GR4J's own quotients (s/x1, the percolation's and the routing store's
-// arguments, net/x1) use the test without its lower bound: a is +0 or
+// arguments, net/x1) are FAITHFUL: a * RN(1/x), one instruction, within 1.5
+// ulp of a/x for every numerator (invdiv.h inv_mul_core) -- the GR4J family
+// is a few-ulp restatement of the reference's libm calls to begin with
+// (tolerance 1e-10 relative), its measured deviation
+// from the reference semantics did not move (1.7e-13 over 30 years), and the two FMAs and
+// the numerator vote of the correctly rounded form were a tenth of the day's
+// vector work (GR4J 1M sets 53.6 -> 48.1 ms, scores 44.6 -> 40.4, 125k 6.7 ->
+// 6.1; fused 90.2 -> 84.7; -DRR_FAITHFUL_QUOTIENTS=0 builds the old form).
+// The only vote left is on the divisor, a loop invariant.  One numerator
+// test survives, on the production store (gr4j_production: the folded store
+// update must not overflow early), and it is the relaxed one: a is +0 or
 // positive and below 2^196 -- ONE unsigned compare of the high word (sign
-// bit set, NaN, inf and anything >= 2^196 are above the bound).  What the
-// lower bound bought: for 0 < a < 2^-900 the residual of the 3-FMA form can
-// underflow, and the quotient is then only faithful -- within one ulp of a/b
-// instead of correctly rounded (tests/native/invdiv_harness.cpp: 5 % of such
-// numerators, never more than one ulp).  A store or flux of 1e-271 mm is no
-// hydrology, the GR4J family is a few-ulp restatement of the reference's libm
-// calls to begin with (tolerance 1e-10 relative), and
-// the three instructions of the strict test were a twelfth of the day's
-// vector work (GR4J 55.6 -> 54.0 ms, 125k sets 7.8 -> 7.2, fused 100.1 ->
-// 96.3).  The per-lane choice in the slow path uses the same relaxed test,
-// so a set's result never depends on its wave neighbours.
+// bit set, NaN, inf and anything >= 2^196 are above the bound).  The
+// per-lane choice in the slow path uses the same test, so a set's result
+// never depends on its wave neighbours.
 #ifndef RR_GR4J_STRICT_VOTES
 #define RR_GR4J_STRICT_VOTES 0
 #endif
 #define GR4J_NUM_HI_WORD 0x4C300000u        // high word of 2^196
+// Multiply-adds of the day contracted where a product goes straight into a
+// sum (the reference's operations in the reference's order, one rounding
+// instead of two); -DRR_GR4J_CONTRACT=0 builds the separately rounded form.
+#ifndef RR_GR4J_CONTRACT
+#define RR_GR4J_CONTRACT 1
+#endif
 __device__ __forceinline__ bool gr4j_num_ok(double a)
 {
 #if RR_GR4J_STRICT_VOTES
@@ -104,6 +112,10 @@ __device__ __forceinline__ double gr4j_div_m(double a, lanemask_t a_ok,
                                              const InvDivisor &d,
                                              lanemask_t d_ok, V &&votes = V())
 {
+#if RR_FAITHFUL_QUOTIENTS
+    (void)a_ok;
+    return mul_by_inverse_m(a, d, d_ok, votes);
+#else
     double q = inv_div_core(a, d);
     if (RR_VOTE(votes, a_ok & d_ok)) {
         const bool ok = gr4j_num_ok(a) && d.ok;
@@ -111,12 +123,17 @@ __device__ __forceinline__ double gr4j_div_m(double a, lanemask_t a_ok,
         q = ok ? q : exact;
     }
     return q;
+#endif
 }
 template <class V = CarefulVotes>
 __device__ __forceinline__ double gr4j_div(double a, const InvDivisor &d,
                                            lanemask_t d_ok, V &&votes = V())
 {
+#if RR_FAITHFUL_QUOTIENTS
+    return mul_by_inverse_m(a, d, d_ok, votes);
+#else
     return gr4j_div_m(a, gr4j_num_lanes(a), d, d_ok, votes);
+#endif
 }
 
 // _s_curve1 (gr4j_model.py:159-173); t is the integer ordinate index
@@ -572,7 +589,11 @@ __device__ __forceinline__ void gr4j_store_coefficients(bool wet, double s,
                                                         double &c, double &k)
 {
     if (wet) {
+#if RR_GR4J_CONTRACT
+        c = x1 * __builtin_fma(-sx, sx, 1.0);
+#else
         c = x1 * (1 - sx * sx);
+#endif
         k = sx;
     } else {
         c = s * (2 - sx);
@@ -631,9 +652,9 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     double E, D;
     fast_tanh_parts<CONSTS>(
         gr4j_div_m(net, net_m, P.inv_x1, P.x1_m, votes), E, D);
-    // One vote covers the 3-FMA quotient s/x1 and the folded form: with
+    // One vote covers the quotient s/x1 and the folded form: with
     // 0 <= s < 2^196 and |x1| in [2^-100, 2^100] (invdiv.h) the quotient is
-    // RN(s/x1) (gr4j_num_lanes) and |s/x1| <= 2^296, so c*E and k*E (E <= 1.2e17,
+    // within 1.5 ulp of s/x1 and |s/x1| <= 2^296, so c*E and k*E (E <= 1.2e17,
     // |c| <= 2^692) stay finite
     // -- they are D times the reference's own c*th, k*th and would otherwise
     // overflow before those do.  The folded quotient itself is taken with
@@ -642,10 +663,18 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     // away from zero: D + k*E >= 1 whenever 0 <= s <= x1, anything else is
     // voted out.  Any other lane sends the wave through the reference's own
     // sequence (IEEE quotient, two divisions).
+#if RR_FAITHFUL_QUOTIENTS
+    const double sx = inv_mul_core(s, P.inv_x1);
+#else
     const double sx = inv_div_core(s, P.inv_x1);
+#endif
     double c, k;
     gr4j_store_coefficients(wet, s, P.x1, sx, c, k);
+#if RR_GR4J_CONTRACT
+    const double den = __builtin_fma(k, E, D);
+#else
     const double den = D + k * E;
+#endif
     const lanemask_t fast = gr4j_num_lanes(s) & P.x1_m &
                             RR_LANES(fabs(den) >= 0x1p-100);
     double frac = fast_div_core(c * E, den);
@@ -689,7 +718,11 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     // sane run, but the difference between r == 0 and r > 0 for a routing
     // store with a negative x3, whose exchange term is 0 in one case and NaN
     // in the other (found by the fuzz soak).  The subtraction is exact.
+#if RR_GR4J_CONTRACT
+    const double b1 = __builtin_fma(v2, v2, 1.0);
+#else
     const double b1 = 1 + v2 * v2;
+#endif
     double root;
     if constexpr (RR_R4_POLY_ENABLED<UH>) {
         const double u = b1 - 1;
@@ -728,6 +761,21 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
     else
         uh.route(in, out, p_r_uh1, p_r_uh2, head1, head2, votes);
 
+#if RR_GR4J_CONTRACT
+    // (the exchange term x2 * (r/x3)**3.5 goes into the two sums that take
+    // it as a fused multiply-add, and so do the squares under the roots:
+    // one rounding where the reference has two)
+    const double p35 =
+        pow_3_5<by_vote>(gr4j_div(r, P.inv_x3, P.x3_m, votes), votes); // :139
+    double rn = nb_max(0.0, __builtin_fma(P.x2, p35, r + head1)); // :142
+    const double w = gr4j_div(rn, P.inv_x3, P.x3_m, votes);
+    const double w2 = w * w;
+    const double q_r =
+        rn * (1 - gr4j_inv_fourth_root<by_vote>(
+                      __builtin_fma(w2, w2, 1.0), votes));      // :145
+    rn = rn - q_r;                                              // :148
+    const double q_d = nb_max(0.0, __builtin_fma(P.x2, p35, head2)); // :151
+#else
     const double gw_exchange =
         P.x2 * pow_3_5<by_vote>(gr4j_div(r, P.inv_x3, P.x3_m, votes),
                                 votes);                         // :139
@@ -738,6 +786,7 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
         rn * (1 - gr4j_inv_fourth_root<by_vote>(1 + w2 * w2, votes)); // :145
     rn = rn - q_r;                                              // :148
     const double q_d = nb_max(0.0, head2 + gw_exchange);        // :151
+#endif
     r = rn;
     return q_r + q_d;                                           // :154
 }

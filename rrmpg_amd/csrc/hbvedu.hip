@@ -121,6 +121,12 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 #ifndef HBV_TILED_MINWAVES
 #define HBV_TILED_MINWAVES 1
 #endif
+#ifndef RR_HBV_POW_LITE
+#define RR_HBV_POW_LITE 1
+#endif
+#ifndef RR_HBV_CONTRACT
+#define RR_HBV_CONTRACT 1
+#endif
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
           bool TAME = true, int TILED = 0>
 __global__ __launch_bounds__(RR_BLOCK, (TILED ? HBV_TILED_MINWAVES : 1)) void
@@ -308,9 +314,13 @@ hbvedu_kernel(
         // altogether.  Outside that box (NaN/inf/zero/negative operands, huge
         // Beta) both are evaluated and 0 * inf / 0 * NaN propagate exactly as
         // in the reference.
-        // lanes inside the box; there soil is also a valid numerator of the
-        // 3-FMA quotients (|soil| in [2^-509, 2^509]), so the box doubles as
-        // their guard and lanes outside it take the IEEE division
+        // lanes inside the box.  (The two quotients by FC and PWP are
+        // FAITHFUL -- soil * RN(1/FC), within 1.5 ulp for every numerator,
+        // invdiv.h inv_mul_core; their only vote is on the divisor, a loop
+        // invariant.  HBV-Edu 1M sets 25.25 -> 24.70 ms, deviation from the
+        // reference semantics 5e-15 -> 6e-15.  -DRR_FAITHFUL_QUOTIENTS=0 builds the
+        // correctly rounded 3-FMA form, for which the box doubles as the
+        // numerator's guard.)
         const lanemask_t soil_m =
             RR_LANES(soil >= soil_lo) & RR_LANES(soil <= soil_hi) & box_m;
         // lanes that need the power: wet, or outside the box (votes are done
@@ -318,15 +328,28 @@ hbvedu_kernel(
         const lanemask_t need_m = RR_LANES(liquid_water != 0.0) | ~soil_m;
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
         if (need_m & rr_exec()) {
+#if RR_FAITHFUL_QUOTIENTS
+            const double wetness = mul_by_inverse_m(soil, inv_FC, fc_m);
+#else
             const double wetness = div_by_invariant_m(soil, soil_m, inv_FC,
                                                       fc_m);
-            // fastmath.h: ~1 ulp, a third of the general pow's instructions;
-            // arguments outside its domain take the general pow (wave-wide)
+#endif
+            // fastmath.h fastpow_tab_lite: the table-driven power in plain
+            // double arithmetic, a few ulp in a sane run's box (bound: (4 +
+            // 3 |Beta log2 wetness| + |Beta| / 4) 2^-53), a fifth of the
+            // general pow's instructions (-DRR_HBV_POW_LITE=0: the
+            // double-double form, 0.97 ulp, 16 instructions more); arguments
+            // outside its domain take the general pow (wave-wide)
             double z;
             // (small sweeps, FORCING == 2: polynomial constants in VGPRs so
             // that the prefetched record fits the SGPR file without spills)
+#if RR_HBV_POW_LITE
+            double pw = fastpow_tab_lite<FORCING == 2>(wetness, beta2_hi,
+                                                       powlog, &z);
+#else
             double pw = fastpow_tab_core<FORCING == 2>(wetness, beta2_hi,
                                                        beta2_lo, powlog, &z);
+#endif
             // Inside the box the arguments are in fastpow's domain by
             // construction: wetness in [2^-9, 2^9] is a positive normal
             // number and |z| = |Beta log2 wetness| <= 64 * 9 < 1000 -- so
@@ -347,10 +370,45 @@ hbvedu_kernel(
         }
         mid();
 
+#if RR_HBV_CONTRACT
+        // The reservoir updates with their multiply-adds CONTRACTED: the
+        // reference's operations in the reference's order, each product
+        // fused into the sum that takes it (one rounding instead of two --
+        // closer to the exact value, not further), 16 instructions instead
+        // of 23 a day.  -DRR_HBV_CONTRACT=0 builds the separately rounded
+        // form below.
+        // potential / actual evapotranspiration (:102-108); the select picks
+        // the factor, 1 or soil/PWP, so that the product with pe goes into
+        // the soil update's FMA
+        const double pe = __builtin_fma(C, f.dtemp, 1.0) * f.pe_m;
+        const double dry = (soil > PWP)
+            ? 1.0 : mul_by_inverse_m(soil, inv_PWP, pwp_m);
+
+        // soil moisture (:111)
+        const double soil_n = __builtin_fma(-pe, dry, soil_lw - prec_eff);
+
+        // near-surface reservoir (:114-118)
+        const double over = nb_max(0.0, s1 - L) * K_0;
+        const double s1_n = __builtin_fma(
+            -s1, K_p, __builtin_fma(-s1, K_1, s1 + prec_eff - over));
+
+        // base-flow reservoir (:121-123)
+        const double s2_n =
+            __builtin_fma(-s2, K_2, __builtin_fma(s1, K_p, s2));
+
+        // discharge mixes old and new states (:125-127)
+        const double q =
+            __builtin_fma(s2_n, K_2, __builtin_fma(s1_n, K_1, over));
+#else
         // potential / actual evapotranspiration (:102-108)
         const double pe = (1 + C * f.dtemp) * f.pe_m;
+#if RR_FAITHFUL_QUOTIENTS
+        const double ea = (soil > PWP)
+            ? pe : pe * mul_by_inverse_m(soil, inv_PWP, pwp_m);
+#else
         const double ea = (soil > PWP)
             ? pe : pe * div_by_invariant_m(soil, soil_m, inv_PWP, pwp_m);
+#endif
 
         // soil moisture (:111)
         const double soil_n = soil_lw - prec_eff - ea;
@@ -364,6 +422,8 @@ hbvedu_kernel(
 
         // discharge mixes old and new states (:125-127)
         const double q = over + s1_n * K_1 + s2_n * K_2;
+
+#endif
 
         snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
 

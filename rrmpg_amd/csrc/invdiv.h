@@ -37,6 +37,18 @@ ID_FN bool inv_div_numerator_ok0(double a) {
     return inv_div_numerator_ok(a) || (a == 0.0 && !__builtin_signbit(a));
 }
 
+// The FAITHFUL form of the quotient: a * RN(1 / b), one instruction.  For d.ok
+// it serves EVERY numerator -- NaN, infinities and signed zeros come out as
+// the division gives them, nothing can be lost in a residual -- within
+// (1 + 2^-53)^2 of a / b: 1.5 ulp at worst where the IEEE quotient is within
+// 0.5 (tests/native/invdiv_harness.cpp).  What HBV-Edu's and GR4J's own
+// quotients use (their results are few-ulp restatements of the reference's
+// libm calls anyway); the snow routines, whose states
+// are bit-identical to the reference's, keep inv_div_core.
+ID_FN double inv_mul_core(double a, const InvDivisor &d) {
+    return a * d.rb;
+}
+
 // valid (== RN(a / b)) when inv_div_numerator_ok[0](a) && d.ok
 ID_FN double inv_div_core(double a, const InvDivisor &d) {
     const double q0 = a * d.rb;

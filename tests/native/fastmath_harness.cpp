@@ -94,6 +94,35 @@ int main(int argc, char **argv) {
         printf("tab_worst_ulp_wide %.4f at x=%.17g y=%.17g\n", tw[1], tx[1], ty[1]);
         printf("tab_worst_ulp_near1 %.4f at x=%.17g y=%.17g\n", tw[2], tx[2], ty[2]);
         printf("tab_guard_rejected %ld\ntab_exact_ok %d\n", rej, ex);
+
+        // the plain-double variant (fastpow_tab_lite, HBV-Edu's default):
+        // relative error in units of 2^-53, (a) the box of a sane run,
+        // (b) the whole guard box x = 2^U(-9, 9), y = U(-64, 64), where the
+        // bound is (4 + 3 |z| + |y| / 4) 2^-53
+        double lw[2] = {0, 0}, lbound = 0;
+        s = 88172645463325252ULL;
+        for (int set = 0; set < 2; ++set)
+            for (long i = 0; i < n; ++i) {
+                double x, y;
+                if (set == 0) { x = 0.05 + 1.45 * u01(); y = 0.5 + 7.5 * u01(); }
+                else { x = exp2(-9 + 18 * u01()); y = -64 + 128 * u01(); }
+                double y2h, y2l, zl;
+                fastpow_tab_exponent(y, &y2h, &y2l);
+                const double got = fastpow_tab_lite(x, y2h, tab, &zl);
+                if (!fastpow_tab_ok(x, zl)) continue;
+                const long double want = powl((long double)x, (long double)y);
+                const double rel = (double)(fabsl((long double)got - want) /
+                                            want) * 0x1p53;
+                if (rel > lw[set]) lw[set] = rel;
+                const double over = rel / (4 + 3 * fabs(zl) + 0.25 * fabs(y));
+                if (over > lbound) lbound = over;
+            }
+        double zl;
+        int lex = fastpow_tab_lite(1.0, 3.7 * FP_INVLN2HI, tab, &zl) == 1.0 &&
+                  fastpow_tab_lite(2.5, 0.0, tab, &zl) == 1.0;
+        printf("lite_worst_rel53_sane %.2f\nlite_worst_rel53_box %.2f\n"
+               "lite_worst_over_bound_x100 %.0f\nlite_exact_ok %d\n",
+               lw[0], lw[1], lbound * 100, lex);
     }
 
     // tanh: arguments as GR4J produces them (net / x1 in [0, ~1]) and wide

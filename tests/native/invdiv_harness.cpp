@@ -79,5 +79,59 @@ int main(int argc, char **argv) {
     }
     printf("tiny_checked %ld\ntiny_worst_ulps %.0f\ntiny_not_rn %ld\n",
            tiny_checked, tiny_worst, tiny_off);
+
+    // The faithful form a * RN(1/b) (inv_mul_core: HBV-Edu's and GR4J's own
+    // quotients) serves EVERY numerator once the divisor is ok: error in
+    // ulps of the IEEE quotient over the whole exponent range (quotients
+    // that overflow or are subnormal measured on their own grid), and the
+    // special numerators must come out exactly as the division gives them.
+    long f_checked = 0, f_special_bad = 0;
+    double f_worst = 0.0;
+    for (long i = 0; i < n / 2; ++i) {
+        const uint64_t ma = rnd(), mb = rnd();
+        const int ea = (int)(rnd() % 2045) - 1022, eb = (int)(rnd() % 201) - 100;
+        const double a = mk(ma, ea, (int)(rnd() & 1));
+        const double b = mk(mb, eb, (int)(rnd() & 1));
+        const InvDivisor d = make_inv_divisor(b);
+        if (!d.ok) continue;
+        const double q = inv_mul_core(a, d), want = a / b;
+        if (std::isinf(want) || std::isinf(q)) {
+            // at the very top of the range the product may round to inf one
+            // ulp before the quotient does (or after): same magnitude class
+            if (!(fabs(want) >= 0x1.ffffffffffff0p1023 &&
+                  fabs(q) >= 0x1.ffffffffffff0p1023)) f_special_bad++;
+            continue;
+        }
+        f_checked++;
+        int e;
+        frexp(want, &e);
+        const double ulp = (fabs(want) < 0x1p-1022) ? 0x1p-1074
+                                                    : ldexp(1.0, e - 53);
+        const double diff = fabs(q - want) / ulp;
+        if (diff > f_worst) f_worst = diff;
+    }
+    {
+        const double specials[] = {0.0, -0.0, INFINITY, -INFINITY, NAN,
+                                   0x1p-1074, -0x1p-1074, 0x1.fffffffffffffp1023};
+        const double divisors[] = {1.0, -3.0, 0x1p-100, 0x1p100, 350.0, -0.7};
+        for (double b : divisors) {
+            const InvDivisor d = make_inv_divisor(b);
+            for (double a : specials) {
+                const double q = inv_mul_core(a, d), want = a / b;
+                const bool same = (std::isnan(q) && std::isnan(want)) ||
+                                  (memcmp(&q, &want, 8) == 0) ||
+                                  (std::isfinite(want) && want != 0.0 &&
+                                   fabs(q - want) <= 2 * fabs(want) * 0x1p-52) ||
+                                  (fabs(want) < 0x1p-1022 &&
+                                   fabs(q - want) <= 0x1p-1074);
+                if (!same || !d.ok) {
+                    printf("SPECIAL a=%a b=%a got=%a want=%a\n", a, b, q, want);
+                    f_special_bad++;
+                }
+            }
+        }
+    }
+    printf("faithful_checked %ld\nfaithful_worst_ulps_x100 %.0f\n"
+           "faithful_special_bad %ld\n", f_checked, f_worst * 100, f_special_bad);
     return bad != 0;
 }

@@ -38,6 +38,13 @@ def test_fastpow_accuracy(tmp_path):
     assert float(vals["tab_worst_ulp_near1"]) < 1.1, out
     assert int(vals["tab_exact_ok"]) == 1, out
     assert int(vals["tab_guard_rejected"]) == 0, out
+    # the plain-double variant HBV-Edu runs by default: relative error in
+    # units of 2^-53 -- a sane run's box, the whole guard box, and the
+    # stated bound (4 + 3 |y log2 x| + |y| / 4) 2^-53
+    assert float(vals["lite_worst_rel53_sane"]) < 100, out
+    assert float(vals["lite_worst_rel53_box"]) < 4 + 3 * 576, out
+    assert int(vals["lite_worst_over_bound_x100"]) <= 100, out
+    assert int(vals["lite_exact_ok"]) == 1, out
     assert float(vals["worst_ulp_tanh_gr4j"]) < 3.0, out
     assert float(vals["worst_ulp_tanh_wide"]) < 3.0, out
     assert int(vals["tanh_special_ok"]) == 1, out
@@ -62,6 +69,11 @@ def test_invariant_division_is_bit_exact(tmp_path):
     # never more than one ulp from the IEEE quotient
     assert int(vals["tiny_checked"]) > 4_000_000, out
     assert int(vals["tiny_worst_ulps"]) <= 1, out
+    # the faithful form a * RN(1/b) of HBV-Edu's and GR4J's own quotients: any
+    # numerator, within 1.5 ulp; zeros, infinities and NaN as the division
+    assert int(vals["faithful_checked"]) > 9_000_000, out
+    assert int(vals["faithful_worst_ulps_x100"]) <= 150, out
+    assert int(vals["faithful_special_bad"]) == 0, out
 
 
 def test_pow_tables_header_matches_its_generator(tmp_path):
@@ -86,12 +98,14 @@ def test_pow_tables_header_matches_its_generator(tmp_path):
         with open(committed, "w") as fp:
             fp.write(want)
     assert got == want
-    # shape of the table: 128 entries, the two around x = 1 are {1, 0, 0}
-    rows = re.findall(r"\{(\S+), (\S+), (\S+), 0\.0\}", want)
+    # shape of the table: 128 entries, the two around x = 1 are {1, 0, 0, 0}
+    rows = re.findall(r"\{(\S+), (\S+), (\S+), (\S+)\}, ", want)
     assert len(rows) == 128
     for i in (79, 80):
-        assert [float.fromhex(v) for v in rows[i]] == [1.0, 0.0, 0.0]
-    for invc, logc, tail in rows:
-        invc, logc, tail = (float.fromhex(v) for v in (invc, logc, tail))
+        assert [float.fromhex(v) for v in rows[i]] == [1.0, 0.0, 0.0, 0.0]
+    for invc, logc, tail, lnc in rows:
+        invc, logc, tail, lnc = (float.fromhex(v)
+                                 for v in (invc, logc, tail, lnc))
         assert (invc * 2 ** 9) % 1 == 0 or (invc * 2 ** 8) % 1 == 0
+        assert lnc == logc + tail          # the pair's sum, rounded once
         assert (logc * 2 ** 43) % 1 == 0 and abs(tail) < 2 ** -43
