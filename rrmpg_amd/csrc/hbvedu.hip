@@ -24,18 +24,37 @@
 //              dropped by the hardware.
 //   tables   : the logarithm table of the power function, 4 KiB in LDS.
 //
-// Arithmetic follows the reference statement by statement in fp64 without
-// FMA contraction (-ffp-contract=off); only the power (soil/FC)**Beta is not
-// libm's: it is fastmath.h's ~1-ulp table-driven evaluation (general pow as
-// fallback), and the two quotients by per-lane constants use invdiv.h's
-// correctly rounded 3-FMA form (bit-identical to `/`).
+// Arithmetic follows the reference statement by statement in fp64; the snow
+// routine is bit-identical to it.  The soil and reservoir updates are
+// tolerance-driven (the discharge has to be within 1e-10 relative; measured
+// 7e-15 over 30 years): the power (soil/FC)**Beta is fastmath.h's table-driven
+// evaluation in plain double (a few ulp; general pow as fallback), the two
+// quotients by per-lane constants are one multiply by the rounded reciprocal
+// (1.5 ulp), and a product that feeds a sum is contracted into it (the file
+// is built with -ffp-contract=off: only the FMAs written out below).
 #include "common.h"
 #include "fastmath.h"
+
+// Tolerance-driven forms (each has its =0 build):
+// the power in plain double arithmetic, the reservoir updates contracted.
+#ifndef RR_HBV_POW_LITE
+#define RR_HBV_POW_LITE 1
+#endif
+#ifndef RR_HBV_CONTRACT
+#define RR_HBV_CONTRACT 1
+#endif
+// (the tame loop copy also for sweeps of exactly two waves per SIMD: since
+// the copy saves a select, a compare and two branches a day it wins there
+// too -- 125k sets 3.46 -> 3.26 ms, 100k 3.34 -> 3.14)
+#ifndef HBV_TWO_PER_SIMD_TAME
+#define HBV_TWO_PER_SIMD_TAME 1
+#endif
 
 struct __attribute__((aligned(8))) HbvDay {
     double temp;   // temp[t]
     double prec;   // prec[t]
-    double dtemp;  // temp[t] - T_m[month[t]]        (hbvedu_model.py:102)
+    double dtemp;  // temp[t] - T_m[month[t]]        (hbvedu_model.py:102);
+                   // RR_HBV_CONTRACT: times PE_m[month[t]], see day_step
     double pe_m;   // PE_m[month[t]]
     double qobs;   // observed discharge of the day (0 if no score is wanted):
                    // rides along so the score needs no second load + wait
@@ -70,6 +89,9 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
     d.prec = prec[g];
     d.dtemp = temp[g] - T_m[c * 12 + m];
     d.pe_m = PE_m[c * 12 + m];
+#if RR_HBV_CONTRACT
+    d.dtemp *= d.pe_m;
+#endif
     d.qobs = qobs ? qobs[g] : 0.0;
     days[g] = d;
 }
@@ -99,8 +121,7 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 // path is the faster one, it costs no vector-memory or LDS instruction at all.
 // TAME: the kernel carries a second copy of the time loop for waves that
 // qualify for it (see day_step); without it the kernel is the general loop
-// alone -- what hbv_launch picks for sweeps of exactly two waves per SIMD,
-// where the second copy's register pressure costs more than it saves.
+// alone (a measurement variant since HBV_TWO_PER_SIMD_TAME).
 //
 // TILED: the time axis in PIECES (common.h "the time axis in pieces"), here
 // in the PERSISTENT form -- measured faster than grid-order items in the
@@ -120,12 +141,6 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 // time order across the pieces).
 #ifndef HBV_TILED_MINWAVES
 #define HBV_TILED_MINWAVES 1
-#endif
-#ifndef RR_HBV_POW_LITE
-#define RR_HBV_POW_LITE 1
-#endif
-#ifndef RR_HBV_CONTRACT
-#define RR_HBV_CONTRACT 1
 #endif
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
           bool TAME = true, int TILED = 0>
@@ -212,6 +227,7 @@ hbvedu_kernel(
     // loop-invariant lane masks for the wave votes (common.h)
     const lanemask_t box_m = RR_LANES(box_ok);
     const lanemask_t fc_m = RR_LANES(inv_FC.ok), pwp_m = RR_LANES(inv_PWP.ok);
+    const bool pwp_pos = inv_PWP.ok && PWP > 0.0;
 
     double snow = snow_init, soil = soil_init, s1 = s1_init, s2 = s2_init;
     double acc = 0.0;
@@ -329,7 +345,12 @@ hbvedu_kernel(
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
         if (need_m & rr_exec()) {
 #if RR_FAITHFUL_QUOTIENTS
-            const double wetness = mul_by_inverse_m(soil, inv_FC, fc_m);
+            // (a tame wave has checked its divisors once, before the loop)
+            double wetness;
+            if constexpr (decltype(tame)::value)
+                wetness = inv_mul_core(soil, inv_FC);
+            else
+                wetness = mul_by_inverse_m(soil, inv_FC, fc_m);
 #else
             const double wetness = div_by_invariant_m(soil, soil_m, inv_FC,
                                                       fc_m);
@@ -380,9 +401,23 @@ hbvedu_kernel(
         // potential / actual evapotranspiration (:102-108); the select picks
         // the factor, 1 or soil/PWP, so that the product with pe goes into
         // the soil update's FMA
-        const double pe = __builtin_fma(C, f.dtemp, 1.0) * f.pe_m;
-        const double dry = (soil > PWP)
-            ? 1.0 : mul_by_inverse_m(soil, inv_PWP, pwp_m);
+        // (1 + C dtemp) PE_m as PE_m + C (dtemp PE_m): the forcing
+        // record carries the product
+        const double pe = __builtin_fma(C, f.dtemp, f.pe_m);
+        // min(soil/PWP, 1) for a lane with a positive, usable PWP -- what the
+        // reference's `if soil > PWP` selects, in one instruction (a NaN soil
+        // has made soil_lw NaN already) --, the select itself for any other
+        // lane; a tame wave has only lanes of the first kind
+        double dry;
+        if constexpr (decltype(tame)::value) {
+            const double ratio = inv_mul_core(soil, inv_PWP);
+            asm("v_min_f64 %0, %1, 1.0" : "=v"(dry) : "v"(ratio));
+        } else {
+            const double ratio = mul_by_inverse_m(soil, inv_PWP, pwp_m);
+            double least;
+            asm("v_min_f64 %0, %1, 1.0" : "=v"(least) : "v"(ratio));
+            dry = pwp_pos ? least : ((soil > PWP) ? 1.0 : ratio);
+        }
 
         // soil moisture (:111)
         const double soil_n = __builtin_fma(-pe, dry, soil_lw - prec_eff);
@@ -518,6 +553,11 @@ hbvedu_kernel(
         tame_wave = odd == 0 && snow_init >= 0.0 &&
                     !__builtin_signbit(snow_init) &&
                     (rr_exec() & ~lanes_of_class(DD, 0x3c3)) == 0;
+#if RR_HBV_CONTRACT && RR_FAITHFUL_QUOTIENTS
+        // ... and both divisors usable, PWP positive (day_step)
+        tame_wave = tame_wave &&
+                    (rr_exec() & ~(fc_m & RR_LANES(pwp_pos))) == 0;
+#endif
     }
     if constexpr (TAME) {
         if (tame_wave) time_loop(std::true_type{});
@@ -679,7 +719,11 @@ static int hbv_launch(const double *temp, const double *prec,
         // 3.14 / 3.22, 125k 3.76 / 3.70, 250k 7.45 / 7.62, 1M 27.4 / 27.8)
         if (variant == 1) go(std::integral_constant<int, 1>{}, std::false_type{});
         else if (variant == 2) go(std::integral_constant<int, 2>{}, std::true_type{});
+#if HBV_TWO_PER_SIMD_TAME
+        else if (two_per_simd) go(std::integral_constant<int, 0>{}, std::true_type{});
+#else
         else if (two_per_simd) go(std::integral_constant<int, 0>{}, std::false_type{});
+#endif
         else go(std::integral_constant<int, 0>{}, std::true_type{});
     });
     RR_HIP(hipGetLastError());
