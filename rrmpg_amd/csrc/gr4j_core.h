@@ -27,6 +27,20 @@
 #include "common.h"
 #include "fastmath.h"
 
+// Tolerance-driven arithmetic of the GR4J day: a
+// product that goes straight into a sum is contracted into it (one rounding
+// instead of two), the unit hydrographs' ordinates carry the 0.9 / 0.1 split
+// of the routed amount (gr4j_model.py:126-127), and the two store updates
+// x - x (1 - y) are taken as x y.  -DRR_GR4J_CONTRACT=0 builds the
+// reference's own sequence.
+#ifndef RR_GR4J_CONTRACT
+#define RR_GR4J_CONTRACT 1
+#endif
+#if RR_GR4J_CONTRACT
+#define GR4J_UH1_SHARE 0.9
+#define GR4J_UH2_SHARE 0.1
+#endif
+
 struct Gr4jPar {
     double x1, x2, x3, x4;
     InvDivisor inv_x1, inv_x3;   // x1, x3 divide five quantities every day
@@ -82,12 +96,6 @@ __device__ __forceinline__ lanemask_t gr4j_num_mask(double a)
 #define RR_GR4J_STRICT_VOTES 0
 #endif
 #define GR4J_NUM_HI_WORD 0x4C300000u        // high word of 2^196
-// Multiply-adds of the day contracted where a product goes straight into a
-// sum (the reference's operations in the reference's order, one rounding
-// instead of two); -DRR_GR4J_CONTRACT=0 builds the separately rounded form.
-#ifndef RR_GR4J_CONTRACT
-#define RR_GR4J_CONTRACT 1
-#endif
 __device__ __forceinline__ bool gr4j_num_ok(double a)
 {
 #if RR_GR4J_STRICT_VOTES
@@ -205,7 +213,11 @@ struct UhRegs {
 #pragma unroll
         for (int j = 0; j < N1MAX; ++j) {
             const double cur = gr4j_s_curve1(j + 1, x4);
+#if RR_GR4J_CONTRACT
+            o1[j] = (j < n1) ? GR4J_UH1_SHARE * (cur - prev) : 0.0;
+#else
             o1[j] = (j < n1) ? cur - prev : 0.0;
+#endif
             prev = cur;
             u.u1[j] = 0.0;
         }
@@ -213,7 +225,11 @@ struct UhRegs {
 #pragma unroll
         for (int j = 0; j < N2MAX; ++j) {
             const double cur = gr4j_s_curve2(j + 1, x4);
+#if RR_GR4J_CONTRACT
+            o2[j] = (j < n2) ? GR4J_UH2_SHARE * (cur - prev) : 0.0;
+#else
             o2[j] = (j < n2) ? cur - prev : 0.0;
+#endif
             prev = cur;
             u.u2[j] = 0.0;
         }
@@ -340,14 +356,22 @@ struct UhIndexed {
         double prev = 0.0;
         for (int j = 0; j < n1w; ++j) {
             const double cur = gr4j_s_curve1(j + 1, x4);
+#if RR_GR4J_CONTRACT
+            O1(j) = GR4J_UH1_SHARE * (cur - prev);
+#else
             O1(j) = cur - prev;
+#endif
             prev = cur;
             U1(j) = 0.0;
         }
         prev = 0.0;
         for (int j = 0; j < n2w; ++j) {
             const double cur = gr4j_s_curve2(j + 1, x4);
+#if RR_GR4J_CONTRACT
+            O2(j) = GR4J_UH2_SHARE * (cur - prev);
+#else
             O2(j) = cur - prev;
+#endif
             prev = cur;
             U2(j) = 0.0;
         }
@@ -736,9 +760,17 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     } else {
         root = gr4j_inv_fourth_root<by_vote>(b1, votes);
     }
+#if RR_GR4J_CONTRACT
+    // :117, :120: the store keeps sn * root and percolates the rest
+    const double kept = sn * root;
+    const double perc = sn - kept;
+    mid();
+    s = kept;
+#else
     const double perc = sn * (1 - root);
     mid();
     s = sn - perc;                                              // :120
+#endif
     return perc + excess;                                       // p_r, :123
 }
 
@@ -752,8 +784,12 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
                                                double p_r, V &&votes = V())
 {
     constexpr bool by_vote = true;    // (the same forms in every tier)
+#if RR_GR4J_CONTRACT
+    const double p_r_uh1 = p_r, p_r_uh2 = p_r;  // (the ordinates carry the split)
+#else
     const double p_r_uh1 = 0.9 * p_r;                           // :126-127
     const double p_r_uh2 = 0.1 * p_r;
+#endif
 
     double head1, head2;
     if constexpr (uh_is_indexed<UH>)
@@ -770,10 +806,12 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
     double rn = nb_max(0.0, __builtin_fma(P.x2, p35, r + head1)); // :142
     const double w = gr4j_div(rn, P.inv_x3, P.x3_m, votes);
     const double w2 = w * w;
-    const double q_r =
-        rn * (1 - gr4j_inv_fourth_root<by_vote>(
-                      __builtin_fma(w2, w2, 1.0), votes));      // :145
-    rn = rn - q_r;                                              // :148
+    // :145, :148: the store keeps rn y, y = (1 + w**4)**-0.25, and gives
+    // the rest
+    const double kept = rn * gr4j_inv_fourth_root<by_vote>(
+                                 __builtin_fma(w2, w2, 1.0), votes);
+    const double q_r = rn - kept;
+    rn = kept;
     const double q_d = nb_max(0.0, __builtin_fma(P.x2, p35, head2)); // :151
 #else
     const double gw_exchange =

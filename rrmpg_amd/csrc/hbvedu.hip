@@ -228,6 +228,8 @@ hbvedu_kernel(
     const lanemask_t box_m = RR_LANES(box_ok);
     const lanemask_t fc_m = RR_LANES(inv_FC.ok), pwp_m = RR_LANES(inv_PWP.ok);
     const bool pwp_pos = inv_PWP.ok && PWP > 0.0;
+    // what a day leaves of the two linear stores (RR_HBV_CONTRACT)
+    const double keep_1 = 1 - K_1 - K_p, keep_2 = 1 - K_2;
 
     double snow = snow_init, soil = soil_init, s1 = s1_init, s2 = s2_init;
     double acc = 0.0;
@@ -392,12 +394,12 @@ hbvedu_kernel(
         mid();
 
 #if RR_HBV_CONTRACT
-        // The reservoir updates with their multiply-adds CONTRACTED: the
-        // reference's operations in the reference's order, each product
-        // fused into the sum that takes it (one rounding instead of two --
-        // closer to the exact value, not further), 16 instructions instead
-        // of 23 a day.  -DRR_HBV_CONTRACT=0 builds the separately rounded
-        // form below.
+        // The reservoir updates with their multiply-adds CONTRACTED -- each
+        // product fused into the sum that takes it, one rounding instead of
+        // two -- and the two linear stores regrouped around their
+        // loop-invariant retention factors: 12 instructions instead of 23 a
+        // day, every result within an ulp or two of the reference's.
+        // -DRR_HBV_CONTRACT=0 builds the reference's own sequence below.
         // potential / actual evapotranspiration (:102-108); the select picks
         // the factor, 1 or soil/PWP, so that the product with pe goes into
         // the soil update's FMA
@@ -422,14 +424,13 @@ hbvedu_kernel(
         // soil moisture (:111)
         const double soil_n = __builtin_fma(-pe, dry, soil_lw - prec_eff);
 
-        // near-surface reservoir (:114-118)
+        // near-surface reservoir (:114-118): s1 - s1 K_1 - s1 K_p as
+        // s1 (1 - K_1 - K_p), the factor a loop invariant
         const double over = nb_max(0.0, s1 - L) * K_0;
-        const double s1_n = __builtin_fma(
-            -s1, K_p, __builtin_fma(-s1, K_1, s1 + prec_eff - over));
+        const double s1_n = __builtin_fma(s1, keep_1, prec_eff - over);
 
-        // base-flow reservoir (:121-123)
-        const double s2_n =
-            __builtin_fma(-s2, K_2, __builtin_fma(s1, K_p, s2));
+        // base-flow reservoir (:121-123), likewise s2 (1 - K_2) + s1 K_p
+        const double s2_n = __builtin_fma(s2, keep_2, s1 * K_p);
 
         // discharge mixes old and new states (:125-127)
         const double q =
