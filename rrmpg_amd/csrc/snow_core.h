@@ -92,17 +92,33 @@ static inline size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp,
 // SGPRs, and every one that overflows into a VGPR lane costs a v_readlane
 // (a VALU slot) per use.
 struct CemaGt { double gt, rgt; };
+// Tolerance-driven forms of the snow routine: the
+// quotient G / G_tresh and the layer mean as ONE multiply by the rounded
+// reciprocal (1.5 ulp, any numerator: no numerator vote), 0.9 ratio + 0.1 as
+// one FMA.  The thermal state keeps the reference's own sequence and stays
+// bit-identical to it; snow pack and outflow are within 1e-14 of it over 30
+// years (tests/conftest.py SNOW_TOL = 1e-12).  Cemaneige 1M sets 38.9 -> 35.0
+// ms, scores 33.4 -> 27.9; fused 83.1 -> 77.6, its 125k shard 12.9 -> 11.7.
+// -DRR_SNOW_FAITHFUL=0 builds the correctly rounded forms (bit-identical
+// snow pack).
+#ifndef RR_SNOW_FAITHFUL
+#define RR_SNOW_FAITHFUL 1
+#endif
 typedef const CemaGt __attribute__((address_space(4))) *cema_gt_ptr_t;
 
-// c / L (the layer mean, np.mean's division by the size): L is a constant,
-// so the correctly rounded 3-FMA quotient of invdiv.h applies; c is a sum of
-// non-negative fluxes, anything else takes the IEEE division.
+// c / L (the layer mean, np.mean's division by the size): L is a constant --
+// one multiply by RN(1/L) (RR_SNOW_FAITHFUL), or the correctly rounded 3-FMA
+// quotient of invdiv.h under its numerator vote.
 template <int L, class V = CarefulVotes>
 __device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 {
     const InvDivisor inv_L = {(double)L, 1.0 / (double)L, true};
+#if RR_SNOW_FAITHFUL
+    return inv_mul_core(c, inv_L);
+#else
     return div_by_invariant_m(c, gr4j_num_mask(c), inv_L, ~0ull, 0x1p900,
                               votes);
+#endif
 }
 
 // One day of the snow routine for all L layers of one parameter set
@@ -168,6 +184,9 @@ __device__ __forceinline__ double cema_day_io(
             e = thermal_state_init;
         } else {
             g = G_in[l] + snow;
+            // (not contracted: the thermal state crosses zero, where an FMA's
+            // other rounding is 1e-9 of the value -- and it would buy one
+            // instruction)
             e = CTG * eTG_in[l] + one_minus_CTG * temp;
         }
         if (SANE && !FIRST) {
@@ -228,11 +247,18 @@ __device__ __forceinline__ double cema_day_io(
             // (the quotient -- and its vote -- for every lane: a vote inside
             // a per-lane conditional would make the vote mask a per-lane
             // value)
+#if RR_SNOW_FAITHFUL
+            const double gq = mul_by_inverse_m(g, inv_gt, gt_ok, votes);
+            const double ratio =                           // :109-112
+                SANE ? rr_hw_min(gq, 1.0) : ((g < inv_gt.b) ? gq : 1.0);
+            melt = __builtin_fma(0.9, ratio, 0.1) * pot_melt;  // :115
+#else
             const double gq = div_by_invariant_m(g, gr4j_num_mask(g), inv_gt,
                                                  gt_ok, 0x1p900, votes);
             const double ratio =                           // :109-112
                 SANE ? rr_hw_min(gq, 1.0) : ((g < inv_gt.b) ? gq : 1.0);
             melt = (0.9 * ratio + 0.1) * pot_melt;         // :115
+#endif
         }
         g = g - melt;                                      // :118
         G[l] = g;

@@ -15,7 +15,7 @@ configs[3] CemaneigeGR4J, one GPU's shard (125k sets) of the 1M-set sweep,
 import numpy as np
 import pytest
 
-from .conftest import rel_err
+from .conftest import rel_err, snow_same
 
 pytestmark = pytest.mark.gpu
 
@@ -421,8 +421,8 @@ def test_column_blocks_with_3d_storages(env, oracle):
     ref = oracle.simulate_cemaneigegr4j(layers[0], layers[1], layers[3],
                                         layers[2], (2.0, -0.1, 0.6, 0.7), flat,
                                         return_storages=True, nthreads=8)
-    assert np.array_equal(G.cpu().numpy(), ref[1])
-    assert np.array_equal(E.cpu().numpy(), ref[2])
+    snow_same(G.cpu().numpy(), ref[1])
+    snow_same(E.cpu().numpy(), ref[2], exact=True)
     assert rel_err(q.cpu().numpy(), ref[0]) < RTOL
     # snow routine alone, same exercise
     C = env["models"].Cemaneige
@@ -437,5 +437,5 @@ def test_column_blocks_with_3d_storages(env, oracle):
     refc = oracle.simulate_cemaneige(layers[0], layers[1], layers[2],
                                      (2.0, -0.1), flat[:, :2],
                                      return_storages=True, nthreads=8)
-    for a, b in zip((o, g, e), refc):
-        assert np.array_equal(a.cpu().numpy(), b)
+    for k, (a, b) in enumerate(zip((o, g, e), refc)):
+        snow_same(a.cpu().numpy(), b, exact=(k == 2))

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from .conftest import golden
+from .conftest import golden, snow_same
 
 #: RR_FUZZ_SEED=<k> shifts every generator seed (soak runs: the committed
 #: runs use 0)
@@ -510,7 +510,8 @@ def test_snow_kernels_with_poisoned_forcing(models, oracle, poison):
         out, _ = cmod._run((lp, lm, fr), inits_c,
                            _records(models.Cemaneige, flat), True, True, None)
         for a, b, name in zip(out, ref, ["outflow", "G", "eTG"]):
-            assert np.array_equal(a, b, equal_nan=True), (poison, name)
+            # (NaN pattern exact in all three; the thermal state bit for bit)
+            snow_same(a, b, exact=name == "eTG", what=(poison, name))
     flat = np.column_stack([rng.uniform(0, 1, n), rng.uniform(0, 10, n),
                             rng.uniform(10, 1200, n), rng.uniform(-5, 3, n),
                             rng.uniform(20, 300, n), rng.uniform(0.5, 2.9, n)])
@@ -522,8 +523,8 @@ def test_snow_kernels_with_poisoned_forcing(models, oracle, poison):
                        _records(models.CemaneigeGR4J, flat), True, True, None)
     for a, b, name in zip(out, ref, ["qsim", "G", "eTG", "s_store", "r_store"]):
         _same(a, b, "%s cemaneigegr4j %s" % (poison, name))
-    assert np.array_equal(out[1], ref[1], equal_nan=True)
-    assert np.array_equal(out[2], ref[2], equal_nan=True)
+    snow_same(out[1], ref[1], what=poison)
+    snow_same(out[2], ref[2], exact=True, what=poison)
     fice = np.array([0.0, 0.1, 0.3, 0.6, 0.9])
     flat = np.column_stack([rng.uniform(0, 1, n), rng.uniform(0, 10, n),
                             rng.uniform(10, 1200, n), rng.uniform(-5, 3, n),
@@ -569,8 +570,7 @@ def test_snow_kernels_with_poisoned_forcing(models, oracle, poison):
             if a is None:
                 continue
             if k in ("G", "eTG", "sca"):
-                assert np.array_equal(a, ref[k], equal_nan=True), \
-                    (poison, ice, k)
+                snow_same(a, ref[k], exact=k != "G", what=(poison, ice, k))
             else:
                 _same(a, ref[k], "%s hyst %s" % (poison, k))
 
