@@ -97,6 +97,10 @@ def parse_args():
                          "(RR_OPT_GR4J_VARIANT: 1 one wave per 64 sets, "
                          "2 wave-specialised)")
     ap.add_argument("--no-parity-spot", action="store_true")
+    ap.add_argument("--no-power-soak", action="store_true",
+                    help="skip the 2.5-s steady-state soak after the timed "
+                         "region that reads socket power and shader clock "
+                         "(roofline.power)")
     ap.add_argument("--score", default="mse", choices=["mse", "nse"],
                     help="per-set score that is all-gathered: mse (the "
                          "reference's monte_carlo) or nse (BASELINE "
@@ -403,6 +407,108 @@ def traffic_record(args, n, t):
         return None, None
 
 
+class SocketSampler:
+    """Socket power and shader clock of one GPU, read from its hwmon files
+    (power1_input in microwatts, freq1_input in hertz, power1_cap) every few
+    milliseconds on a thread of its own: which roof the chip is at.
+    Everything is optional -- no files, no record."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        self.dir = None
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id,
+                                        pr.pci_device_id)
+        except Exception:
+            pass
+        cands = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if os.path.exists(os.path.join(d, "power1_input")):
+                cands.append(d)
+        for d in cands:
+            if want and want in os.path.realpath(os.path.join(d, "..", "..")):
+                self.dir = d
+        if self.dir is None and len(cands) == 1:
+            self.dir = cands[0]
+        self.power, self.clock = [], []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as fp:
+                return float(fp.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            p, c = self._read("power1_input"), self._read("freq1_input")
+            if p is not None:
+                self.power.append(p * 1e-6)
+            if c is not None:
+                self.clock.append(c * 1e-6)
+            time.sleep(0.004)
+
+    def __enter__(self):
+        if self.dir:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.dir:
+            self._thread.join(timeout=1.0)
+
+    def record(self):
+        if not self.power:
+            return None
+        cap = self._read("power1_cap")
+        return {"socket_w": float(np.mean(self.power)),
+                "sclk_mhz": float(np.mean(self.clock)) if self.clock else None,
+                "cap_w": cap * 1e-6 if cap else None,
+                "samples": len(self.power),
+                "source": "hwmon power1_input / freq1_input of this GPU"}
+
+
+def power_soak(sweep, per_step_s, device, world, seconds=2.5):
+    """Socket power and shader clock of the sweep in steady state: the same
+    step repeated for `seconds` AFTER the timed region (the sensor is an
+    average over about a second; the timed region of a default run lasts a
+    tenth of one), samples of the second half only.  Every rank runs the
+    same number of steps (the step holds a collective)."""
+    import torch
+    import torch.distributed as dist
+    count = max(4, int(seconds / max(per_step_s, 1e-4)))
+    sampler = SocketSampler(device.index if getattr(device, "index", None)
+                            is not None else 0)
+    with sampler:
+        t0 = time.perf_counter()
+        for k in range(count):
+            if k == count // 2:
+                torch.cuda.synchronize(device)
+                half = (len(sampler.power), len(sampler.clock))
+            sweep.step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        wall = time.perf_counter() - t0
+    sampler.power = sampler.power[half[0]:]
+    sampler.clock = sampler.clock[half[1]:]
+    rec = sampler.record()
+    if rec:
+        rec["soak_steps"] = count
+        rec["soak_ms_per_step"] = wall / count * 1e3
+        rec["source"] = ("hwmon power1_input / freq1_input of this GPU, "
+                         "second half of a %.1f-s soak of the same sweep "
+                         "after the timed region" % wall)
+    return rec
+
+
 def run_workload(args, device, rank, world, on_host, steps, warmup,
                  score="mse"):
     """Build this rank's share of the workload `args` names, time `steps`
@@ -580,6 +686,9 @@ def main():
     r = run_workload(args, device, rank, world, on_host, args.steps,
                      args.warmup, score=args.score)
     n, t, kernel_ms = r["n"], r["t"], r["kernel_ms"]
+    r["power"] = (None if args.no_power_soak else
+                  power_soak(r["sweep"], r["elapsed"] / args.steps, device,
+                             world))
 
     if rank == 0:
         value = r["total_units"] * t * args.steps / r["elapsed"]
@@ -613,6 +722,9 @@ def main():
                        "valu.instr_per_unit": "profiles/traffic.json "
                                               "(SQ_INSTS_VALU pass)"},
             "valu_instr_per_unit": valu,
+            # socket power and shader clock of the same sweep in steady
+            # state (rank 0's GPU): at the cap, the kernel is power-bound
+            "power": r["power"],
         }
         if valu:
             # the roof that actually binds the 8 B/unit mode: fp64 VALU issue.

@@ -83,6 +83,11 @@ def test_default_line_carries_every_config_and_the_valu_roof():
     assert v["cycles_per_instr"] == 4 and v["simds"] == 1024
     assert abs(v["frac"] - v["floor_ms"] / r["kernel_ms"]) < 1e-12
     assert 0.4 < v["frac"] < 1.0 and 0.3 < r["frac"] < 1.0
+    # socket power / shader clock of the same sweep in steady state, read
+    # after the timed region (None where the GPU has no hwmon files)
+    pw = r["power"]
+    assert pw is None or (pw["samples"] >= 1 and 50 < pw["socket_w"] < 3000
+                          and pw["soak_steps"] >= 4)
     ex = d["extra_configs"]
     assert len(ex) == 6
     for e in ex:
