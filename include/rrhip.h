@@ -30,8 +30,19 @@
  *     Monte-Carlo sweep (rrmpg/tools/monte_carlo.py:66-71) need not move
  *     qsim at all;
  *   - return value: RR_OK or a negative RR_E_* code; rr_last_error() gives
- *     the text.  Numerical trouble is not an error: NaN propagates exactly
- *     as in the reference.  Nothing here falls back to a CPU path.
+ *     the text.  Numerical trouble is not an error: NaN propagates as in
+ *     the reference.  Nothing here falls back to a CPU path.
+ *
+ * Numerics: fp64 throughout.  ABC, HBV-Edu's snow pack and every thermal
+ * state are bit-identical to the reference's arithmetic; everything else is
+ * within 1e-10 relative of it (measured over 30 years: 2e-14 HBV-Edu, 4e-13
+ * the GR4J family, 1e-14 Cemaneige) -- power, tanh and roots are not libm's,
+ * quotients by per-set constants are one multiply by the rounded reciprocal,
+ * a product that feeds a sum is one FMA (each form has
+ * a build flag that restores the reference's own sequence).  One consequence
+ * beyond ulps: a run that overflows (parameters like 1e200, an infinite
+ * parameter reaching a store) may read inf where the reference reads NaN, or
+ * the other way round, from the day it leaves the numbers.
  *
  * Two families:
  *   rr_<model>_simulate      host pointers; synchronous; the library moves
