@@ -439,3 +439,38 @@ def test_layer_preprocessing_argument_errors_without_gpu():
                                        None, None, None, None, None, 0,
                                        None) == 0
     assert lib.rr_gr4j_plan_status(None, None) == -1
+
+
+def test_fuzz_horizon_rules():
+    """tests/test_gpu_fuzz.py _overflow_horizon, the one place where the GPU
+    tests stop following the oracle: sets whose reference run holds an
+    infinity, can overflow, or runs away are cut short -- nothing else is."""
+    from . import test_gpu_fuzz as F
+    t, n = 10, 6
+    flat = np.ones((n, 3))
+    ref = np.ones((t, n))
+    flat[1, 0] = np.nan; ref[4:, 1] = np.nan      # NaN parameter: followed
+    flat[2, 1] = np.inf; ref[7, 2] = np.inf; ref[8:, 2] = np.nan
+    flat[3, 2] = 1e200; ref[5:, 3] = np.nan       # can overflow
+    ref[6:, 4] = 3e6                              # run-away store
+    flat[5, 0] = 5e-324; flat[5, 1] = -0.0        # subnormal, -0: followed
+    hz = F._overflow_horizon(flat, [ref, ref.copy()])
+    assert hz.tolist() == [t, t, 7, 5, 6, t]
+    # 3-D series (layers) count as well
+    r3 = np.ones((t, 2, n))
+    r3[3, 1, 0] = -np.inf
+    assert F._overflow_horizon(flat, [ref, r3])[0] == 3
+
+
+def test_bench_socket_sampler_without_hwmon():
+    """bench.py's power record is optional: no hwmon files (this container),
+    no record -- and nothing raises."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s = bench.SocketSampler(0)
+    with s:
+        pass
+    assert s.record() is None or s.record()["samples"] >= 1
