@@ -36,6 +36,9 @@
 #ifndef RR_GR4J_CONTRACT
 #define RR_GR4J_CONTRACT 1
 #endif
+#ifndef RR_GR4J_TANH_RATIONAL
+#define RR_GR4J_TANH_RATIONAL 1
+#endif
 #if RR_GR4J_CONTRACT
 #define GR4J_UH1_SHARE 0.9
 #define GR4J_UH2_SHARE 0.1
@@ -552,7 +555,12 @@ static inline void gr4j_for_each_tier(F &&f)
 // the plain GR4J kernels keep the tanh's in SGPRs; the fused snow kernels are
 // short of SGPRs and fetch them from constant memory at the point of use;
 // their small-sweep variants (at most two waves per SIMD) hold them in VGPRs.
-enum { GR4J_CONSTS_SGPR = 0, GR4J_CONSTS_VGPR = 1, GR4J_CONSTS_JIT = 2 };
+enum { GR4J_CONSTS_SGPR = 0, GR4J_CONSTS_VGPR = 1, GR4J_CONSTS_JIT = 2,
+       // ... and the exponential tanh instead of the rational one: the ice
+       // kernels (snownext.hip), which spill already and lose 6-9 % to the
+       // approximant's live ranges (ice 86.4 -> 92.0 ms, hysteresis + ice
+       // 165 -> 181) where every other kernel gains 3-11 %
+       GR4J_CONSTS_JIT_EXP = 3 };
 
 #ifndef RR_R4_POLY
 #define RR_R4_POLY 1        // measurement switch: 0 = Newton form everywhere
@@ -661,7 +669,7 @@ struct Gr4jNoHook {
 // the halves in different waves of a workgroup, a few days apart; everybody
 // else calls them back to back through gr4j_step_net.  Same instruction
 // sequence either way, so the results are bit-identical.
-template <class UH, int CONSTS = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook,
+template <class UH, int CONSTS_ = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook,
           class V = CarefulVotes>
 __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
                                                   double net, bool wet,
@@ -669,13 +677,28 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
                                                   MID &&mid = MID(),
                                                   V &&votes = V())
 {
+    constexpr bool rational_tanh =
+        RR_GR4J_TANH_RATIONAL && CONSTS_ != GR4J_CONSTS_JIT_EXP;
+    constexpr int CONSTS =
+        CONSTS_ == GR4J_CONSTS_JIT_EXP ? (int)GR4J_CONSTS_JIT : CONSTS_;
     // tanh(net/x1) = E / D (fastmath.h: E = expm1(2a)/2, D = E + 1); its
     // quotient is folded into the store update's own:
     //     c*th / (1 + k*th) == c*E / (D + k*E),
     // one division per day instead of two.
+    // RR_GR4J_TANH_RATIONAL: E / D is the [9/8] Pade approximant of tanh
+    // (fastmath.h fast_tanh_rational_parts: ten instructions instead of 28)
+    // for |net/x1| <= 1 -- net rainfall below the store's capacity, every day
+    // of a sane run --; a lane beyond that (or NaN) is voted out with the
+    // rest below and takes the exponential form.
+    const double a_th = gr4j_div_m(net, net_m, P.inv_x1, P.x1_m, votes);
     double E, D;
-    fast_tanh_parts<CONSTS>(
-        gr4j_div_m(net, net_m, P.inv_x1, P.x1_m, votes), E, D);
+    lanemask_t a_small = ~0ull;
+    if constexpr (rational_tanh) {
+        fast_tanh_rational_parts<CONSTS>(a_th, E, D);
+        a_small = RR_LANES(fabs(a_th) <= FP_TANHR_AMAX);
+    } else {
+        fast_tanh_parts<CONSTS>(a_th, E, D);
+    }
     // One vote covers the quotient s/x1 and the folded form: with
     // 0 <= s < 2^196 and |x1| in [2^-100, 2^100] (invdiv.h) the quotient is
     // within 1.5 ulp of s/x1 and |s/x1| <= 2^296, so c*E and k*E (E <= 1.2e17,
@@ -699,23 +722,39 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
 #else
     const double den = D + k * E;
 #endif
-    const lanemask_t fast = gr4j_num_lanes(s) & P.x1_m &
+    const lanemask_t fast = gr4j_num_lanes(s) & P.x1_m & a_small &
                             RR_LANES(fabs(den) >= 0x1p-100);
     double frac = fast_div_core(c * E, den);
     if (RR_VOTE(votes, fast)) {
+        // (a lane keeps ITS tanh whatever sends the wave here: the
+        // approximant inside its range, the exponential form outside)
+        bool small = true;
+        double Es = E, Ds = D;
+        if constexpr (rational_tanh) {
+            asm volatile("");                       // keep this a branch
+            // (the argument taken again -- the same product -- rather than
+            // kept alive across the day for a path that never runs)
+            const double a_again =
+                gr4j_div_m(net, net_m, P.inv_x1, P.x1_m);
+            double E2, D2;
+            fast_tanh_parts<CONSTS>(a_again, E2, D2);
+            small = fabs(a_again) <= FP_TANHR_AMAX;
+            Es = small ? E : E2;
+            Ds = small ? D : D2;
+        }
         double exact;
         if constexpr (std::is_same<UH, UhRegs<10>>::value) {
             // measured: out of line is 2 % faster in these kernels, 1-2 %
             // slower in the others
-            exact = gr4j_store_change_reference(wet, s, P.x1, E, D);
+            exact = gr4j_store_change_reference(wet, s, P.x1, Es, Ds);
         } else {
             asm volatile("");                       // keep this a branch
             double ce, ke;
             gr4j_store_coefficients(wet, s, P.x1, s / P.x1, ce, ke);
-            const double th = E / D;
+            const double th = Es / Ds;
             exact = ce * th / (1 + ke * th);
         }
-        const bool ok = gr4j_num_ok(s) && P.inv_x1.ok &&
+        const bool ok = gr4j_num_ok(s) && P.inv_x1.ok && small &&
                         fabs(den) >= 0x1p-100;
         frac = ok ? frac : exact;
     }

@@ -230,7 +230,8 @@ snow_gr4j_kernel(
             }
             liquid = snowmelt + ice_total;
         }
-        const double q = gr4j_step<UH, GR4J_CONSTS_JIT>(P, s, r, uh, liquid, day[3 * L]);
+        const double q = gr4j_step<UH, ICE ? GR4J_CONSTS_JIT_EXP : GR4J_CONSTS_JIT>(
+            P, s, r, uh, liquid, day[3 * L]);
         if (active && (wq | ws)) {
             snow_out_ptr_t po =
                 (snow_out_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -401,7 +402,8 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
         }
         const double snowmelt = c / (double)L;
         const double liquid = ICE ? snowmelt + ice_total : snowmelt;
-        const double q = gr4j_step<UH, GR4J_CONSTS_JIT>(P, s, r, uh, liquid, day[3 * L]);
+        const double q = gr4j_step<UH, ICE ? GR4J_CONSTS_JIT_EXP : GR4J_CONSTS_JIT>(
+            P, s, r, uh, liquid, day[3 * L]);
         if (active) {
             if (wq) o.qsim[t * ld + i] = q;
             if (ws) {

@@ -143,6 +143,30 @@ int main(int argc, char **argv) {
                        std::isnan(fast_tanh(NAN)) &&
                        fast_tanh(1e-300) == 1e-300 && fast_tanh(-4e-320) == -4e-320;
     printf("tanh_special_ok %d\n", tanh_special);
+    // the [9/8] Pade pair (fast_tanh_rational_parts, GR4J's default inside
+    // |a| <= 1): num / den against tanhl over its whole range, both signs;
+    // zeros keep their sign, tiny arguments come back unchanged
+    {
+        double wr = 0, wrx = 0;
+        for (long i = 0; i < n; ++i) {
+            const double a = FP_TANHR_AMAX * u01() * (u01() < 0.5 ? -1 : 1);
+            double nu, de;
+            fast_tanh_rational_parts(a, nu, de);
+            const double err = ulp_err(nu / de, tanhl((long double)a));
+            if (err > wr) { wr = err; wrx = a; }
+        }
+        double nu, de;
+        fast_tanh_rational_parts(0.0, nu, de);
+        int ok = nu == 0.0 && !signbit(nu) && de == 1.0;
+        fast_tanh_rational_parts(-0.0, nu, de);
+        ok = ok && nu == 0.0 && signbit(nu);
+        fast_tanh_rational_parts(1e-300, nu, de);
+        ok = ok && nu / de == 1e-300;
+        fast_tanh_rational_parts(NAN, nu, de);
+        ok = ok && std::isnan(nu / de);
+        printf("worst_ulp_tanh_rational %.4f at a=%.17g\n", wr, wrx);
+        printf("tanh_rational_special_ok %d\n", ok);
+    }
 
     // fast_sqrt_core on its domain
     double ws = 0, wsx = 0;

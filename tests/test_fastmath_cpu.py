@@ -48,6 +48,9 @@ def test_fastpow_accuracy(tmp_path):
     assert float(vals["worst_ulp_tanh_gr4j"]) < 3.0, out
     assert float(vals["worst_ulp_tanh_wide"]) < 3.0, out
     assert int(vals["tanh_special_ok"]) == 1, out
+    # GR4J's default inside |a| <= 1: the [9/8] Pade pair
+    assert float(vals["worst_ulp_tanh_rational"]) < 4.0, out
+    assert int(vals["tanh_rational_special_ok"]) == 1, out
     assert float(vals["worst_ulp_fast_sqrt"]) < 0.75, out
     assert float(vals["worst_ulp_inv_fourth_root"]) < 2.0, out
     assert int(vals["r4_special_ok"]) == 1, out
