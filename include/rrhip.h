@@ -101,12 +101,24 @@ int rr_get_device(void);
  * next call allocates again). */
 int rr_release_cached_memory(void);
 
-/* Measurement / test hooks.  Process-wide integer options that select a
- * specific kernel variant for A/B measurements and for parity tests that
- * must reach a variant the size heuristics would not pick.  The launch paths
- * read them as plain ints (no environment variables are consulted anywhere
- * in the library).  rr_debug_set_option returns RR_E_PARAM for an unknown
- * option or value; rr_debug_get_option returns the current value (or
+/* Options: which GPUs a host-pointer call spreads over, and which kernel
+ * variant / blocking a call uses where the library's own choice (by sweep
+ * size) is to be overridden.  Every option is an integer indexed by RR_OPT_*.
+ * Three ways to set one, consulted in this order:
+ *   1. per call: rr_<model>_simulate_opt(..., const rr_call_options *opt) --
+ *      the form a product caller uses (monte_carlo(gpus=...), sharding.sweep);
+ *      it holds for that call only, on the calling thread and the shard
+ *      threads the call starts.  Re-entrant: concurrent calls from several
+ *      threads, each with its own options, do not see each other;
+ *   2. per thread: rr_thread_options(opt) -- standing options of the calling
+ *      thread for its later calls (the *_simulate_dev family has no per-call
+ *      argument); NULL clears them;
+ *   3. process-wide: rr_debug_set_option -- MEASUREMENT AND TEST HOOKS ONLY
+ *      (A/B timing of kernel variants, parity tests that must reach a variant
+ *      the size heuristics would not pick).  No product path sets them.
+ * No environment variable is consulted anywhere in the library.
+ * rr_debug_set_option / rr_call_options_set return RR_E_PARAM for an unknown
+ * option or value; rr_debug_get_option returns the process-wide value (or
  * INT64_MIN for an unknown option). */
 #define RR_OPT_HBV_VARIANT     1 /* -1 heuristic (default); 0 one scalar load
                                   * per day; 1 forcing staged in LDS; 2 next
@@ -136,8 +148,9 @@ int rr_release_cached_memory(void);
                                   * workgroup); 3 gr4j_kernel in workgroups of
                                   * four waves; 4 optimistic (branch-free day,
                                   * redone if a vote failed)                 */
-#define RR_OPT_HOST_SHARDS     7 /* the host-pointer family (rr_<model>_simulate)
-                                  * over several GPUs inside ONE call: 0 / 1
+#define RR_OPT_HOST_SHARDS     7 /* the host-pointer family (rr_<model>_simulate
+                                  * [_opt]) over several GPUs inside ONE call
+                                  * -- the `ndev` of the call: 0 / 1
                                   * (default) the current device only; S > 1
                                   * cuts the N sets into S contiguous shards,
                                   * shard j on device (current + j) % count,
@@ -146,15 +159,32 @@ int rr_release_cached_memory(void);
                                   * one shard per visible device.  No
                                   * collective: sets are independent, the
                                   * forcing is uploaded to every device.      */
-#define RR_OPT_TIME_TILES      8 /* million-set sweeps (HBV-Edu, GR4J): the time
-                                  * axis in pieces pulled from a work queue by
-                                  * persistent waves, which evens out the last
-                                  * round of equal-length waves: -1 by sweep
-                                  * size (default: 4 pieces from ten waves per
-                                  * SIMD on), 0 never, k > 1 pieces           */
+#define RR_OPT_TIME_TILES      8 /* HBV-Edu, GR4J, Cemaneige: the time axis of
+                                  * every wave's sets in pieces, the states
+                                  * handed from piece to piece through HBM,
+                                  * which evens out the last round of
+                                  * equal-length waves.  Work
+                                  * items are handed out by an atomic ticket
+                                  * counter (HBV-Edu: to persistent waves), so
+                                  * an item only ever waits for one a running
+                                  * wave already holds.  -1 by sweep size
+                                  * (default), 0 never, k > 1 pieces          */
 #define RR_OPT_COUNT_          9
 int rr_debug_set_option(int option, int64_t value);
 int64_t rr_debug_get_option(int option);
+
+#define RR_OPT_UNSET INT64_MIN   /* "the library's choice" in rr_call_options */
+typedef struct rr_call_options {
+    size_t struct_bytes;         /* sizeof(rr_call_options), set by _init     */
+    int64_t value[16];           /* indexed by RR_OPT_*                       */
+} rr_call_options;
+/* All options RR_OPT_UNSET. */
+void rr_call_options_init(rr_call_options *opt);
+/* opt->value[option] = value after the range check of rr_debug_set_option
+ * (RR_OPT_UNSET is always accepted). */
+int rr_call_options_set(rr_call_options *opt, int option, int64_t value);
+/* Standing options of the calling thread (copied; NULL clears). */
+int rr_thread_options(const rr_call_options *opt);
 
 /* ---- ABC model -------------------------------------------------------
  * replaces run_abcmodel(prec, initial_state, params)
@@ -169,6 +199,12 @@ int rr_abc_simulate(const double *prec, int64_t T, double initial_state,
                     const double *params, int64_t N,
                     double *qsim, double *storage,
                     const double *qobs, double *sse);
+/* the same with per-call options (NULL: none) */
+int rr_abc_simulate_opt(const double *prec, int64_t T, double initial_state,
+                    const double *params, int64_t N,
+                    double *qsim, double *storage,
+                    const double *qobs, double *sse,
+    const rr_call_options *opt);
 
 /* ---- HBV-Edu ---------------------------------------------------------
  * replaces run_hbvedu(temp, prec, month, PE_m, T_m, snow_init, soil_init,
@@ -194,6 +230,15 @@ int rr_hbvedu_simulate(const double *temp, const double *prec,
                        double s2_init, const double *params, int64_t N,
                        double *qsim, double *snow, double *soil, double *s1,
                        double *s2, const double *qobs, double *sse);
+/* the same with per-call options (NULL: none) */
+int rr_hbvedu_simulate_opt(const double *temp, const double *prec,
+                       const int8_t *month, const double *PE_m,
+                       const double *T_m, int64_t T,
+                       double snow_init, double soil_init, double s1_init,
+                       double s2_init, const double *params, int64_t N,
+                       double *qsim, double *snow, double *soil, double *s1,
+                       double *s2, const double *qobs, double *sse,
+    const rr_call_options *opt);
 
 /* Multi-catchment HBV-Edu (BASELINE.json configs[4]): C independent
  * catchments, each with its own forcing and its own N parameter sets, in ONE
@@ -257,6 +302,13 @@ int rr_gr4j_simulate(const double *prec, const double *etp, int64_t T,
                      const double *params, int64_t N,
                      double *qsim, double *s_store, double *r_store,
                      const double *qobs, double *sse);
+/* the same with per-call options (NULL: none) */
+int rr_gr4j_simulate_opt(const double *prec, const double *etp, int64_t T,
+                     double s_init, double r_init,
+                     const double *params, int64_t N,
+                     double *qsim, double *s_store, double *r_store,
+                     const double *qobs, double *sse,
+    const rr_call_options *opt);
 
 /* ---- Cemaneige snow routine -------------------------------------------
  * replaces run_cemaneige(prec, mean_temp, frac_solid_prec, snow_pack_init,
@@ -280,6 +332,14 @@ int rr_cemaneige_simulate(const double *prec, const double *mean_temp,
                           const double *params, int64_t N,
                           double *outflow, double *G, double *eTG,
                           const double *qobs, double *sse);
+/* the same with per-call options (NULL: none) */
+int rr_cemaneige_simulate_opt(const double *prec, const double *mean_temp,
+                          const double *frac_solid_prec, int64_t T, int64_t L,
+                          double snow_pack_init, double thermal_state_init,
+                          const double *params, int64_t N,
+                          double *outflow, double *G, double *eTG,
+                          const double *qobs, double *sse,
+    const rr_call_options *opt);
 
 /* Forcing preprocessing of the Cemaneige family on the device -- replaces
  * extrapolate_precipitation, extrapolate_temperature and
@@ -330,6 +390,16 @@ int rr_cemaneigegr4j_simulate(const double *prec, const double *mean_temp,
                               double *qsim, double *G, double *eTG,
                               double *s_store, double *r_store,
                               const double *qobs, double *sse);
+/* the same with per-call options (NULL: none) */
+int rr_cemaneigegr4j_simulate_opt(const double *prec, const double *mean_temp,
+                              const double *etp, const double *frac_solid_prec,
+                              int64_t T, int64_t L, double snow_pack_init,
+                              double thermal_state_init, double s_init,
+                              double r_init, const double *params, int64_t N,
+                              double *qsim, double *G, double *eTG,
+                              double *s_store, double *r_store,
+                              const double *qobs, double *sse,
+    const rr_call_options *opt);
 
 /* ---- per-set skill scores from a resident discharge array ---------------
  * One pass over qsim[T][ld] (device) against obs[T] (device) gives, for each
@@ -404,6 +474,15 @@ int rr_cemaneigehystgr4j_simulate(
     double s_init, double r_init, const double *params, int64_t N,
     double *qsim, double *G, double *eTG, double *s_store, double *r_store,
     double *sca, const double *qobs, double *sse);
+/* the same with per-call options (NULL: none) */
+int rr_cemaneigehystgr4j_simulate_opt(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_solid_prec, int64_t T, int64_t L,
+    double snow_pack_init, double thermal_state_init, double sca_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *sca, const double *qobs, double *sse,
+    const rr_call_options *opt);
 
 /* replaces run_cemaneigegr4jice(prec, mean_temp, etp, frac_ice,
  *     frac_solid_prec, snow_pack_init, thermal_state_init, s_init, r_init,
@@ -425,6 +504,15 @@ int rr_cemaneigegr4jice_simulate(
     double s_init, double r_init, const double *params, int64_t N,
     double *qsim, double *G, double *eTG, double *s_store, double *r_store,
     double *icemelt, const double *qobs, double *sse);
+/* the same with per-call options (NULL: none) */
+int rr_cemaneigegr4jice_simulate_opt(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *icemelt, const double *qobs, double *sse,
+    const rr_call_options *opt);
 
 /* replaces run_cemaneigehystgr4jice(prec, mean_temp, etp, frac_ice,
  *     frac_solid_prec, snow_pack_init, thermal_state_init, sca_init, s_init,
@@ -448,6 +536,16 @@ int rr_cemaneigehystgr4jice_simulate(
     int64_t N, double *qsim, double *G, double *eTG, double *s_store,
     double *r_store, double *sca, double *icemelt, double *snowmelt,
     const double *qobs, double *sse);
+/* the same with per-call options (NULL: none) */
+int rr_cemaneigehystgr4jice_simulate_opt(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double sca_init, double s_init, double r_init, const double *params,
+    int64_t N, double *qsim, double *G, double *eTG, double *s_store,
+    double *r_store, double *sca, double *icemelt, double *snowmelt,
+    const double *qobs, double *sse,
+    const rr_call_options *opt);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@ import ctypes
 import importlib.util
 import os
 import sys
+import threading
 
 import numpy as np
 
@@ -25,6 +26,18 @@ RR_OK = 0
 ERROR_NAMES = {-1: "RR_E_NULL", -2: "RR_E_SIZE", -3: "RR_E_HIP",
                -4: "RR_E_PARAM", -5: "RR_E_NODEVICE", -6: "RR_E_WORKSPACE"}
 
+RR_OPT_UNSET = -2 ** 63
+
+
+class CallOptions(ctypes.Structure):
+    """include/rrhip.h rr_call_options: per-call options of the host-pointer
+    family (rr_<model>_simulate_opt), indexed by RR_OPT_*."""
+    _fields_ = [("struct_bytes", ctypes.c_size_t),
+                ("value", ctypes.c_int64 * 16)]
+
+
+_optp = ctypes.POINTER(CallOptions)
+
 # name -> (restype, argtypes); mirrors include/rrhip.h one to one
 _SIGNATURES = {
     "rr_version": (ctypes.c_int, []),
@@ -35,6 +48,9 @@ _SIGNATURES = {
     "rr_release_cached_memory": (ctypes.c_int, []),
     "rr_debug_set_option": (ctypes.c_int, [ctypes.c_int, _i64]),
     "rr_debug_get_option": (_i64, [ctypes.c_int]),
+    "rr_call_options_init": (None, [_optp]),
+    "rr_call_options_set": (ctypes.c_int, [_optp, ctypes.c_int, _i64]),
+    "rr_thread_options": (ctypes.c_int, [_optp]),
     "rr_column_sums_dev": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp,
                                           _vp]),
     "rr_column_sums_shifted_dev": (ctypes.c_int,
@@ -50,6 +66,8 @@ _SIGNATURES = {
                                            _vp]),
     "rr_abc_simulate": (ctypes.c_int, [_f64p, _i64, _dbl, _f64p, _i64, _f64p,
                                        _f64p, _f64p, _f64p]),
+    "rr_abc_simulate_opt": (ctypes.c_int, ([_f64p, _i64, _dbl, _f64p, _i64, _f64p,
+                                       _f64p, _f64p, _f64p]) + [_optp]),
     "rr_hbvedu_workspace_bytes": (_sz, [_i64, _i64]),
     "rr_hbvedu_simulate_dev": (ctypes.c_int,
                                [_vp] * 5 + [_i64] + [_dbl] * 4 + [_vp, _i64]
@@ -57,6 +75,8 @@ _SIGNATURES = {
     "rr_hbvedu_simulate": (ctypes.c_int,
                            [_f64p, _f64p, _i8p, _f64p, _f64p, _i64]
                            + [_dbl] * 4 + [_f64p, _i64] + [_f64p] * 7),
+    "rr_hbvedu_simulate_opt": (ctypes.c_int, ([_f64p, _f64p, _i8p, _f64p, _f64p, _i64]
+                           + [_dbl] * 4 + [_f64p, _i64] + [_f64p] * 7) + [_optp]),
     "rr_hbvedu_catchments_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "rr_hbvedu_simulate_catchments_dev": (ctypes.c_int,
                                           [_vp] * 5 + [_i64, _i64, _vp, _vp,
@@ -71,6 +91,8 @@ _SIGNATURES = {
     "rr_gr4j_simulate": (ctypes.c_int,
                          [_f64p, _f64p, _i64, _dbl, _dbl, _f64p, _i64]
                          + [_f64p] * 5),
+    "rr_gr4j_simulate_opt": (ctypes.c_int, ([_f64p, _f64p, _i64, _dbl, _dbl, _f64p, _i64]
+                         + [_f64p] * 5) + [_optp]),
     "rr_cemaneige_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "rr_cemaneige_simulate_dev": (ctypes.c_int,
                                   [_vp] * 3 + [_i64, _i64, _dbl, _dbl, _vp,
@@ -79,6 +101,8 @@ _SIGNATURES = {
     "rr_cemaneige_simulate": (ctypes.c_int,
                               [_f64p] * 3 + [_i64, _i64, _dbl, _dbl, _f64p,
                                              _i64] + [_f64p] * 5),
+    "rr_cemaneige_simulate_opt": (ctypes.c_int, ([_f64p] * 3 + [_i64, _i64, _dbl, _dbl, _f64p,
+                                             _i64] + [_f64p] * 5) + [_optp]),
     "rr_cemaneige_layers_workspace_bytes": (_sz, [_i64]),
     "rr_cemaneige_layers_dev": (ctypes.c_int,
                                 [_vp] * 4 + [_i64, _f64p, _i64, _dbl, _f64p]
@@ -92,6 +116,8 @@ _SIGNATURES = {
     "rr_cemaneigegr4j_simulate": (ctypes.c_int,
                                   [_f64p] * 4 + [_i64, _i64] + [_dbl] * 4
                                   + [_f64p, _i64] + [_f64p] * 7),
+    "rr_cemaneigegr4j_simulate_opt": (ctypes.c_int, ([_f64p] * 4 + [_i64, _i64] + [_dbl] * 4
+                                  + [_f64p, _i64] + [_f64p] * 7) + [_optp]),
     "rr_snowgr4j_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "rr_snowgr4j_workspace_bytes_x4": (_sz, [_i64, _i64, _i64, _dbl]),
     "rr_cemaneigehystgr4j_simulate_dev": (
@@ -100,18 +126,24 @@ _SIGNATURES = {
     "rr_cemaneigehystgr4j_simulate": (
         ctypes.c_int, [_f64p] * 4 + [_i64, _i64] + [_dbl] * 5 + [_f64p, _i64]
         + [_f64p] * 8),
+    "rr_cemaneigehystgr4j_simulate_opt": (ctypes.c_int, ([_f64p] * 4 + [_i64, _i64] + [_dbl] * 5 + [_f64p, _i64]
+        + [_f64p] * 8) + [_optp]),
     "rr_cemaneigegr4jice_simulate_dev": (
         ctypes.c_int, [_vp] * 5 + [_i64, _i64] + [_dbl] * 4 + [_vp, _i64]
         + [_vp] * 6 + [_i64, _vp, _vp, _vp, _sz, _vp]),
     "rr_cemaneigegr4jice_simulate": (
         ctypes.c_int, [_f64p] * 5 + [_i64, _i64] + [_dbl] * 4 + [_f64p, _i64]
         + [_f64p] * 8),
+    "rr_cemaneigegr4jice_simulate_opt": (ctypes.c_int, ([_f64p] * 5 + [_i64, _i64] + [_dbl] * 4 + [_f64p, _i64]
+        + [_f64p] * 8) + [_optp]),
     "rr_cemaneigehystgr4jice_simulate_dev": (
         ctypes.c_int, [_vp] * 5 + [_i64, _i64] + [_dbl] * 5 + [_vp, _i64]
         + [_vp] * 8 + [_i64, _vp, _vp, _vp, _sz, _vp]),
     "rr_cemaneigehystgr4jice_simulate": (
         ctypes.c_int, [_f64p] * 5 + [_i64, _i64] + [_dbl] * 5 + [_f64p, _i64]
         + [_f64p] * 10),
+    "rr_cemaneigehystgr4jice_simulate_opt": (ctypes.c_int, ([_f64p] * 5 + [_i64, _i64] + [_dbl] * 5 + [_f64p, _i64]
+        + [_f64p] * 10) + [_optp]),
 }
 
 _lib = None
@@ -195,10 +227,94 @@ OPTIONS = {"hbv_variant": 1, "gr4j_force_lds": 2, "max_block_cols": 3,
            "host_shards": 7, "time_tiles": 8}
 
 
+_tls = threading.local()
+
+
+def _new_options(values):
+    lib = load()
+    opt = CallOptions()
+    lib.rr_call_options_init(ctypes.byref(opt))
+    for name, value in values.items():
+        if value is None:
+            continue
+        check(lib.rr_call_options_set(ctypes.byref(opt), OPTIONS[name],
+                                      int(value)), "rr_call_options_set")
+    return opt
+
+
+class call_options:
+    """``with call_options(host_shards=3): model.simulate(...)`` -- per-call
+    options (include/rrhip.h rr_call_options) for every host-pointer call this
+    THREAD makes inside the block: they travel as the `opt` argument of
+    rr_<model>_simulate_opt, so concurrent callers in other threads are not
+    affected (this is what ``monte_carlo(gpus=...)`` and ``sharding.sweep``
+    use).  Nested blocks merge, the inner one winning."""
+
+    def __init__(self, **values):
+        for name in values:
+            if name not in OPTIONS:
+                raise KeyError("unknown option %r (one of %s)"
+                               % (name, sorted(OPTIONS)))
+        self.values = values
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "stack", None)
+        merged = dict(self.prev[0]) if self.prev else {}
+        merged.update(self.values)
+        _tls.stack = (merged, _new_options(merged))
+        return self
+
+    def __exit__(self, *exc):
+        _tls.stack = self.prev
+        return False
+
+
+def host_shards_of(gpus):
+    """The RR_OPT_HOST_SHARDS value of a ``gpus=`` argument: None -> unset
+    (the current device), 'all' -> -1 (one shard per visible device), a
+    positive int -> that many shards."""
+    if gpus is None:
+        return None
+    if isinstance(gpus, str):
+        if gpus == "all":
+            return -1
+        raise ValueError("gpus must be a positive int, 'all' or None")
+    if isinstance(gpus, bool) or int(gpus) != gpus or int(gpus) < 1:
+        raise ValueError("gpus must be a positive int, 'all' or None")
+    return int(gpus)
+
+
+def opts_ptr():
+    """The `opt` argument of a host-pointer call made by this thread now:
+    the innermost call_options block's struct, or NULL."""
+    stack = getattr(_tls, "stack", None)
+    return ctypes.byref(stack[1]) if stack else None
+
+
+class thread_options:
+    """``with thread_options(hbv_variant=0): ens.run(...)`` -- standing
+    options of the calling thread (rr_thread_options) for the *_simulate_dev
+    family, which has no per-call argument; cleared on exit."""
+
+    def __init__(self, **values):
+        self.values = values
+
+    def __enter__(self):
+        opt = _new_options(self.values)
+        check(load().rr_thread_options(ctypes.byref(opt)),
+              "rr_thread_options")
+        return self
+
+    def __exit__(self, *exc):
+        check(load().rr_thread_options(None), "rr_thread_options")
+        return False
+
+
 class debug_option:
-    """``with debug_option("hbv_variant", 0): ...`` pins a measurement / test
-    option of the library (rr_debug_set_option) and restores the previous
-    value afterwards."""
+    """``with debug_option("hbv_variant", 0): ...`` pins a PROCESS-WIDE
+    measurement / test option of the library (rr_debug_set_option) and
+    restores the previous value afterwards.  Tests and A/B timing only -- not
+    thread safe by nature; product code passes call_options instead."""
 
     def __init__(self, name, value):
         self.opt, self.value = OPTIONS[name], int(value)

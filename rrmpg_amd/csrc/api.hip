@@ -35,31 +35,116 @@ void rr_set_error(const char *fmt, ...)
 extern "C" const char *rr_last_error(void) { return g_err; }
 extern "C" int rr_version(void) { return 100; }
 
-// ---- measurement / test options (rrhip.h RR_OPT_*) ---------------------------
+// ---- options (rrhip.h RR_OPT_*) -----------------------------------------------
+// Three layers, consulted in this order by rr_option():
+//   1. the rr_call_options of the host-pointer call in progress on this thread
+//      (rr_<model>_simulate_opt; inherited by the call's shard threads),
+//   2. the calling thread's standing options (rr_thread_options: the way a
+//      caller of the *_simulate_dev family pins a kernel variant),
+//   3. the process-wide measurement / test values (rr_debug_set_option).
+// Layers 1 and 2 are thread local: concurrent callers never see each other's
+// choices.
 static std::atomic<int64_t> g_options[RR_OPT_COUNT_] = {
     {0}, {-1} /* HBV variant: heuristic */, {0}, {0}, {0}, {0}, {0}, {0},
     {-1} /* HBV tiles: by sweep size */};
+static thread_local const rr_call_options *tl_call = nullptr;
+static thread_local rr_call_options tl_standing;
+static thread_local bool tl_standing_on = false;
 
 int64_t rr_option(int option)
 {
+    if (tl_call && tl_call->value[option] != RR_OPT_UNSET)
+        return tl_call->value[option];
+    if (tl_standing_on && tl_standing.value[option] != RR_OPT_UNSET)
+        return tl_standing.value[option];
     return g_options[option].load(std::memory_order_relaxed);
+}
+
+static bool option_value_ok(int option, int64_t value)
+{
+    switch (option) {
+    case RR_OPT_HBV_VARIANT: return value >= -1 && value <= 3;
+    case RR_OPT_GR4J_FORCE_LDS: return value == 0 || value == 1;
+    case RR_OPT_FUSED_VARIANT: return value >= 0 && value <= 4;
+    case RR_OPT_GR4J_VARIANT: return value >= 0 && value <= 4;
+    case RR_OPT_MAX_BLOCK_COLS: return value >= 0;
+    case RR_OPT_GATHER_THREADS: return value >= 0 && value <= 256;
+    case RR_OPT_HOST_SHARDS: return value >= -1 && value <= 1024;
+    case RR_OPT_TIME_TILES: return value >= -1 && value <= 64 && value != 1;
+    default: return false;
+    }
+}
+
+static int check_call_options(const char *who, const rr_call_options *opt)
+{
+    if (!opt) return RR_OK;
+    if (opt->struct_bytes != sizeof(rr_call_options)) {
+        rr_set_error("%s: rr_call_options.struct_bytes is %zu, this library's "
+                     "struct has %zu (rr_call_options_init sets it)", who,
+                     (size_t)opt->struct_bytes, sizeof(rr_call_options));
+        return RR_E_PARAM;
+    }
+    for (int o = 1; o < RR_OPT_COUNT_; ++o)
+        if (opt->value[o] != RR_OPT_UNSET && !option_value_ok(o, opt->value[o])) {
+            rr_set_error("%s: option %d does not take %lld", who, o,
+                         (long long)opt->value[o]);
+            return RR_E_PARAM;
+        }
+    return RR_OK;
+}
+
+// The options of one host-pointer call, for its duration on this thread (and,
+// through host_fan_out, on the call's shard threads).
+struct CallOptionsScope {
+    const rr_call_options *prev;
+    explicit CallOptionsScope(const rr_call_options *opt) : prev(tl_call)
+    {
+        if (opt) tl_call = opt;
+    }
+    ~CallOptionsScope() { tl_call = prev; }
+};
+
+extern "C" void rr_call_options_init(rr_call_options *opt)
+{
+    if (!opt) return;
+    opt->struct_bytes = sizeof(rr_call_options);
+    for (int64_t &v : opt->value) v = RR_OPT_UNSET;
+}
+
+extern "C" int rr_call_options_set(rr_call_options *opt, int option,
+                                   int64_t value)
+{
+    if (!opt || opt->struct_bytes != sizeof(rr_call_options)) {
+        rr_set_error("rr_call_options_set: options not initialised "
+                     "(rr_call_options_init)");
+        return RR_E_PARAM;
+    }
+    if (option < 1 || option >= RR_OPT_COUNT_ ||
+        (value != RR_OPT_UNSET && !option_value_ok(option, value))) {
+        rr_set_error("rr_call_options_set: option %d does not take %lld",
+                     option, (long long)value);
+        return RR_E_PARAM;
+    }
+    opt->value[option] = value;
+    return RR_OK;
+}
+
+extern "C" int rr_thread_options(const rr_call_options *opt)
+{
+    if (!opt) {
+        tl_standing_on = false;
+        return RR_OK;
+    }
+    const int rc = check_call_options("rr_thread_options", opt);
+    if (rc != RR_OK) return rc;
+    tl_standing = *opt;
+    tl_standing_on = true;
+    return RR_OK;
 }
 
 extern "C" int rr_debug_set_option(int option, int64_t value)
 {
-    bool ok = false;
-    switch (option) {
-    case RR_OPT_HBV_VARIANT: ok = value >= -1 && value <= 2; break;
-    case RR_OPT_GR4J_FORCE_LDS: ok = value == 0 || value == 1; break;
-    case RR_OPT_FUSED_VARIANT: ok = value >= 0 && value <= 4; break;
-    case RR_OPT_GR4J_VARIANT: ok = value >= 0 && value <= 4; break;
-    case RR_OPT_MAX_BLOCK_COLS: ok = value >= 0; break;
-    case RR_OPT_GATHER_THREADS: ok = value >= 0 && value <= 256; break;
-    case RR_OPT_HOST_SHARDS: ok = value >= -1 && value <= 1024; break;
-    case RR_OPT_TIME_TILES: ok = value >= -1 && value <= 64 && value != 1; break;
-    default: break;
-    }
-    if (!ok) {
+    if (!option_value_ok(option, value)) {
         rr_set_error("rr_debug_set_option: option %d does not take %lld",
                      option, (long long)value);
         return RR_E_PARAM;
@@ -71,7 +156,7 @@ extern "C" int rr_debug_set_option(int option, int64_t value)
 extern "C" int64_t rr_debug_get_option(int option)
 {
     if (option < 1 || option >= RR_OPT_COUNT_) return INT64_MIN;
-    return rr_option(option);
+    return g_options[option].load(std::memory_order_relaxed);
 }
 
 extern "C" int rr_device_count(void)
@@ -328,15 +413,25 @@ struct OutSpec {
 // block k+1 is computed while block k crosses PCIe) within half of the free
 // device memory; large results are cut into at least 8 blocks so that page
 // faulting, DMA and compute overlap.
-int64_t pick_block(int64_t T, int64_t N, const std::vector<OutSpec> &outs)
+template <class WsBytes>
+int64_t pick_block(int64_t T, int64_t N, const std::vector<OutSpec> &outs,
+                   WsBytes ws_bytes)
 {
     size_t per_col = 0;
     for (const OutSpec &o : outs)
         if (o.host) per_col += (size_t)T * (size_t)o.rows_per_t * 8;
-    if (per_col == 0) return N;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
     const size_t budget = free_b / 2;
+    // the workspace grows with the block too (the GR4J family's
+    // unit-hydrograph scratch: nc * (6 ceil(x4) + 2) * 8 B per slab): a block
+    // has to fit with both of its workspaces
+    auto shrink_to_budget = [&](int64_t nc) {
+        while (nc > 64 && 2 * (ws_bytes(nc) + per_col * (size_t)nc) > budget)
+            nc = (nc / 2 + 63) / 64 * 64;
+        return nc;
+    };
+    if (per_col == 0) return shrink_to_budget(N);
     int64_t nc = (int64_t)(budget / (2 * per_col));
     if ((size_t)N * per_col > ((size_t)1 << 30)) {
         const int64_t eighth = rr_ceil_div(N, 8);
@@ -350,7 +445,8 @@ int64_t pick_block(int64_t T, int64_t N, const std::vector<OutSpec> &outs)
     // test hook: force a small column block to exercise the pitched gather
     const int64_t cap = rr_option(RR_OPT_MAX_BLOCK_COLS);
     if (cap > 0 && cap < nc) nc = cap;
-    return nc < N ? nc : N;
+    if (nc > N) nc = N;
+    return shrink_to_budget(nc);
 }
 
 // ---- large results: pinned staging ring + host copy threads -----------------
@@ -510,13 +606,16 @@ struct Gatherer {
 // rr_gr4j_plan_status is made for every block.
 // ldh: row pitch (in doubles) of the caller's arrays -- N, or more when this
 // sweep fills a column block of a wider array (host_fan_out below).
-template <class Launch>
+// ws_bytes_of(nc): workspace a block of nc columns needs; the launch gets the
+// size of the workspace it is handed.
+template <class WsBytes, class Launch>
 int sweep_blocks_run(HostCall &call, int64_t T, int64_t N, int64_t ldh,
                      const std::vector<OutSpec> &outs, double *sse_host,
-                     size_t ws_bytes, bool gr4j_family, Launch launch)
+                     WsBytes ws_bytes_of, bool gr4j_family, Launch launch)
 {
     HostCtx &c = *call.c;
-    const int64_t nc_max = pick_block(T, N, outs);
+    const int64_t nc_max = pick_block(T, N, outs, ws_bytes_of);
+    const size_t ws_bytes = ws_bytes_of(nc_max);
     const int64_t nb = rr_ceil_div(N, nc_max);
     const int nslab = nb > 1 ? 2 : 1;
     size_t out_bytes = 0;
@@ -549,7 +648,7 @@ int sweep_blocks_run(HostCall &call, int64_t T, int64_t N, int64_t ldh,
             RR_HIP(hipStreamWaitEvent(c.compute, c.copied2[b], 0));
         }
         int rc = launch(i0, nc, ptrs[b], sse_host ? c.sse[b].as<double>() : nullptr,
-                        c.ws[b].p, (void *)c.compute);
+                        c.ws[b].p, ws_bytes, (void *)c.compute);
         if (rc != RR_OK) return rc;
         RR_HIP(hipEventRecord(c.done[b], c.compute));
         return RR_OK;
@@ -611,13 +710,13 @@ int sweep_blocks_run(HostCall &call, int64_t T, int64_t N, int64_t ldh,
     return RR_OK;
 }
 
-template <class Launch>
+template <class WsBytes, class Launch>
 int sweep_blocks(HostCall &call, int64_t T, int64_t N, int64_t ldh,
                  const std::vector<OutSpec> &outs, double *sse_host,
-                 size_t ws_bytes, bool gr4j_family, Launch launch)
+                 WsBytes ws_bytes_of, bool gr4j_family, Launch launch)
 {
-    const int rc = sweep_blocks_run(call, T, N, ldh, outs, sse_host, ws_bytes,
-                                    gr4j_family, launch);
+    const int rc = sweep_blocks_run(call, T, N, ldh, outs, sse_host,
+                                    ws_bytes_of, gr4j_family, launch);
     if (rc != RR_OK) {
         // an early exit may leave kernels and copies in flight that still
         // use the slabs and the pinned bounce buffer the next call reuses:
@@ -686,10 +785,17 @@ int host_fan_out(int64_t N, Body body)
     std::vector<std::string> msgs((size_t)shards);
     std::vector<std::thread> th;
     const int64_t base = N / shards, extra = N % shards;
+    // (the shard threads see the options the calling thread sees)
+    const rr_call_options *const call_opt = tl_call;
+    const bool standing_on = tl_standing_on;
+    const rr_call_options standing = tl_standing;
     for (int64_t j = 0; j < shards; ++j) {
         const int64_t first = j * base + (j < extra ? j : extra);
         const int64_t n = base + (j < extra ? 1 : 0);
         th.emplace_back([&, j, first, n]() {
+            tl_call = call_opt;
+            tl_standing = standing;
+            tl_standing_on = standing_on;
             if (hipSetDevice((cur + (int)j) % ndev) != hipSuccess) {
                 (void)hipGetLastError();
                 rcs[(size_t)j] = RR_E_HIP;
@@ -736,11 +842,18 @@ extern "C" int rr_release_cached_memory(void)
     return RR_OK;
 }
 
-extern "C" int rr_abc_simulate(const double *prec, int64_t T,
+extern "C" int rr_abc_simulate_opt(const double *prec, int64_t T,
                                double initial_state, const double *params,
                                int64_t N, double *qsim, double *storage,
-                               const double *qobs, double *sse)
+                               const double *qobs, double *sse,
+    const rr_call_options *opt)
 {
+    {
+        const int orc = check_call_options("rr_abc_simulate_opt", opt);
+        if (orc != RR_OK) return orc;
+    }
+    const CallOptionsScope options_scope(opt);
+
     int rc = rr_check_common("rr_abc_simulate", T, N, N, params, qobs, sse);
     if (rc != RR_OK) return rc;
     if (T == 0 || N == 0) return RR_OK;
@@ -755,26 +868,41 @@ extern "C" int rr_abc_simulate(const double *prec, int64_t T,
         if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
             return rc;
         if ((rc = call.params(params + first * 3, (size_t)n * 3 * 8, &d_par)) != RR_OK) return rc;
-        const size_t wsb = rr_abc_workspace_bytes(T, n);
+        auto wsb = [&](int64_t nc) { return rr_abc_workspace_bytes(T, nc); };
         std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(storage, first), 1}};
         return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, false,
             [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-                void *st) {
+                size_t ws_size, void *st) {
                 return rr_abc_simulate_dev(
                     (const double *)d_prec, T, initial_state, d_par + i0 * 3, nc,
                     o[0], o[1], nc, qobs ? (const double *)d_qobs : nullptr,
-                    qobs ? d_sse : nullptr, ws, wsb, st);
+                    qobs ? d_sse : nullptr, ws, ws_size, st);
             });
     });
 }
 
-extern "C" int rr_hbvedu_simulate(
+extern "C" int rr_abc_simulate(const double *prec, int64_t T,
+                               double initial_state, const double *params,
+                               int64_t N, double *qsim, double *storage,
+                               const double *qobs, double *sse)
+{
+    return rr_abc_simulate_opt(prec, T, initial_state, params, N, qsim, storage, qobs, sse, nullptr);
+}
+
+extern "C" int rr_hbvedu_simulate_opt(
     const double *temp, const double *prec, const int8_t *month,
     const double *PE_m, const double *T_m, int64_t T, double snow_init,
     double soil_init, double s1_init, double s2_init, const double *params,
     int64_t N, double *qsim, double *snow, double *soil, double *s1,
-    double *s2, const double *qobs, double *sse)
+    double *s2, const double *qobs, double *sse,
+    const rr_call_options *opt)
 {
+    {
+        const int orc = check_call_options("rr_hbvedu_simulate_opt", opt);
+        if (orc != RR_OK) return orc;
+    }
+    const CallOptionsScope options_scope(opt);
+
     int rc = rr_check_common("rr_hbvedu_simulate", T, N, N, params, qobs, sse);
     if (rc != RR_OK) return rc;
     if (T == 0 || N == 0) return RR_OK;
@@ -797,29 +925,46 @@ extern "C" int rr_hbvedu_simulate(
             return rc;
         if ((rc = call.params(params + first * 11, (size_t)n * 11 * 8, &d_par)) != RR_OK)
             return rc;
-        const size_t wsb = rr_hbvedu_workspace_bytes(T, n);
+        auto wsb = [&](int64_t nc) { return rr_hbvedu_workspace_bytes(T, nc); };
         std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(snow, first), 1}, {rr_col(soil, first), 1}, {rr_col(s1, first), 1},
                                      {rr_col(s2, first), 1}};
         return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, false,
             [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-                void *st) {
+                size_t ws_size, void *st) {
                 return rr_hbvedu_simulate_dev(
                     (const double *)d_temp, (const double *)d_prec,
                     (const int8_t *)d_month, (const double *)d_pe,
                     (const double *)d_tm, T, snow_init, soil_init, s1_init,
                     s2_init, d_par + i0 * 11, nc, o[0], o[1], o[2], o[3], o[4],
                     nc, qobs ? (const double *)d_qobs : nullptr,
-                    qobs ? d_sse : nullptr, ws, wsb, st);
+                    qobs ? d_sse : nullptr, ws, ws_size, st);
             });
     });
 }
 
-extern "C" int rr_gr4j_simulate(const double *prec, const double *etp,
+extern "C" int rr_hbvedu_simulate(
+    const double *temp, const double *prec, const int8_t *month,
+    const double *PE_m, const double *T_m, int64_t T, double snow_init,
+    double soil_init, double s1_init, double s2_init, const double *params,
+    int64_t N, double *qsim, double *snow, double *soil, double *s1,
+    double *s2, const double *qobs, double *sse)
+{
+    return rr_hbvedu_simulate_opt(temp, prec, month, PE_m, T_m, T, snow_init, soil_init, s1_init, s2_init, params, N, qsim, snow, soil, s1, s2, qobs, sse, nullptr);
+}
+
+extern "C" int rr_gr4j_simulate_opt(const double *prec, const double *etp,
                                 int64_t T, double s_init, double r_init,
                                 const double *params, int64_t N, double *qsim,
                                 double *s_store, double *r_store,
-                                const double *qobs, double *sse)
+                                const double *qobs, double *sse,
+    const rr_call_options *opt)
 {
+    {
+        const int orc = check_call_options("rr_gr4j_simulate_opt", opt);
+        if (orc != RR_OK) return orc;
+    }
+    const CallOptionsScope options_scope(opt);
+
     int rc = rr_check_common("rr_gr4j_simulate", T, N, N, params, qobs, sse);
     if (rc != RR_OK) return rc;
     if (T == 0 || N == 0) return RR_OK;
@@ -841,26 +986,44 @@ extern "C" int rr_gr4j_simulate(const double *prec, const double *etp,
         const double max_x4 = host_max_x4(params + first * 4, n, 4, 3);
         if ((rc = check_host_x4("rr_gr4j_simulate", max_x4)) != RR_OK)
             return rc;
-        const size_t wsb = rr_gr4j_workspace_bytes_x4(T, n, max_x4);
+        auto wsb = [&](int64_t nc) {
+            return rr_gr4j_workspace_bytes_x4(T, nc, max_x4);
+        };
         std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(s_store, first), 1}, {rr_col(r_store, first), 1}};
         return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, true,
             [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-                void *st) {
+                size_t ws_size, void *st) {
                 return rr_gr4j_simulate_dev(
                     (const double *)d_prec, (const double *)d_etp, T, s_init,
                     r_init, d_par + i0 * 4, nc, o[0], o[1], o[2], nc,
                     qobs ? (const double *)d_qobs : nullptr,
-                    qobs ? d_sse : nullptr, ws, wsb, st);
+                    qobs ? d_sse : nullptr, ws, ws_size, st);
             });
     });
 }
 
-extern "C" int rr_cemaneige_simulate(
+extern "C" int rr_gr4j_simulate(const double *prec, const double *etp,
+                                int64_t T, double s_init, double r_init,
+                                const double *params, int64_t N, double *qsim,
+                                double *s_store, double *r_store,
+                                const double *qobs, double *sse)
+{
+    return rr_gr4j_simulate_opt(prec, etp, T, s_init, r_init, params, N, qsim, s_store, r_store, qobs, sse, nullptr);
+}
+
+extern "C" int rr_cemaneige_simulate_opt(
     const double *prec, const double *mean_temp, const double *frac_solid_prec,
     int64_t T, int64_t L, double snow_pack_init, double thermal_state_init,
     const double *params, int64_t N, double *outflow, double *G, double *eTG,
-    const double *qobs, double *sse)
+    const double *qobs, double *sse,
+    const rr_call_options *opt)
 {
+    {
+        const int orc = check_call_options("rr_cemaneige_simulate_opt", opt);
+        if (orc != RR_OK) return orc;
+    }
+    const CallOptionsScope options_scope(opt);
+
     int rc = rr_check_common("rr_cemaneige_simulate", T, N, N, params, qobs,
                              sse);
     if (rc != RR_OK) return rc;
@@ -883,29 +1046,47 @@ extern "C" int rr_cemaneige_simulate(
         if ((rc = call.input(qobs, qobs ? (size_t)T * 8 : 0, &d_qobs)) != RR_OK)
             return rc;
         if ((rc = call.params(params + first * 2, (size_t)n * 2 * 8, &d_par)) != RR_OK) return rc;
-        const size_t wsb = rr_cemaneige_workspace_bytes(T, L, n);
+        auto wsb = [&](int64_t nc) {
+            return rr_cemaneige_workspace_bytes(T, L, nc);
+        };
         std::vector<OutSpec> outs = {{rr_col(outflow, first), 1}, {rr_col(G, first), L}, {rr_col(eTG, first), L}};
         return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, false,
             [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-                void *st) {
+                size_t ws_size, void *st) {
                 return rr_cemaneige_simulate_dev(
                     (const double *)d_prec, (const double *)d_temp,
                     (const double *)d_frac, T, L, snow_pack_init,
                     thermal_state_init, d_par + i0 * 2, nc, o[0], o[1], o[2], nc,
                     qobs ? (const double *)d_qobs : nullptr,
-                    qobs ? d_sse : nullptr, ws, wsb, st);
+                    qobs ? d_sse : nullptr, ws, ws_size, st);
             });
     });
 }
 
-extern "C" int rr_cemaneigegr4j_simulate(
+extern "C" int rr_cemaneige_simulate(
+    const double *prec, const double *mean_temp, const double *frac_solid_prec,
+    int64_t T, int64_t L, double snow_pack_init, double thermal_state_init,
+    const double *params, int64_t N, double *outflow, double *G, double *eTG,
+    const double *qobs, double *sse)
+{
+    return rr_cemaneige_simulate_opt(prec, mean_temp, frac_solid_prec, T, L, snow_pack_init, thermal_state_init, params, N, outflow, G, eTG, qobs, sse, nullptr);
+}
+
+extern "C" int rr_cemaneigegr4j_simulate_opt(
     const double *prec, const double *mean_temp, const double *etp,
     const double *frac_solid_prec, int64_t T, int64_t L,
     double snow_pack_init, double thermal_state_init, double s_init,
     double r_init, const double *params, int64_t N, double *qsim, double *G,
     double *eTG, double *s_store, double *r_store, const double *qobs,
-    double *sse)
+    double *sse,
+    const rr_call_options *opt)
 {
+    {
+        const int orc = check_call_options("rr_cemaneigegr4j_simulate_opt", opt);
+        if (orc != RR_OK) return orc;
+    }
+    const CallOptionsScope options_scope(opt);
+
     int rc = rr_check_common("rr_cemaneigegr4j_simulate", T, N, N, params,
                              qobs, sse);
     if (rc != RR_OK) return rc;
@@ -932,21 +1113,34 @@ extern "C" int rr_cemaneigegr4j_simulate(
         const double max_x4 = host_max_x4(params + first * 6, n, 6, 5);
         if ((rc = check_host_x4("rr_cemaneigegr4j_simulate", max_x4)) != RR_OK)
             return rc;
-        const size_t wsb = rr_cemaneigegr4j_workspace_bytes_x4(T, L, n, max_x4);
+        auto wsb = [&](int64_t nc) {
+            return rr_cemaneigegr4j_workspace_bytes_x4(T, L, nc, max_x4);
+        };
         std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(G, first), L}, {rr_col(eTG, first), L}, {rr_col(s_store, first), 1},
                                      {rr_col(r_store, first), 1}};
         return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, true,
             [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-                void *st) {
+                size_t ws_size, void *st) {
                 return rr_cemaneigegr4j_simulate_dev(
                     (const double *)d_prec, (const double *)d_temp,
                     (const double *)d_etp, (const double *)d_frac, T, L,
                     snow_pack_init, thermal_state_init, s_init, r_init,
                     d_par + i0 * 6, nc, o[0], o[1], o[2], o[3], o[4], nc,
                     qobs ? (const double *)d_qobs : nullptr,
-                    qobs ? d_sse : nullptr, ws, wsb, st);
+                    qobs ? d_sse : nullptr, ws, ws_size, st);
             });
     });
+}
+
+extern "C" int rr_cemaneigegr4j_simulate(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_solid_prec, int64_t T, int64_t L,
+    double snow_pack_init, double thermal_state_init, double s_init,
+    double r_init, const double *params, int64_t N, double *qsim, double *G,
+    double *eTG, double *s_store, double *r_store, const double *qobs,
+    double *sse)
+{
+    return rr_cemaneigegr4j_simulate_opt(prec, mean_temp, etp, frac_solid_prec, T, L, snow_pack_init, thermal_state_init, s_init, r_init, params, N, qsim, G, eTG, s_store, r_store, qobs, sse, nullptr);
 }
 
 // ---- device self-test hook (not part of include/rrhip.h) -------------------
@@ -1010,8 +1204,14 @@ int snow_gr4j_host(const char *who, int variant, const double *prec,
                    double r_init, const double *params, int64_t N,
                    double *qsim, double *G, double *eTG, double *s_store,
                    double *r_store, double *sca, double *icemelt,
-                   double *snowmelt, const double *qobs, double *sse)
+                   double *snowmelt, const double *qobs, double *sse,
+                   const rr_call_options *opt)
 {
+    {
+        const int orc = check_call_options(who, opt);
+        if (orc != RR_OK) return orc;
+    }
+    const CallOptionsScope options_scope(opt);
     const bool hyst = variant & HYST, ice = variant & ICE;
     const int npar = 6 + (hyst ? 2 : 0) + (ice ? 1 : 0);
     int rc = rr_check_common(who, T, N, N, params, qobs, sse);
@@ -1043,13 +1243,15 @@ int snow_gr4j_host(const char *who, int variant, const double *prec,
         const double max_x4 = host_max_x4(params + first * npar, n, npar,
                                           (hyst ? 4 : 2) + 3);
         if ((rc = check_host_x4(who, max_x4)) != RR_OK) return rc;
-        const size_t wsb = rr_snowgr4j_workspace_bytes_x4(T, L, n, max_x4);
+        auto wsb = [&](int64_t nc) {
+            return rr_snowgr4j_workspace_bytes_x4(T, L, nc, max_x4);
+        };
         std::vector<OutSpec> outs = {{rr_col(qsim, first), 1}, {rr_col(G, first), L}, {rr_col(eTG, first), L}, {rr_col(s_store, first), 1},
                                      {rr_col(r_store, first), 1}, {rr_col(sca, first), L}, {rr_col(icemelt, first), 1},
                                      {rr_col(snowmelt, first), 1}};
         return sweep_blocks(call, T, n, N, outs, rr_col(sse, first), wsb, true,
             [&](int64_t i0, int64_t nc, double **o, double *d_sse, void *ws,
-                void *st) {
+                size_t ws_size, void *st) {
                 const double *p = d_par + i0 * npar;
                 const double *qo = qobs ? (const double *)d_qobs : nullptr;
                 double *so = qobs ? d_sse : nullptr;
@@ -1063,21 +1265,38 @@ int snow_gr4j_host(const char *who, int variant, const double *prec,
                         pr, tm, et, fi, fr, T, L, snow_pack_init,
                         thermal_state_init, sca_init, s_init, r_init, p, nc, o[0],
                         o[1], o[2], o[3], o[4], o[5], o[6], o[7], nc, qo, so, ws,
-                        wsb, st);
+                        ws_size, st);
                 if (hyst)
                     return rr_cemaneigehystgr4j_simulate_dev(
                         pr, tm, et, fr, T, L, snow_pack_init, thermal_state_init,
                         sca_init, s_init, r_init, p, nc, o[0], o[1], o[2], o[3],
-                        o[4], o[5], nc, qo, so, ws, wsb, st);
+                        o[4], o[5], nc, qo, so, ws, ws_size, st);
                 return rr_cemaneigegr4jice_simulate_dev(
                     pr, tm, et, fi, fr, T, L, snow_pack_init, thermal_state_init,
                     s_init, r_init, p, nc, o[0], o[1], o[2], o[3], o[4], o[6], nc,
-                    qo, so, ws, wsb, st);
+                    qo, so, ws, ws_size, st);
             });
     });
 }
 
 }  // namespace
+
+extern "C" int rr_cemaneigehystgr4j_simulate_opt(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_solid_prec, int64_t T, int64_t L,
+    double snow_pack_init, double thermal_state_init, double sca_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *sca, const double *qobs, double *sse,
+    const rr_call_options *opt)
+{
+
+    return snow_gr4j_host("rr_cemaneigehystgr4j_simulate", HYST, prec,
+                          mean_temp, etp, nullptr, frac_solid_prec, T, L,
+                          snow_pack_init, thermal_state_init, sca_init, s_init,
+                          r_init, params, N, qsim, G, eTG, s_store, r_store,
+                          sca, nullptr, nullptr, qobs, sse, opt);
+}
 
 extern "C" int rr_cemaneigehystgr4j_simulate(
     const double *prec, const double *mean_temp, const double *etp,
@@ -1087,11 +1306,24 @@ extern "C" int rr_cemaneigehystgr4j_simulate(
     double *qsim, double *G, double *eTG, double *s_store, double *r_store,
     double *sca, const double *qobs, double *sse)
 {
-    return snow_gr4j_host("rr_cemaneigehystgr4j_simulate", HYST, prec,
-                          mean_temp, etp, nullptr, frac_solid_prec, T, L,
-                          snow_pack_init, thermal_state_init, sca_init, s_init,
-                          r_init, params, N, qsim, G, eTG, s_store, r_store,
-                          sca, nullptr, nullptr, qobs, sse);
+    return rr_cemaneigehystgr4j_simulate_opt(prec, mean_temp, etp, frac_solid_prec, T, L, snow_pack_init, thermal_state_init, sca_init, s_init, r_init, params, N, qsim, G, eTG, s_store, r_store, sca, qobs, sse, nullptr);
+}
+
+extern "C" int rr_cemaneigegr4jice_simulate_opt(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *params, int64_t N,
+    double *qsim, double *G, double *eTG, double *s_store, double *r_store,
+    double *icemelt, const double *qobs, double *sse,
+    const rr_call_options *opt)
+{
+
+    return snow_gr4j_host("rr_cemaneigegr4jice_simulate", ICE, prec, mean_temp,
+                          etp, frac_ice, frac_solid_prec, T, L, snow_pack_init,
+                          thermal_state_init, 0.0, s_init, r_init, params, N,
+                          qsim, G, eTG, s_store, r_store, nullptr, icemelt,
+                          nullptr, qobs, sse, opt);
 }
 
 extern "C" int rr_cemaneigegr4jice_simulate(
@@ -1102,11 +1334,25 @@ extern "C" int rr_cemaneigegr4jice_simulate(
     double *qsim, double *G, double *eTG, double *s_store, double *r_store,
     double *icemelt, const double *qobs, double *sse)
 {
-    return snow_gr4j_host("rr_cemaneigegr4jice_simulate", ICE, prec, mean_temp,
-                          etp, frac_ice, frac_solid_prec, T, L, snow_pack_init,
-                          thermal_state_init, 0.0, s_init, r_init, params, N,
-                          qsim, G, eTG, s_store, r_store, nullptr, icemelt,
-                          nullptr, qobs, sse);
+    return rr_cemaneigegr4jice_simulate_opt(prec, mean_temp, etp, frac_ice, frac_solid_prec, T, L, snow_pack_init, thermal_state_init, s_init, r_init, params, N, qsim, G, eTG, s_store, r_store, icemelt, qobs, sse, nullptr);
+}
+
+extern "C" int rr_cemaneigehystgr4jice_simulate_opt(
+    const double *prec, const double *mean_temp, const double *etp,
+    const double *frac_ice, const double *frac_solid_prec, int64_t T,
+    int64_t L, double snow_pack_init, double thermal_state_init,
+    double sca_init, double s_init, double r_init, const double *params,
+    int64_t N, double *qsim, double *G, double *eTG, double *s_store,
+    double *r_store, double *sca, double *icemelt, double *snowmelt,
+    const double *qobs, double *sse,
+    const rr_call_options *opt)
+{
+
+    return snow_gr4j_host("rr_cemaneigehystgr4jice_simulate", HYST | ICE, prec,
+                          mean_temp, etp, frac_ice, frac_solid_prec, T, L,
+                          snow_pack_init, thermal_state_init, sca_init, s_init,
+                          r_init, params, N, qsim, G, eTG, s_store, r_store,
+                          sca, icemelt, snowmelt, qobs, sse, opt);
 }
 
 extern "C" int rr_cemaneigehystgr4jice_simulate(
@@ -1118,9 +1364,6 @@ extern "C" int rr_cemaneigehystgr4jice_simulate(
     double *r_store, double *sca, double *icemelt, double *snowmelt,
     const double *qobs, double *sse)
 {
-    return snow_gr4j_host("rr_cemaneigehystgr4jice_simulate", HYST | ICE, prec,
-                          mean_temp, etp, frac_ice, frac_solid_prec, T, L,
-                          snow_pack_init, thermal_state_init, sca_init, s_init,
-                          r_init, params, N, qsim, G, eTG, s_store, r_store,
-                          sca, icemelt, snowmelt, qobs, sse);
+    return rr_cemaneigehystgr4jice_simulate_opt(prec, mean_temp, etp, frac_ice, frac_solid_prec, T, L, snow_pack_init, thermal_state_init, sca_init, s_init, r_init, params, N, qsim, G, eTG, s_store, r_store, sca, icemelt, snowmelt, qobs, sse, nullptr);
 }
+

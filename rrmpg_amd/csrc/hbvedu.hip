@@ -367,10 +367,10 @@ hbvedu_kernel(
             // (small sweeps, FORCING == 2: polynomial constants in VGPRs so
             // that the prefetched record fits the SGPR file without spills)
 #if RR_HBV_POW_LITE
-            double pw = fastpow_tab_lite<FORCING == 2>(wetness, beta2_hi,
+            double pw = fastpow_tab_lite<FORCING >= 2>(wetness, beta2_hi,
                                                        powlog, &z);
 #else
-            double pw = fastpow_tab_core<FORCING == 2>(wetness, beta2_hi,
+            double pw = fastpow_tab_core<FORCING >= 2>(wetness, beta2_hi,
                                                        beta2_lo, powlog, &z);
 #endif
             // Inside the box the arguments are in fastpow's domain by
@@ -525,16 +525,69 @@ hbvedu_kernel(
                 day_step(b, t + 1, [&] { fetch(a); }, tame);
             }
             if (t < Ti) day_step(a, t, [] {}, tame);
+        } else if constexpr (FORCING == 3) {
+            // sweeps of at most two waves per SIMD, round 4: a lone wave's
+            // day is a latency chain (a day takes as long with one wave on
+            // the SIMD as with two), and the longest link that nothing covers
+            // is the record's scalar load, requested and waited for in the
+            // same day by the two loops above (FORCING == 2 asks in the
+            // middle of the day before, and hipcc schedules the next day's
+            // first instructions -- the record's first use -- right behind
+            // that).  Here THREE records rotate (loop unrolled by three: no
+            // copies) and the middle of day t requests the record of day
+            // t + 2: by the time it is used a whole day has passed.  Scalar
+            // loads return out of order, so every wait is for all of them:
+            // the `use` of the NEXT day's record right before the request
+            // makes that wait explicit at a point where the record, asked
+            // for a day ago, has long arrived -- and the compiler then knows
+            // it to be there at the top of the next day.  The fetch runs two
+            // records ahead: the workspace holds two spare records.
+            typedef const HbvDay __attribute__((address_space(4))) *cp_t;
+            cp_t pn = (cp_t)(days + t_begin + 2);
+            auto fetch = [&](HbvDay &dst) {
+                asm volatile("" : "+s"(pn));
+                dst.temp = pn->temp; dst.prec = pn->prec;     // one load burst
+                dst.dtemp = pn->dtemp; dst.pe_m = pn->pe_m; dst.qobs = pn->qobs;
+                pn += 1;
+            };
+            auto use = [](const HbvDay &r) {
+                asm volatile("" : : "s"(r.temp), "s"(r.prec), "s"(r.dtemp),
+                             "s"(r.pe_m), "s"(r.qobs));
+            };
+            HbvDay a = days[t_begin], b = days[t_begin + 1], c;
+            use(a);
+            int t = t_begin;
+            for (; t + 2 < t_end; t += 3) {
+                day_step(a, t, [&] { use(b); fetch(c); }, tame);
+                day_step(b, t + 1, [&] { use(c); fetch(a); }, tame);
+                day_step(c, t + 2, [&] { use(a); fetch(b); }, tame);
+            }
+            if (t < t_end) {
+                day_step(a, t, [&] { use(b); }, tame);
+                if (t + 1 < t_end) day_step(b, t + 1, [] {}, tame);
+            }
         } else {
             // (two days per trip, written out -- the votes are convergent
             // operations, which keeps hipcc from unrolling a loop with a
             // remainder on its own: one taken branch per two days)
             int t = t_begin;
             for (; t + 1 < t_end; t += 2) {
+#ifdef HBV_EXP_CONST_RECORD
+                // timing experiment only (wrong results): every day reads
+                // the same two records -- no scalar-cache misses
+                int tt = 1;
+                asm volatile("" : "+s"(tt));
+                const HbvDay f0 = days[tt];
+                day_step(f0, t, [] {}, tame);
+                asm volatile("" : "+s"(tt));
+                const HbvDay f1 = days[tt + 1];
+                day_step(f1, t + 1, [] {}, tame);
+#else
                 const HbvDay f0 = days[t];     // wave-uniform -> s_load_dwordx8
                 day_step(f0, t, [] {}, tame);
                 const HbvDay f1 = days[t + 1];
                 day_step(f1, t + 1, [] {}, tame);
+#endif
             }
             if (t < t_end) {
                 const HbvDay f = days[t];
@@ -586,13 +639,13 @@ hbvedu_kernel(
   }
 }
 
-// forcing records (+ 1: the spare record the prefetching variant may touch)
+// forcing records (+ 2: the spare records the prefetching variants may touch)
 // and the pre-pass's flags of odd precipitation values (one int per 256 days)
 static size_t hbv_forcing_bytes(int64_t T, int64_t C)
 {
     if (T < 1) T = 1;
     if (C < 1) C = 1;
-    return rr_align256((size_t)(T * C + 1) * sizeof(HbvDay) +
+    return rr_align256((size_t)(T * C + 2) * sizeof(HbvDay) +
                        (size_t)rr_ceil_div(T, 256) * (size_t)C * sizeof(int));
 }
 // the tiled kernel's work queue {counter, flag per job} and its hand-over
@@ -638,7 +691,7 @@ static int hbv_launch(const double *temp, const double *prec,
         return RR_E_SIZE;
     }
     HbvDay *days = (HbvDay *)workspace;
-    int *odd_prec = (int *)(days + (size_t)T * (size_t)C + 1);
+    int *odd_prec = (int *)(days + (size_t)T * (size_t)C + 2);
     hipLaunchKernelGGL(hbv_pack_forcing,
                        dim3((unsigned)rr_ceil_div(T, 256), (unsigned)C),
                        dim3(256), 0, st, temp, prec, month, PE_m, T_m,
@@ -720,6 +773,7 @@ static int hbv_launch(const double *temp, const double *prec,
         // 3.14 / 3.22, 125k 3.76 / 3.70, 250k 7.45 / 7.62, 1M 27.4 / 27.8)
         if (variant == 1) go(std::integral_constant<int, 1>{}, std::false_type{});
         else if (variant == 2) go(std::integral_constant<int, 2>{}, std::true_type{});
+        else if (variant == 3) go(std::integral_constant<int, 3>{}, std::true_type{});
 #if HBV_TWO_PER_SIMD_TAME
         else if (two_per_simd) go(std::integral_constant<int, 0>{}, std::true_type{});
 #else

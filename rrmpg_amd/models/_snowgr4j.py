@@ -85,22 +85,25 @@ def run(hyst, ice, layers, frac_ice, inits, params, want_qsim, want_storages,
     arrays = [prec, mean_temp, etp] + ([frac_ice] if ice else []) + [frac]
     keep, ptrs = _lib.f64s(*arrays)
     if hyst and ice:
-        rc = lib.rr_cemaneigehystgr4jice_simulate(
+        rc = lib.rr_cemaneigehystgr4jice_simulate_opt(
             *ptrs, t, nl, *inits, p_ptr, n, out_ptr(qsim), out_ptr(G),
             out_ptr(eTG), out_ptr(s_store), out_ptr(r_store), out_ptr(sca),
-            out_ptr(icemelt), out_ptr(snowmelt), qobs_ptr, out_ptr(sse))
+            out_ptr(icemelt), out_ptr(snowmelt), qobs_ptr, out_ptr(sse),
+        _lib.opts_ptr())
         what = "rr_cemaneigehystgr4jice_simulate"
     elif hyst:
-        rc = lib.rr_cemaneigehystgr4j_simulate(
+        rc = lib.rr_cemaneigehystgr4j_simulate_opt(
             *ptrs, t, nl, *inits, p_ptr, n, out_ptr(qsim), out_ptr(G),
             out_ptr(eTG), out_ptr(s_store), out_ptr(r_store), out_ptr(sca),
-            qobs_ptr, out_ptr(sse))
+            qobs_ptr, out_ptr(sse),
+        _lib.opts_ptr())
         what = "rr_cemaneigehystgr4j_simulate"
     else:
-        rc = lib.rr_cemaneigegr4jice_simulate(
+        rc = lib.rr_cemaneigegr4jice_simulate_opt(
             *ptrs, t, nl, inits[0], inits[1], inits[3], inits[4], p_ptr, n,
             out_ptr(qsim), out_ptr(G), out_ptr(eTG), out_ptr(s_store),
-            out_ptr(r_store), out_ptr(icemelt), qobs_ptr, out_ptr(sse))
+            out_ptr(r_store), out_ptr(icemelt), qobs_ptr, out_ptr(sse),
+        _lib.opts_ptr())
         what = "rr_cemaneigegr4jice_simulate"
     del keep
     _lib.check(rc, what)

@@ -89,18 +89,19 @@ class ABCModel(BaseModel):
             return qsim, storage
         return qsim
 
-    def fit(self, qobs, prec, initial_state=0, batched=True):
+    def fit(self, qobs, prec, initial_state=0, batched=False):
         """Fit the model to a timeseries of discharge.
 
         Uses scipy's differential evolution, as the reference does
         (abcmodel.py:188-232); every candidate is one GPU call that returns
         only its squared-error sum.
 
-        batched (default True): one GPU sweep per generation -- a DIFFERENT
-        optimiser trajectory than the reference's (a seeded fit ends in other,
-        equally good parameters); batched=False: one candidate per call, the
-        reference's own call, which reproduces its seeded runs evaluation by
-        evaluation (tests/test_gpu_fit_reference.py).
+        batched (extension; default False): False is the reference's own
+        call -- one candidate per loss evaluation, immediate updating --
+        which reproduces its seeded runs evaluation by evaluation
+        (tests/test_gpu_fit_reference.py); True: one GPU sweep per generation
+        -- a DIFFERENT optimiser trajectory than the reference's (a seeded
+        fit ends in other, equally good parameters), a hundred times faster.
 
         Returns:
             res: A scipy OptimizeResult class object.
@@ -141,9 +142,10 @@ def _run(prec, initial_state, params, want_qsim, want_storage, qobs):
     if qobs is not None and qobs_arr.shape[0] != t:
         raise ValueError("Arrays must have the same size.")
     keep, (prec_ptr,) = _lib.f64s(prec)
-    rc = lib.rr_abc_simulate(prec_ptr, t, initial_state, p_ptr, n,
+    rc = lib.rr_abc_simulate_opt(prec_ptr, t, initial_state, p_ptr, n,
                              out_ptr(qsim), out_ptr(storage), qobs_ptr,
-                             out_ptr(sse))
+                             out_ptr(sse),
+        _lib.opts_ptr())
     del keep
     _lib.check(rc, "rr_abc_simulate")
     return qsim, storage, sse

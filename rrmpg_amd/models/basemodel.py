@@ -179,15 +179,15 @@ class BaseModel(object):
     def _differential_evolution(self, loss, args, batched):
         """scipy's differential evolution over the default bounds.
 
-        batched=True (the default of every ``fit``): scipy gets a vectorised
-        loss, so each generation's whole population is ONE GPU sweep
-        (updating='deferred').  A GPU runs a single candidate no faster than
-        numba does (the time loop is serial: ~1 ms for ten years either way),
-        but a population of 165 in the same ~1 ms.
-        batched=False reproduces the reference's call exactly (one candidate
-        per loss evaluation, updating='immediate'; e.g. reference
-        hbvedu.py:305): the same optimiser trajectory as the reference for a
-        seeded run, at the reference's speed.
+        batched=False (the default of every ``fit``) is the reference's call
+        exactly (one candidate per loss evaluation, updating='immediate';
+        e.g. reference hbvedu.py:305): the same optimiser trajectory as the
+        reference for a seeded run, at the reference's speed.
+        batched=True (opt-in): scipy gets a vectorised loss, so each
+        generation's whole population is ONE GPU sweep (updating='deferred').
+        A GPU runs a single candidate no faster than numba does (the time
+        loop is serial: ~1 ms for ten years either way), but a population of
+        165 in the same ~1 ms.
         """
         from scipy import optimize
         bnds = tuple([self._default_bounds[p] for p in self._param_list])

@@ -83,20 +83,20 @@ class Cemaneige(BaseModel):
 
     def fit(self, obs, prec, mean_temp, min_temp, max_temp,
             met_station_height, snow_pack_init=0, thermal_state_init=0,
-            altitudes=[], batched=True):
+            altitudes=[], batched=False):
         """Fit the Cemaneige model to an observed timeseries.
 
         scipy differential evolution over the default bounds, as in the
         reference (cemaneige.py:247-359).
 
-        batched: (extension) True (default): scipy gets a vectorised loss and
-            every generation's population is ONE GPU sweep
+        batched: (extension) False (default): the reference's own call -- one
+            candidate per loss evaluation, immediate updating -- which
+            reproduces the reference's seeded runs evaluation by evaluation
+            (tests/test_gpu_fit_reference.py).  True: scipy gets a vectorised
+            loss and every generation's population is ONE GPU sweep
             (updating='deferred') -- about a hundred times faster, but a
-            DIFFERENT optimiser trajectory than the reference's: a seeded fit
-            ends in other (equally good) parameters.  batched=False is the
-            reference's own call -- one candidate per loss evaluation,
-            immediate updating -- and reproduces its seeded runs evaluation
-            by evaluation (tests/test_gpu_fit_reference.py).
+            DIFFERENT optimiser trajectory than the reference's: a seeded
+            fit ends in other (equally good) parameters.
 
         Returns:
             res: A scipy OptimizeResult class object.
@@ -200,10 +200,11 @@ def _run(layers, inits, params, want_outflow, want_storages, qobs):
         raise ValueError("Arrays must have the same size.")
     sse = np.zeros(n) if qobs is not None else None
     keep, (p_prec, p_temp, p_frac) = _lib.f64s(prec, mean_temp, frac)
-    rc = lib.rr_cemaneige_simulate(p_prec, p_temp, p_frac, t, nl, inits[0],
+    rc = lib.rr_cemaneige_simulate_opt(p_prec, p_temp, p_frac, t, nl, inits[0],
                                    inits[1], p_ptr, n, out_ptr(outflow),
                                    out_ptr(G), out_ptr(eTG), qobs_ptr,
-                                   out_ptr(sse))
+                                   out_ptr(sse),
+        _lib.opts_ptr())
     del keep
     _lib.check(rc, "rr_cemaneige_simulate")
     return [outflow, G, eTG], sse

@@ -82,20 +82,20 @@ class CemaneigeGR4J(BaseModel):
 
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp,
             met_station_height, snow_pack_init=0, thermal_state_init=0,
-            s_init=0, r_init=0, altitudes=[], batched=True):
+            s_init=0, r_init=0, altitudes=[], batched=False):
         """Fit the Cemaneige + GR4J coupled model to an observed timeseries.
 
         scipy differential evolution over the default bounds, as in the
         reference (cemaneigegr4j.py:275-400).
 
-        batched: (extension) True (default): scipy gets a vectorised loss and
-            every generation's population is ONE GPU sweep
+        batched: (extension) False (default): the reference's own call -- one
+            candidate per loss evaluation, immediate updating -- which
+            reproduces the reference's seeded runs evaluation by evaluation
+            (tests/test_gpu_fit_reference.py).  True: scipy gets a vectorised
+            loss and every generation's population is ONE GPU sweep
             (updating='deferred') -- about a hundred times faster, but a
-            DIFFERENT optimiser trajectory than the reference's: a seeded fit
-            ends in other (equally good) parameters.  batched=False is the
-            reference's own call -- one candidate per loss evaluation,
-            immediate updating -- and reproduces its seeded runs evaluation
-            by evaluation (tests/test_gpu_fit_reference.py).
+            DIFFERENT optimiser trajectory than the reference's: a seeded
+            fit ends in other (equally good) parameters.
 
         Returns:
             res: A scipy OptimizeResult class object.
@@ -146,10 +146,11 @@ def _run(layers, inits, params, want_qsim, want_storages, qobs):
     sse = np.zeros(n) if qobs is not None else None
     keep, (p_prec, p_temp, p_etp, p_frac) = _lib.f64s(prec, mean_temp, etp,
                                                       frac)
-    rc = lib.rr_cemaneigegr4j_simulate(
+    rc = lib.rr_cemaneigegr4j_simulate_opt(
         p_prec, p_temp, p_etp, p_frac, t, nl, *inits, p_ptr, n, out_ptr(qsim),
         out_ptr(G), out_ptr(eTG), out_ptr(s_store), out_ptr(r_store),
-        qobs_ptr, out_ptr(sse))
+        qobs_ptr, out_ptr(sse),
+        _lib.opts_ptr())
     del keep
     _lib.check(rc, "rr_cemaneigegr4j_simulate")
     return [qsim, G, eTG, s_store, r_store], sse

@@ -100,19 +100,19 @@ class CemaneigeHystGR4J(BaseModel):
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp,
             met_station_height, loss_metric="mse", snow_pack_init=0,
             thermal_state_init=0, sca_init=0, s_init=0, r_init=0,
-            altitudes=[], batched=True):
+            altitudes=[], batched=False):
         """Fit the model to an observed discharge series (scipy differential
         evolution; loss_metric 'mse' or 'kge'; reference:
         cemaneigehystgr4j.py:292-424).
 
-        batched: (extension) True (default): scipy gets a vectorised loss and
-            every generation's population is ONE GPU sweep
+        batched: (extension) False (default): the reference's own call -- one
+            candidate per loss evaluation, immediate updating -- which
+            reproduces the reference's seeded runs evaluation by evaluation
+            (tests/test_gpu_fit_reference.py).  True: scipy gets a vectorised
+            loss and every generation's population is ONE GPU sweep
             (updating='deferred') -- about a hundred times faster, but a
-            DIFFERENT optimiser trajectory than the reference's: a seeded fit
-            ends in other (equally good) parameters.  batched=False is the
-            reference's own call -- one candidate per loss evaluation,
-            immediate updating -- and reproduces its seeded runs evaluation
-            by evaluation (tests/test_gpu_fit_reference.py).
+            DIFFERENT optimiser trajectory than the reference's: a seeded
+            fit ends in other (equally good) parameters.
 
         Returns:
             res: A SciPy OptimizeResult object.
@@ -130,19 +130,19 @@ class CemaneigeHystGR4J(BaseModel):
                   NDSI2, NDSI3, NDSI4, NDSI5, met_station_height,
                   loss_metric="mse", snow_pack_init=0, thermal_state_init=0,
                   sca_init=0, s_init=0, r_init=0, altitudes=[],
-                  batched=True):
+                  batched=False):
         """Fit to discharge AND the snow-covered area of five elevation bands
         (NDSI1..NDSI5, in percent); 75 % / 5 x 5 % weighting (reference:
         cemaneigehystgr4j.py:427-570).
 
-        batched: (extension) True (default): scipy gets a vectorised loss and
-            every generation's population is ONE GPU sweep
+        batched: (extension) False (default): the reference's own call -- one
+            candidate per loss evaluation, immediate updating -- which
+            reproduces the reference's seeded runs evaluation by evaluation
+            (tests/test_gpu_fit_reference.py).  True: scipy gets a vectorised
+            loss and every generation's population is ONE GPU sweep
             (updating='deferred') -- about a hundred times faster, but a
-            DIFFERENT optimiser trajectory than the reference's: a seeded fit
-            ends in other (equally good) parameters.  batched=False is the
-            reference's own call -- one candidate per loss evaluation,
-            immediate updating -- and reproduces its seeded runs evaluation
-            by evaluation (tests/test_gpu_fit_reference.py).
+            DIFFERENT optimiser trajectory than the reference's: a seeded
+            fit ends in other (equally good) parameters.
 
         Returns:
             res: A SciPy OptimizeResult object.

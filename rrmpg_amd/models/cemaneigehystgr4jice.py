@@ -87,19 +87,19 @@ class CemaneigeHystGR4JIce(BaseModel):
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
             met_station_height, loss_metric="mse", snow_pack_init=0,
             thermal_state_init=0, sca_init=0, s_init=0, r_init=0,
-            altitudes=[], batched=True):
+            altitudes=[], batched=False):
         """Fit the model to an observed discharge series (scipy differential
         evolution; loss_metric 'mse' or 'kge'; reference:
         cemaneigehystgr4jice.py:308-445).
 
-        batched: (extension) True (default): scipy gets a vectorised loss and
-            every generation's population is ONE GPU sweep
+        batched: (extension) False (default): the reference's own call -- one
+            candidate per loss evaluation, immediate updating -- which
+            reproduces the reference's seeded runs evaluation by evaluation
+            (tests/test_gpu_fit_reference.py).  True: scipy gets a vectorised
+            loss and every generation's population is ONE GPU sweep
             (updating='deferred') -- about a hundred times faster, but a
-            DIFFERENT optimiser trajectory than the reference's: a seeded fit
-            ends in other (equally good) parameters.  batched=False is the
-            reference's own call -- one candidate per loss evaluation,
-            immediate updating -- and reproduces its seeded runs evaluation
-            by evaluation (tests/test_gpu_fit_reference.py).
+            DIFFERENT optimiser trajectory than the reference's: a seeded
+            fit ends in other (equally good) parameters.
 
         Returns:
             res: A SciPy OptimizeResult object.
@@ -117,18 +117,18 @@ class CemaneigeHystGR4JIce(BaseModel):
                   frac_ice, NDSI1, NDSI2, NDSI3, NDSI4, NDSI5,
                   met_station_height, loss_metric="mse", snow_pack_init=0,
                   thermal_state_init=0, sca_init=0, s_init=0, r_init=0,
-                  altitudes=[], batched=True):
+                  altitudes=[], batched=False):
         """Fit to discharge AND the snow-covered area of five elevation bands
         (reference: cemaneigehystgr4jice.py:447-593).
 
-        batched: (extension) True (default): scipy gets a vectorised loss and
-            every generation's population is ONE GPU sweep
+        batched: (extension) False (default): the reference's own call -- one
+            candidate per loss evaluation, immediate updating -- which
+            reproduces the reference's seeded runs evaluation by evaluation
+            (tests/test_gpu_fit_reference.py).  True: scipy gets a vectorised
+            loss and every generation's population is ONE GPU sweep
             (updating='deferred') -- about a hundred times faster, but a
-            DIFFERENT optimiser trajectory than the reference's: a seeded fit
-            ends in other (equally good) parameters.  batched=False is the
-            reference's own call -- one candidate per loss evaluation,
-            immediate updating -- and reproduces its seeded runs evaluation
-            by evaluation (tests/test_gpu_fit_reference.py).
+            DIFFERENT optimiser trajectory than the reference's: a seeded
+            fit ends in other (equally good) parameters.
 
         Returns:
             res: A SciPy OptimizeResult object.

@@ -82,20 +82,20 @@ class GR4J(BaseModel):
             return tuple(out)
         return out[0]
 
-    def fit(self, qobs, prec, etp, s_init=0., r_init=0., batched=True):
+    def fit(self, qobs, prec, etp, s_init=0., r_init=0., batched=False):
         """Fit the GR4J model to a timeseries of discharge.
 
         scipy differential evolution over the default bounds, as in the
         reference (gr4j.py:185-249).
 
-        batched: (extension) True (default): scipy gets a vectorised loss and
-            every generation's population is ONE GPU sweep
+        batched: (extension) False (default): the reference's own call -- one
+            candidate per loss evaluation, immediate updating -- which
+            reproduces the reference's seeded runs evaluation by evaluation
+            (tests/test_gpu_fit_reference.py).  True: scipy gets a vectorised
+            loss and every generation's population is ONE GPU sweep
             (updating='deferred') -- about a hundred times faster, but a
-            DIFFERENT optimiser trajectory than the reference's: a seeded fit
-            ends in other (equally good) parameters.  batched=False is the
-            reference's own call -- one candidate per loss evaluation,
-            immediate updating -- and reproduces its seeded runs evaluation
-            by evaluation (tests/test_gpu_fit_reference.py).
+            DIFFERENT optimiser trajectory than the reference's: a seeded
+            fit ends in other (equally good) parameters.
 
         Returns:
             res: A scipy OptimizeResult class object.
@@ -151,9 +151,10 @@ def _run(prec, etp, s_init, r_init, params, want_qsim, want_storage, qobs):
         raise ValueError("Arrays must have the same size.")
     sse = np.zeros(n) if qobs is not None else None
     keep, (p_prec, p_etp) = _lib.f64s(prec, etp)
-    rc = lib.rr_gr4j_simulate(p_prec, p_etp, t, s_init, r_init, p_ptr, n,
+    rc = lib.rr_gr4j_simulate_opt(p_prec, p_etp, t, s_init, r_init, p_ptr, n,
                               *[out_ptr(a) for a in out], qobs_ptr,
-                              out_ptr(sse))
+                              out_ptr(sse),
+        _lib.opts_ptr())
     del keep
     _lib.check(rc, "rr_gr4j_simulate")
     return out, sse

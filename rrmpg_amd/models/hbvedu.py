@@ -80,20 +80,20 @@ class HBVEdu(BaseModel):
         return out[0]
 
     def fit(self, qobs, temp, prec, month, PE_m, T_m, snow_init=0.,
-            soil_init=0., s1_init=0., s2_init=0., batched=True):
+            soil_init=0., s1_init=0., s2_init=0., batched=False):
         """Fit the HBVEdu model to a timeseries of discharge.
 
         scipy differential evolution over the default bounds, as in the
         reference (hbvedu.py:216-307).
 
-        batched: (extension) True (default): scipy gets a vectorised loss and
-            every generation's population is ONE GPU sweep
+        batched: (extension) False (default): the reference's own call -- one
+            candidate per loss evaluation, immediate updating -- which
+            reproduces the reference's seeded runs evaluation by evaluation
+            (tests/test_gpu_fit_reference.py).  True: scipy gets a vectorised
+            loss and every generation's population is ONE GPU sweep
             (updating='deferred') -- about a hundred times faster, but a
-            DIFFERENT optimiser trajectory than the reference's: a seeded fit
-            ends in other (equally good) parameters.  batched=False is the
-            reference's own call -- one candidate per loss evaluation,
-            immediate updating -- and reproduces its seeded runs evaluation
-            by evaluation (tests/test_gpu_fit_reference.py).
+            DIFFERENT optimiser trajectory than the reference's: a seeded
+            fit ends in other (equally good) parameters.
 
         Returns:
             res: A scipy OptimizeResult class object.
@@ -152,9 +152,10 @@ def _run(forcing, inits, params, want_qsim, want_storage, qobs):
     sse = np.zeros(n) if qobs is not None else None
     month0 = np.ascontiguousarray(month0, dtype=np.int8)
     keep, (p_temp, p_prec, p_pe, p_tm) = _lib.f64s(temp, prec, PE_m, T_m)
-    rc = lib.rr_hbvedu_simulate(
+    rc = lib.rr_hbvedu_simulate_opt(
         p_temp, p_prec, month0.ctypes.data_as(_lib._i8p), p_pe, p_tm, t,
-        *inits, p_ptr, n, *[out_ptr(a) for a in out], qobs_ptr, out_ptr(sse))
+        *inits, p_ptr, n, *[out_ptr(a) for a in out], qobs_ptr, out_ptr(sse),
+        _lib.opts_ptr())
     del keep
     _lib.check(rc, "rr_hbvedu_simulate")
     return out, sse

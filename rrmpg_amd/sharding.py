@@ -130,7 +130,7 @@ def sweep(model, params, qobs, score="mse", gpus=None, return_qsim=False,
     * Without a process group: the host-pointer call itself fans the
       parameter-set axis out over `gpus` devices (an int, or 'all'; None: the
       current device), one host thread per device inside librrhip
-      (RR_OPT_HOST_SHARDS, include/rrhip.h), every device writing its columns
+      (the call's rr_call_options, RR_OPT_HOST_SHARDS, include/rrhip.h), every device writing its columns
       of the one [T, N] result.
 
     Returns a dict: 'scores' ([N] numpy, the whole sweep on every rank),
@@ -151,10 +151,7 @@ def sweep(model, params, qobs, score="mse", gpus=None, return_qsim=False,
         scores = allgather_scores(local, n, group=group).numpy()
     else:
         first, stop = 0, n
-        shards = 0 if gpus is None else (-1 if gpus == "all" else int(gpus))
-        if shards != -1 and shards < 0:
-            raise ValueError("gpus must be a positive int, 'all' or None")
-        with _lib.debug_option("host_shards", shards):
+        with _lib.call_options(host_shards=_lib.host_shards_of(gpus)):
             qsim, sse = model._sweep(params, qobs, bool(return_qsim),
                                      **forcing)
         scores = scores_from_sse(sse, qobs, score)

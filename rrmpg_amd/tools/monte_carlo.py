@@ -70,12 +70,12 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
         # a simulate() keyword the fused sweep does not take (return_storage
         # ...): go through simulate itself, as the reference does
         sweep = lambda *a, **kw: BaseModel._sweep(model, *a, **kw)  # noqa
-    shards = 0 if gpus is None else (-1 if gpus == "all" else int(gpus))
     if score not in ("mse", "nse"):
         raise ValueError("score must be 'mse' or 'nse'")
-    if shards != -1 and shards < 0:
-        raise ValueError("gpus must be a positive int, 'all' or None")
-    with _lib.debug_option("host_shards", shards):
+    # per-call option of the host-pointer entry point (rr_<model>_simulate_opt,
+    # include/rrhip.h): nothing process-wide is touched, so concurrent sweeps
+    # from several threads keep their own shard counts
+    with _lib.call_options(host_shards=_lib.host_shards_of(gpus)):
         qsim, sse = sweep(params, qobs, bool(return_qsim), **kwargs)
 
     result = {'params': params}

@@ -71,10 +71,12 @@ def oracle():
 # Every HBV-Edu kernel variant must meet the fixtures, not only the one the
 # size heuristic picks for the test's (small) number of sets: 0 = one scalar
 # load per day (what million-set sweeps and bench.py run), 2 = next-day
-# prefetch (small sweeps), 1 = LDS-staged forcing (measurement variant),
-# -1 = the library's own choice.
-@pytest.fixture(params=[-1, 0, 2, 1],
-                ids=["auto", "scalar-load", "prefetch", "lds-forcing"])
+# prefetch (small sweeps), 3 = the record of two days ahead requested, three
+# records rotating (sweeps of at most two waves per SIMD), 1 = LDS-staged
+# forcing (measurement variant), -1 = the library's own choice.
+@pytest.fixture(params=[-1, 0, 2, 3, 1],
+                ids=["auto", "scalar-load", "prefetch", "prefetch-2-days",
+                     "lds-forcing"])
 def hbv_variant(request):
     from rrmpg_amd import _lib
     with _lib.debug_option("hbv_variant", request.param):

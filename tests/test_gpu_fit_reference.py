@@ -1,4 +1,4 @@
-"""``fit(batched=False)`` against the REFERENCE's own optimiser runs.
+"""``fit()`` -- the default call -- against the REFERENCE's own optimiser runs.
 
 tests/golden/fit_ref.npz (tests/golden/gen_golden_fit.py) holds seeded runs of
 the reference's HBVEdu.fit / GR4J.fit / ABCModel.fit (scipy differential
@@ -57,7 +57,7 @@ def test_fit_follows_the_reference_trajectory(which):
     log, inner = _logged(mod)
     try:
         np.random.seed(int(g[which + "_seed"]))
-        res = cls().fit(*args, batched=False, **kw)
+        res = cls().fit(*args, **kw)      # the default: the reference's call
     finally:
         mod._loss = inner
     got = np.array(log)

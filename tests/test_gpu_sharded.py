@@ -1,5 +1,6 @@
 """The parameter-set axis over several GPUs as a LIBRARY call: the in-process
-fan-out of the host-pointer family (RR_OPT_HOST_SHARDS: one host thread and
+fan-out of the host-pointer family (the call's rr_call_options,
+RR_OPT_HOST_SHARDS, through rr_<model>_simulate_opt: one host thread and
 one device context per shard, every shard filling its columns of the caller's
 [T, N] arrays) behind ``monte_carlo(..., gpus=...)`` / ``sharding.sweep``, and
 the HBM-resident form ``sharding.ResidentSweep`` that bench.py loops over.
@@ -44,7 +45,7 @@ def test_host_family_fans_out_bit_identically(env, shards):
     args = (f["temp"], f["prec"], f["month"], f["PE_m"], f["T_m"])
     one = m.HBVEdu().simulate(*args, return_storage=True, params=p,
                               **env["syn"].HBV_INITS)
-    with lib.debug_option("host_shards", shards):
+    with lib.call_options(host_shards=shards):
         many = m.HBVEdu().simulate(*args, return_storage=True, params=p,
                                    **env["syn"].HBV_INITS)
     _same(one, many)
@@ -52,7 +53,7 @@ def test_host_family_fans_out_bit_identically(env, shards):
     p = m.GR4J().get_random_params(n)
     one = m.GR4J().simulate(f["prec"], f["etp"], 0.6, 0.7,
                             return_storage=True, params=p)
-    with lib.debug_option("host_shards", shards):
+    with lib.call_options(host_shards=shards):
         many = m.GR4J().simulate(f["prec"], f["etp"], 0.6, 0.7,
                                  return_storage=True, params=p)
         bad = p.copy()
@@ -62,7 +63,7 @@ def test_host_family_fans_out_bit_identically(env, shards):
     _same(one, many)
     p = m.ABCModel().get_random_params(n)
     one = m.ABCModel().simulate(f["prec"], 2.0, return_storage=True, params=p)
-    with lib.debug_option("host_shards", shards):
+    with lib.call_options(host_shards=shards):
         many = m.ABCModel().simulate(f["prec"], 2.0, return_storage=True,
                                      params=p)
     _same(one, many)
@@ -74,8 +75,7 @@ def test_host_family_fans_out_bit_identically(env, shards):
               altitudes=list(env["syn"].ALTITUDES), s_init=0.6, r_init=0.7,
               return_storages=True, params=p)
     one = m.CemaneigeGR4J().simulate(**kw)
-    with lib.debug_option("host_shards", shards), \
-            lib.debug_option("max_block_cols", 64):
+    with lib.call_options(host_shards=shards, max_block_cols=64):
         many = m.CemaneigeGR4J().simulate(**kw)
     _same(one, many)
 
@@ -108,8 +108,85 @@ def test_monte_carlo_gpus_and_sharding_sweep(env):
     assert np.array_equal(out["scores"], one["nse"])
     with pytest.raises(ValueError):
         monte_carlo(m.HBVEdu(), 10, qobs=qobs, score="kge", **kw)
-    with pytest.raises(ValueError):
-        monte_carlo(m.HBVEdu(), 10, qobs=qobs, gpus=-3, **kw)
+    for bad in (-3, 0, 2.5, "some"):
+        with pytest.raises(ValueError):
+            monte_carlo(m.HBVEdu(), 10, qobs=qobs, gpus=bad, **kw)
+
+
+def test_concurrent_sweeps_keep_their_own_options(env):
+    """The shard count travels with the CALL (rr_<model>_simulate_opt's
+    rr_call_options), not through a process-wide switch: two threads running
+    monte_carlo(gpus=1) and monte_carlo(gpus=3) at the same time -- and a
+    third sweeping GR4J in small column blocks -- get the bits of the same
+    calls made one after the other.  (The reference's seam:
+    rrmpg/tools/monte_carlo.py:61-71.)"""
+    import threading
+    from rrmpg_amd.tools import monte_carlo
+    m, f, lib = env["models"], env["f"], env["lib"]
+    kw = dict(temp=f["temp"], prec=f["prec"], month=f["month"],
+              PE_m=f["PE_m"], T_m=f["T_m"], **env["syn"].HBV_INITS)
+    np.random.seed(11)
+    pa = m.HBVEdu().get_random_params(3001)
+    pb = m.HBVEdu().get_random_params(2777)
+    pg = m.GR4J().get_random_params(1500)
+    qobs = m.HBVEdu().simulate(f["temp"], f["prec"], f["month"], f["PE_m"],
+                               f["T_m"], params=pa[:1],
+                               **env["syn"].HBV_INITS)[:, 0] * 1.03
+
+    def fixed(model, params):
+        # monte_carlo draws from numpy's global stream: hand each thread its
+        # own pre-drawn population instead
+        model.get_random_params = lambda num=1: params[:num]
+        return model
+
+    def job_a():
+        return monte_carlo(fixed(m.HBVEdu(), pa), len(pa), qobs=qobs,
+                           gpus=1, score="nse", **kw)
+
+    def job_b():
+        return monte_carlo(fixed(m.HBVEdu(), pb), len(pb), qobs=qobs,
+                           gpus=3, **kw)
+
+    def job_g():
+        with lib.call_options(max_block_cols=192, host_shards=2):
+            return m.GR4J().simulate(f["prec"], f["etp"], 0.6, 0.7,
+                                     return_storage=True, params=pg)
+
+    want = [job_a(), job_b(), job_g()]
+    # nothing process-wide was touched
+    assert lib.load().rr_debug_get_option(lib.OPTIONS["host_shards"]) == 0
+    assert lib.load().rr_debug_get_option(lib.OPTIONS["max_block_cols"]) == 0
+    for _ in range(3):
+        got, errs = [None] * 3, []
+
+        def run(k, fn):
+            try:
+                got[k] = fn()
+            except Exception as e:            # pragma: no cover
+                errs.append(e)
+        th = [threading.Thread(target=run, args=(k, fn))
+              for k, fn in enumerate((job_a, job_b, job_g))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for key in ("qsim", "mse", "nse"):
+            assert np.array_equal(got[0][key], want[0][key]), key
+        for key in ("qsim", "mse"):
+            assert np.array_equal(got[1][key], want[1][key]), key
+        _same(got[2], want[2])
+    # a thread's options never leak into another thread's calls
+    seen = {}
+
+    def probe():
+        seen["ptr"] = lib.opts_ptr()
+    with lib.call_options(host_shards=5):
+        t = threading.Thread(target=probe)
+        t.start()
+        t.join()
+        assert lib.opts_ptr() is not None
+    assert seen["ptr"] is None and lib.opts_ptr() is None
 
 
 def test_resident_sweep_scores(env):

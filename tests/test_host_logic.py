@@ -417,6 +417,45 @@ def test_debug_options_and_cache_release_need_no_gpu():
     assert lib.rr_debug_set_option(99, 0) == -4
     assert lib.rr_debug_get_option(99) == -2 ** 63
     assert lib.rr_release_cached_memory() == 0
+    # per-call / per-thread options (rr_call_options): range-checked like the
+    # process-wide hooks, and independent of them
+    import ctypes
+    o = _lib.CallOptions()
+    lib.rr_call_options_init(ctypes.byref(o))
+    assert o.struct_bytes == ctypes.sizeof(_lib.CallOptions)
+    assert all(v == _lib.RR_OPT_UNSET for v in o.value)
+    assert lib.rr_call_options_set(ctypes.byref(o), opt["host_shards"], 3) == 0
+    assert o.value[opt["host_shards"]] == 3
+    assert lib.rr_call_options_set(ctypes.byref(o), opt["host_shards"],
+                                   -7) == -4
+    assert lib.rr_call_options_set(ctypes.byref(o), 99, 0) == -4
+    assert lib.rr_call_options_set(ctypes.byref(o), opt["host_shards"],
+                                   _lib.RR_OPT_UNSET) == 0
+    assert lib.rr_thread_options(ctypes.byref(o)) == 0
+    assert lib.rr_thread_options(None) == 0
+    raw = _lib.CallOptions()                       # never initialised
+    assert lib.rr_call_options_set(ctypes.byref(raw), opt["host_shards"],
+                                   2) == -4
+    assert lib.rr_thread_options(ctypes.byref(raw)) == -4
+    assert b"struct_bytes" in lib.rr_last_error()
+    with _lib.call_options(host_shards=2):
+        with _lib.call_options(max_block_cols=64):
+            ptr = _lib.opts_ptr()
+            assert ptr is not None
+            cur = ptr._obj
+            assert cur.value[opt["host_shards"]] == 2
+            assert cur.value[opt["max_block_cols"]] == 64
+        assert _lib.opts_ptr()._obj.value[opt["max_block_cols"]] \
+            == _lib.RR_OPT_UNSET
+    assert _lib.opts_ptr() is None
+    assert lib.rr_debug_get_option(opt["host_shards"]) == 0
+    with pytest.raises(KeyError):
+        _lib.call_options(no_such_option=1)
+    for bad in (0, -2, 1.5, True, "most"):
+        with pytest.raises(ValueError):
+            _lib.host_shards_of(bad)
+    assert _lib.host_shards_of(None) is None
+    assert _lib.host_shards_of("all") == -1 and _lib.host_shards_of(4) == 4
     # no getenv anywhere in the library's sources
     csrc = os.path.join(REPO, "rrmpg_amd", "csrc")
     for name in os.listdir(csrc):
