@@ -109,6 +109,9 @@ def parse_args():
                     help="N = 1 only: skip the short timings of the other "
                          "BASELINE configurations after the headline")
     ap.add_argument("--extra-steps", type=int, default=3)
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="N = 1 only: skip the PCIe-inclusive timing of the "
+                         "host-pointer family (HBVEdu.simulate, 100k sets)")
     return ap.parse_args()
 
 
@@ -280,49 +283,87 @@ def build_catchments(args, device, rank):
     return ens, params, params_host, qsim, None, qobs, sse, name, fs[0]
 
 
-def cpu_baseline(args, f, params_host):
-    """The CPU oracle (oracle/rr_oracle.c, kind "port") timed on this box's
-    host cores on a bounded sample of the same workload.  Checker code: it is
-    only timed here, never used to produce the GPU result."""
+def _oracle_sweep(args, f):
+    """(name, k, fn): fn(flat, nthreads) runs the CPU oracle over the rows of
+    `flat` for the model of `args` on the forcing `f` -- reference-shaped (one
+    run per set, fresh [T] arrays, column scatter into qsim[T, N])."""
     from oracle import pyoracle
     from rrmpg_amd.utils import synthetic as syn
-    if args.model != "hbvedu":
+    if args.model == "hbvedu":
+        m0 = (f["month"] - 1).astype(np.int8)
+        inits = [syn.HBV_INITS[k] for k in ("snow_init", "soil_init",
+                                            "s1_init", "s2_init")]
+        return "HBV-Edu", 11, lambda flat, nt: pyoracle.simulate_hbvedu(
+            f["temp"], f["prec"], m0, f["PE_m"], f["T_m"], inits, flat,
+            nthreads=nt)
+    if args.model == "abc":
+        return "ABC", 3, lambda flat, nt: pyoracle.simulate_abc(
+            f["prec"], 2.5, flat, nthreads=nt)
+    if args.model == "gr4j":
+        return "GR4J", 4, lambda flat, nt: pyoracle.simulate_gr4j(
+            f["prec"], f["etp"], (syn.GR4J_INITS["s_init"],
+                                  syn.GR4J_INITS["r_init"]), flat,
+            nthreads=nt)
+    if args.model == "cemaneigegr4j":
+        from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+        layers, _ = prepare_snow_inputs(
+            f["prec"], f["temp"], f["tmin"], f["tmax"], syn.STATION_HEIGHT, 0,
+            0, list(syn.ALTITUDES), etp=f["etp"])
+        return "CemaneigeGR4J(L=5)", 6, \
+            lambda flat, nt: pyoracle.simulate_cemaneigegr4j(
+                layers[0], layers[1], layers[3], layers[2],
+                (0., 0., 0.6, 0.7), flat, nthreads=nt)
+    return None
+
+
+# the reference's own published single-thread numba rates (BASELINE.md /
+# docs/source/examples/speed_comparision.rst:205-210), model-timesteps/s
+PUBLISHED_NUMBA = {"abc": 3.0e8}
+
+
+def cpu_baseline(args, f, params_host, seconds=10.0):
+    """The CPU oracle (oracle/rr_oracle.c, kind "port") timed on this box's
+    host cores on a bounded sample of the same workload (about `seconds` of
+    all-core work).  Checker code: it is only timed here, never used to
+    produce the GPU result."""
+    from oracle import pyoracle
+    sweep = _oracle_sweep(args, f)
+    if sweep is None or args.catchments > 0:
         return None
+    name, k, run = sweep
     cores = pyoracle.max_threads()
-    flat = np.ascontiguousarray(params_host)      # [sets, 11]
-    m0 = (f["month"] - 1).astype(np.int8)
-    inits = [syn.HBV_INITS[k] for k in ("snow_init", "soil_init", "s1_init",
-                                        "s2_init")]
+    flat = np.ascontiguousarray(params_host).reshape(-1, k)
 
     def timed(nsets, nthreads):
         t0 = time.perf_counter()
-        pyoracle.simulate_hbvedu(f["temp"], f["prec"], m0, f["PE_m"], f["T_m"],
-                                 inits, flat[:nsets], nthreads=nthreads)
+        run(flat[:nsets], nthreads)
         return time.perf_counter() - t0
 
-    # single thread, reference-shaped (one call per set, fresh arrays,
-    # column scatter): ~2-3 s
-    n1 = min(2000, flat.shape[0])
+    # single thread, reference-shaped: a second or two
+    n1 = min(2000 if seconds >= 10 else 500, flat.shape[0])
     t1 = timed(n1, 1)
     rate1 = n1 * args.days / t1
-    # all host cores: calibrate, then ~10 s of work
+    # all host cores: calibrate, then ~`seconds` of work
     ncal = min(flat.shape[0], 250 * cores)
     tcal = timed(ncal, cores)
-    nall = int(min(flat.shape[0], max(ncal, ncal * 10.0 / max(tcal, 1e-3))))
+    nall = int(min(flat.shape[0], max(ncal, ncal * seconds / max(tcal, 1e-3))))
     tall = timed(nall, cores) if nall > ncal else tcal
-    return {
+    rec = {
         "value": nall * args.days / tall,
         "unit": "model-timesteps/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d HBV-Edu parameter sets x %d days, all %d host threads "
+        "sample": "%d %s parameter sets x %d days, all %d host threads "
                   "(OpenMP over sets), reference-shaped: one run per set, "
                   "fresh [T] arrays, column scatter into qsim[T,N]; %.1f s"
-                  % (nall, args.days, cores, tall),
+                  % (nall, name, args.days, cores, tall),
         "value_1thread": rate1,
         "sample_1thread": "%d sets x %d days, 1 thread, %.1f s"
                           % (n1, args.days, t1),
     }
+    if args.model in PUBLISHED_NUMBA:
+        rec["published_numba_1thread"] = PUBLISHED_NUMBA[args.model]
+    return rec
 
 
 def parity_spot(args, f, params_host, qsim, sse, qobs, n_cols=16):
@@ -380,6 +421,88 @@ def parity_spot(args, f, params_host, qsim, sse, qobs, n_cols=16):
     return float(err.max())
 
 
+MODEL_CLASSES = {"hbvedu": "HBVEdu", "abc": "ABCModel", "gr4j": "GR4J",
+                 "cemaneigegr4j": "CemaneigeGR4J"}
+
+
+def parity_spot_host_population(args, ens, f, n=4096, n_cols=16):
+    """SURVEY.md section 8d's population -- ``np.random.seed(1)`` then
+    ``Model.get_random_params(n)``, the reference's own sampler -- run
+    through the resident ensemble after the timed region and compared with
+    the CPU oracle column by column (checker only).  The timed sweep draws
+    its sets on the device (numpy's Philox stream); this shows the legacy
+    population gives the same agreement.  Returns the max relative error."""
+    import torch
+    from rrmpg_amd import models
+    sweep = _oracle_sweep(args, f)
+    if sweep is None or args.catchments > 0:
+        return None
+    _, k, run = sweep
+    cls = getattr(models, MODEL_CLASSES[args.model])
+    np.random.seed(1)
+    rec = cls().get_random_params(n)
+    params = ens.upload_params(rec)
+    q = ens.new_output(n)
+    ens.run(params, q)
+    torch.cuda.synchronize()
+    cols = np.unique(np.linspace(0, n - 1, n_cols).astype(np.int64))
+    flat = np.stack([rec[name] for name in cls._param_list], 1)
+    ref = run(np.ascontiguousarray(flat[cols]), 4)
+    if isinstance(ref, tuple):
+        ref = ref[0]
+    got = q[:, torch.from_numpy(cols).to(q.device)].cpu().numpy()
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-9)
+    return float(err.max()) if np.all(np.isfinite(err)) else float("nan")
+
+
+def end_to_end(args, n=100_000):
+    """The host-pointer family as a reference user calls it -- numpy in, numpy
+    out, PCIe and the first touch of the result's pages included (never
+    `value`): HBVEdu.simulate of BASELINE configs[1] (100k sets x 30 years =
+    8.77 GB of qsim into a numpy array; replaces the loop of the reference's
+    rrmpg/models/hbvedu.py:190-214) and monte_carlo(return_qsim=False) of the
+    same sets (scores only: 0.8 MB back)."""
+    from rrmpg_amd import _lib, models
+    from rrmpg_amd.tools import monte_carlo
+    from rrmpg_amd.utils import synthetic as syn
+    f = syn.make_forcing(args.days)
+    kw = dict(temp=f["temp"], prec=f["prec"], month=f["month"],
+              PE_m=f["PE_m"], T_m=f["T_m"], **syn.HBV_INITS)
+    np.random.seed(1)
+    m = models.HBVEdu()
+    p = m.get_random_params(n)
+    m.simulate(params=p[:64], **kw)                  # context, forcing upload
+    t0 = time.perf_counter()
+    q = m.simulate(params=p, **kw)
+    t_sim = time.perf_counter() - t0
+    qobs = syn.make_qobs(q[:, :1].copy())
+    finite = bool(np.isfinite(q[-1]).all())
+    nbytes = q.nbytes
+    del q
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    mc = monte_carlo(m, n, qobs=qobs, return_qsim=False, **kw)
+    t_mc = time.perf_counter() - t0
+    _lib.load().rr_release_cached_memory()
+    steps = n * args.days
+    return {
+        "workload": "HBVEdu.simulate, %d sets x %d days, host pointers: "
+                    "numpy in, qsim[T,N] (%.2f GB) in a fresh numpy array out"
+                    % (n, args.days, nbytes / 1e9),
+        "seconds": t_sim,
+        "model_timesteps_per_s": steps / t_sim,
+        "gb_per_s_into_numpy": nbytes / t_sim / 1e9,
+        "finite": finite,
+        "monte_carlo_scores_only": {
+            "workload": "monte_carlo(HBVEdu, %d, qobs, return_qsim=False): "
+                        "sampling, upload, sweep, per-set MSE back" % n,
+            "seconds": t_mc,
+            "model_timesteps_per_s": steps / t_mc,
+            "finite": bool(np.isfinite(mc["mse"]).all())},
+        "note": "PCIe-inclusive, single GPU; never the line's `value`",
+    }
+
+
 # fp64 VALU issue roof (profiles/README.md, profiles/ubench/valu_cost.hip): a
 # wave64 fp64 instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs;
 # 2.4 GHz nominal engine clock.
@@ -399,6 +522,9 @@ def traffic_record(args, n, t):
     in this run -- the line says so in "source"."""
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     key = "%s:%s:%d:%d" % (args.model, args.mode, n, t)
+    if args.catchments > 0:
+        key = "%s:%s:%dx%d:%d" % (args.model, args.mode, args.catchments,
+                                  args.sets, t)
     try:
         with open(tpath) as fh:
             pmc = json.load(fh)
@@ -634,6 +760,22 @@ def extra_configs(args, device):
                                    parity_spot(a, r["f"], r["params_host"],
                                                r["qsim"], r["sweep"].sse,
                                                r["qobs"]))}
+            traffic, valu = traffic_record(a, r["n"], r["t"])
+            if traffic:
+                rec["traffic"] = traffic
+            if valu:
+                floor_ms = (valu / 64.0 * r["n"] * r["t"]
+                            * VALU_CYCLES_PER_INSTR / SIMDS
+                            / (CLOCK_GHZ_NOMINAL * 1e9) * 1e3)
+                rec["valu"] = {"instr_per_unit": valu, "floor_ms": floor_ms,
+                               "frac": floor_ms / r["kernel_ms"]}
+            if not args.no_cpu_baseline:
+                # the oracle on the host cores for THIS model (a short
+                # sample); the HBV-Edu configurations share the headline's
+                rec["cpu_baseline"] = (
+                    "the headline's (same model)" if a.model == "hbvedu"
+                    else cpu_baseline(a, r["f"], r["params_host"],
+                                      seconds=2.5))
         except Exception as exc:                # keep the headline line
             rec = {"workload": label, "error": "%s: %s"
                    % (type(exc).__name__, exc)}
@@ -777,6 +919,10 @@ def main():
             out["parity_spot"] = parity_spot(args, r["f"], r["params_host"],
                                              r["qsim"], r["sweep"].sse,
                                              r["qobs"])
+            # ... and SURVEY 8d's own population (np.random.seed(1) +
+            # get_random_params) through the same resident ensemble
+            out["parity_spot_host_population"] = parity_spot_host_population(
+                args, r["ens"], r["f"])
         if (not args.no_cpu_baseline and world == 1
                 and args.catchments == 0):
             out["cpu_baseline"] = cpu_baseline(args, r["f"], r["params_host"])
@@ -785,6 +931,14 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["extra_configs"] = extra_configs(args, device)
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                if not args.no_end_to_end:
+                    out["end_to_end"] = end_to_end(args)
+            except Exception as exc:            # keep the headline line
+                out["end_to_end"] = {"error": "%s: %s"
+                                     % (type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

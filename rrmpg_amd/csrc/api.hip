@@ -1191,6 +1191,34 @@ extern "C" int rrdbg_divide_by_invariant(const double *a, const double *b,
     return rc;
 }
 
+// ---- device test hook (not part of include/rrhip.h) --------------------------
+// A kernel that does nothing but hold the GPU: `blocks` workgroups of 256
+// threads spin until `microseconds` of wall time have passed since each
+// started.  tests/test_gpu_async.py runs two time-tiled sweeps beside it: the
+// tiles' tickets (common.h) must get every sweep through whatever else shares
+// the device and in whatever order its workgroups start.
+__global__ void dbg_spin_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    (void)t0;
+    const unsigned long long r0 = wall_clock64();
+    while (wall_clock64() - r0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int rrdbg_spin_dev(int blocks, int64_t microseconds, void *stream)
+{
+    if (blocks < 1 || microseconds < 0 || microseconds > 5000000) {
+        rr_set_error("rrdbg_spin_dev: bad arguments");
+        return RR_E_PARAM;
+    }
+    // wall_clock64 counts at 100 MHz on gfx9
+    hipLaunchKernelGGL(dbg_spin_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream,
+                       (unsigned long long)microseconds * 100ull);
+    RR_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 // ---- next tier: hysteresis / ice-melt couplings (host pointers) ------------
 namespace {
 

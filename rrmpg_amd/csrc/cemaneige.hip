@@ -111,7 +111,7 @@ __global__ void cema_gt_table(double *__restrict__ gtresh, int L, int nreg)
     gtresh[4 * L] = all_ok ? 1.0 : 0.0;
 }
 
-// TILED: the time axis in pieces, items in grid order (common.h RrTiles:
+// TILED: the time axis in pieces, one workgroup per ticket (common.h RrTiles:
 // million-set sweeps); handed over: both snow states of every layer and the
 // score sum.
 template <int L, bool TILED = false>
@@ -126,8 +126,9 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
     int job = blockIdx.x, piece = 0;
     if constexpr (TILED) {
-        piece = (int)blockIdx.x / njobs;
-        job = (int)blockIdx.x - piece * njobs;
+        const int item = rr_tile_ticket(tiles);
+        piece = __builtin_amdgcn_readfirstlane(item / njobs);
+        job = __builtin_amdgcn_readfirstlane(item - piece * njobs);
     }
     const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
@@ -264,7 +265,7 @@ typedef const CoupledOut __attribute__((address_space(4))) *coupled_out_ptr_t;
 
 typedef const double __attribute__((address_space(4))) *cema_rec_ptr_t;
 // TILED (register hydrograph tiers 3 and 5 only): the time axis in pieces,
-// items in grid order (common.h RrTiles: million-set sweeps); handed over:
+// one workgroup per ticket (common.h RrTiles: million-set sweeps); handed over:
 // the snow states, both stores, the hydrograph slots, the score sum.
 #ifndef COUPLED_TILED_MINWAVES
 #define COUPLED_TILED_MINWAVES 3
@@ -288,8 +289,9 @@ cemaneigegr4j_kernel(
     int job = blockIdx.x, piece = 0;
     const int njobs = TILED ? (int)((N + RR_BLOCK - 1) / RR_BLOCK) : 0;
     if constexpr (TILED) {
-        piece = (int)blockIdx.x / njobs;
-        job = (int)blockIdx.x - piece * njobs;
+        const int item = rr_tile_ticket(tiles);
+        piece = __builtin_amdgcn_readfirstlane(item / njobs);
+        job = __builtin_amdgcn_readfirstlane(item - piece * njobs);
     }
     const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
     const bool active = i < N;

@@ -249,26 +249,31 @@ __device__ __forceinline__ unsigned rr_row_bytes(int64_t first, int64_t N)
 // per SIMD, so 265 SIMDs run a sixteenth wave while the others idle -- the
 // kernel takes 16 wave slots for 15.26 slots of work -- and the dispatcher's
 // wave placement is not even either.  The tiled kernels cut every wave's 30
-// years into PIECES: workgroup b runs piece b / jobs of job b % jobs (the 64
-// sets of a wave), piece-major, and the model states travel from piece to
-// piece through a small HBM scratch [nstate][jobs * 64], handed over with a
-// release / acquire pair at agent scope (the next piece may run on another
-// XCD) and a per-job flag.  Items are a quarter as long, slots refill as
-// they free, and the SIMDs finish within a fraction of a wave of each other
-// (HBV-Edu 1M sets: 27.1 -> 25.3 ms, scores 21.8 -> 19.6; GR4J scores 46.8 ->
-// 44.4).  A piece waits only for a workgroup with a SMALLER index: no
-// deadlock as long as every XCD dispatches its workgroups in increasing
-// order -- the smallest unfinished item then never waits for a slot held by
-// a waiting one.  (The robust form -- persistent waves pulling items from an
-// atomic counter, free of any assumption about the dispatcher -- is what
-// hbvedu.hip runs, where it is also the faster one; for GR4J and Cemaneige
-// the loop around the whole kernel body cost registers and time, and it did
-// not survive hipcc's control-flow structurizer reliably unless job and
-// piece were forced scalar with readfirstlane.)
+// years into PIECES: an ITEM is piece p of job j (the 64 sets of a wave),
+// numbered piece-major (item = p * jobs + j), and the model states travel from
+// piece to piece through a small HBM scratch [nstate][jobs * 64], handed over
+// with a release / acquire pair at agent scope (the next piece may run on
+// another XCD) and a per-job flag.  Items are a quarter as long, slots refill
+// as they free, and the SIMDs finish within a fraction of a wave of each
+// other (HBV-Edu 1M sets: 27.1 -> 25.3 ms, scores 21.8 -> 19.6; GR4J scores
+// 46.8 -> 44.4).
+// Which item a wave works on is decided by a TICKET drawn from one atomic
+// counter when the wave starts to run (rr_tile_ticket) -- never by its
+// workgroup index.  An item waits only for the item `jobs` tickets before it,
+// and a ticket exists only because a wave that is already running drew it:
+// whatever order the dispatcher starts workgroups in, whatever else shares the
+// GPU, the smallest unfinished ticket can always proceed, so the launch
+// cannot deadlock (rounds 1-3 took the item from blockIdx and relied on every
+// XCD dispatching workgroups in increasing order, with a poll limit that
+// turned a violation into a failed launch).  HBV-Edu runs the same scheme
+// with PERSISTENT waves (as many as are resident at once, each drawing
+// tickets until none is left: hbvedu.hip); GR4J and Cemaneige launch one
+// single-wave workgroup per item, each drawing exactly one ticket -- no loop
+// around the kernel body, whose register allocation did not survive one.
 // Results are bit-identical to the untiled loops: the same operations in the
 // same order.
 struct RrTiles {
-    int *queue;        // [1 + job] pieces done ([0]: the persistent form's item counter)
+    int *queue;        // [0]: ticket counter; [1 + job]: pieces of the job done
     double *state;     // hand-over scratch
     int pieces;        // 0 / 1: untiled
 };
@@ -284,20 +289,25 @@ __device__ __forceinline__ void rr_tile_range(int t0, int t1, int pieces,
     if (b > t1) b = t1;
     e = (b + len < t1) ? b + len : t1;
 }
-// wait until piece - 1 of this job has published its states
+// this wave's item: the next ticket of the launch (wave-uniform; queue[0],
+// zeroed by the host before the launch)
+__device__ __forceinline__ int rr_tile_ticket(const RrTiles &q)
+{
+    int item = 0;
+    if ((threadIdx.x & (RR_BLOCK - 1)) == 0)
+        item = __hip_atomic_fetch_add(q.queue, 1, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(item);
+}
+// wait until piece - 1 of this job has published its states (an item with a
+// smaller ticket, held by a wave that is running or done: the wait ends)
 __device__ __forceinline__ void rr_tile_wait(const RrTiles &q, int job,
                                              int piece)
 {
     int *flag = q.queue + 1 + job;
-    // (the wait is at most one piece long; the count turns a dispatch order
-    // this scheme does not expect into a failed launch after about a minute
-    // of polling, instead of a hang)
-    int polls = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT) < piece) {
+                             __HIP_MEMORY_SCOPE_AGENT) < piece)
         __builtin_amdgcn_s_sleep(8);
-        if (++polls == (1 << 26)) __builtin_trap();
-    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // after the states of `piece` have been stored

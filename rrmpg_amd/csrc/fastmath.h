@@ -320,20 +320,32 @@ FP_FN double fastpow_tab_core(double x, double y2hi, double y2lo,
 // HBV-Edu's deviation from the reference semantics over 30 years: DESIGN.md section 4.
 // Same domain and guard as fastpow_tab_core (fastpow_tab_ok).
 #define FP_LN2 0x1.62e42fefa39efp-1
-template <bool VCONST = false>
-FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,
-                              double *z_out)
+// The evaluation in two halves, so that a caller can put work of its own
+// between the table read (an LDS access on the device) and the first use of
+// the entry: fastpow_tab_lookup splits x and fetches the subinterval's entry,
+// fastpow_tab_lite_finish does the arithmetic.
+struct FpPowLookup {
+    double z, kd, invc, lnc;
+};
+FP_FN FpPowLookup fastpow_tab_lookup(double x, const FpPowLogEntry *tab)
 {
     const int hi = FP_HI32(x);
     const int tmp = hi - FP_POWLOG_OFF_HI;
     const int i = (tmp >> 13) & (FP_POWLOG_N - 1);
     const int k = tmp >> 20;                          // arithmetic shift
-    const double z = FP_FROM_HILO(hi - (tmp & (int)0xFFF00000), FP_LO32(x));
-    const double kd = (double)k;
-    const double invc = tab[i].invc, lnc = tab[i].lnc;
-
-    const double r = FP_FMA(z, invc, -1.0);
-    const double t = FP_FMA(kd, FP_LN2, lnc);
+    FpPowLookup e;
+    e.z = FP_FROM_HILO(hi - (tmp & (int)0xFFF00000), FP_LO32(x));
+    e.kd = (double)k;
+    e.invc = tab[i].invc;
+    e.lnc = tab[i].lnc;
+    return e;
+}
+template <bool VCONST = false>
+FP_FN double fastpow_tab_lite_finish(const FpPowLookup &e, double y2,
+                                     double *z_out)
+{
+    const double r = FP_FMA(e.z, e.invc, -1.0);
+    const double t = FP_FMA(e.kd, FP_LN2, e.lnc);
     // ln(1 + r) = r + r^2 (-1/2 + r/3 - r^2/4 + r^3/5 - r^4/6 + r^5/7)
     double h = 1.0 / 7.0;
     h = FP_FMA_K(h, r, -1.0 / 6.0);
@@ -360,6 +372,13 @@ FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,
     q = FP_FMA_K(q, q0, 0.6931471805599453);
     q = FP_FMA(q, q0, 1.0);                           // inline constant
     return FP_LDEXP(q, (int)n);
+}
+template <bool VCONST = false>
+FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,
+                              double *z_out)
+{
+    return fastpow_tab_lite_finish<VCONST>(fastpow_tab_lookup(x, tab), y2,
+                                           z_out);
 }
 
 // Where fastpow_tab_core's result may be used: x a positive NORMAL number

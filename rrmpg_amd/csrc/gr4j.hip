@@ -201,8 +201,9 @@ constexpr int gr4j_tile_states()
     return 3 + UH::TIER + (2 * UH::TIER + 1);       // s, r, acc + slots
 }
 
-// TILED: 0 no, 1 items in grid order, 2 persistent waves pulling items from the
-// queue's counter (the job / piece of an item kept explicitly scalar).
+// TILED: 0 no, 1 one workgroup per item (the item: a ticket from the queue's
+// counter), 2 persistent waves drawing tickets until none is left (the job /
+// piece of an item kept explicitly scalar).
 template <class UH, bool Q, bool S, bool E, int TILED = 0>
 __global__ __launch_bounds__(RR_BLOCK, GR4J_OPT_MINWAVES)
 void gr4j_opt_kernel(
@@ -218,17 +219,16 @@ void gr4j_opt_kernel(
     const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
     typedef const GrDay __attribute__((address_space(4))) *day_ptr_t;
     const day_ptr_t dp = (day_ptr_t)days;
-    // (TILED here takes its items in GRID order, workgroup b = piece
-    // b / jobs of job b % jobs, instead of from an atomic item counter: the
-    // persistent loop around this kernel's two-generation day did not
-    // survive hipcc's control-flow structurizer.  Safe as long as every XCD
-    // dispatches its workgroups in increasing order: the smallest unfinished
-    // item then never waits for a slot held by a waiting one.)
+    // (TILED == 1: one single-wave workgroup per item, the item a ticket
+    // drawn when the wave starts -- common.h "the time axis in pieces";
+    // TILED == 2, the persistent loop around this kernel's two-generation
+    // day, is kept as a measurement variant: it costs scratch spills)
   for (;;) {
     int job = blockIdx.x, piece = 0;
     if constexpr (TILED == 1) {
-        piece = (int)blockIdx.x / njobs;
-        job = (int)blockIdx.x - piece * njobs;
+        const int item = rr_tile_ticket(tiles);
+        piece = __builtin_amdgcn_readfirstlane(item / njobs);
+        job = __builtin_amdgcn_readfirstlane(item - piece * njobs);
     } else if constexpr (TILED == 2) {
         int item = 0;
         if (threadIdx.x == 0) item = atomicAdd(tiles.queue, 1);
@@ -494,7 +494,7 @@ static size_t gr4j_days_bytes(int64_t T)
 // ... + the tiled kernels' work queue and hand-over scratch (common.h RrTiles)
 #define GR4J_TILE_STATES (gr4j_tile_states<UhRegs<5>>())
 #ifndef GR4J_TILE_MODE
-#define GR4J_TILE_MODE 1   // 1 grid-order items, 2 persistent waves
+#define GR4J_TILE_MODE 1   // 1 one workgroup per ticket, 2 persistent waves
 #endif
 extern "C" size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N)
 {

@@ -142,6 +142,20 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 #ifndef HBV_TILED_MINWAVES
 #define HBV_TILED_MINWAVES 1
 #endif
+#ifndef HBV_SMALL_TILES
+#define HBV_SMALL_TILES 0
+#endif
+// Measurement switch, off: 1 writes the part of the day that does not wait
+// for the power (evaporation factor, overflow, base-flow store) INSIDE both
+// arms of the power branch, fenced by scheduling barriers between the
+// logarithm table's LDS read and the first use of its entry -- the idea: a
+// sweep of one or two waves per SIMD sits that latency out.  Measured, A/B in
+// one call (round 4): 65k sets 2.44 -> 2.49 ms, 125k 2.85 -> 2.91, 250k 5.73
+// -> 7.1, 1M 19.8 -> 20.2 (hipcc hoists half of the part above the branch
+// again and pays a register copy per day for the rest).
+#ifndef HBV_INDEPENDENT_IN_ARMS
+#define HBV_INDEPENDENT_IN_ARMS 0
+#endif
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
           bool TAME = true, int TILED = 0>
 __global__ __launch_bounds__(RR_BLOCK, (TILED ? HBV_TILED_MINWAVES : 1)) void
@@ -214,22 +228,34 @@ hbvedu_kernel(
 
     const InvDivisor inv_FC = make_inv_divisor(FC);
     const InvDivisor inv_PWP = make_inv_divisor(PWP);
-    // box in which (soil/FC)**Beta is certainly finite (see the time loop)
-    double soil_lo = FC * 0x1p-9, soil_hi = FC * 0x1p9;
-    // (opaque to the compiler: otherwise it re-derives both from FC with two
-    // v_ldexp_f64 every day to save four registers)
-    asm("" : "+v"(soil_lo), "+v"(soil_hi));
+    // box in which (soil/FC)**Beta is certainly finite (see the time loop):
+    // FC 2^-9 < soil < FC 2^9, |Beta| <= 64, FC a sane positive number.
+    // Tested on soil's HIGH WORD with two 32-bit integer instructions (a
+    // subtraction and an unsigned compare against the box's span) instead of
+    // two fp64 compares: for positive finite doubles the high word is
+    // monotonic, a negative, zero, subnormal, infinite or NaN soil wraps to a
+    // difference beyond any span, and a lane whose FC or Beta rule the box
+    // out has span 0 -- the box is a sufficient condition only, so being a
+    // few ulps of 2^32 tighter at both ends costs nothing.
     const bool box_ok = (FC > 0x1p-500) && (FC < 0x1p500) &&
                         (fabs(Beta) <= 64.0);
+    unsigned box_lo = (unsigned)__double2hiint(FC * 0x1p-9) + 1u;
+    unsigned box_span =
+        box_ok ? (unsigned)__double2hiint(FC * 0x1p9) - box_lo : 0u;
+    // (opaque to the compiler, which would otherwise re-derive both every day)
+    asm("" : "+v"(box_lo), "+v"(box_span));
     // Beta / ln 2 as a double-double, for fastpow_tab_core
     double beta2_hi, beta2_lo;
     fastpow_tab_exponent(Beta, &beta2_hi, &beta2_lo);
     // loop-invariant lane masks for the wave votes (common.h)
-    const lanemask_t box_m = RR_LANES(box_ok);
     const lanemask_t fc_m = RR_LANES(inv_FC.ok), pwp_m = RR_LANES(inv_PWP.ok);
     const bool pwp_pos = inv_PWP.ok && PWP > 0.0;
     // what a day leaves of the two linear stores (RR_HBV_CONTRACT)
     const double keep_1 = 1 - K_1 - K_p, keep_2 = 1 - K_2;
+    const double neg_LK0 = -(L * K_0);
+    // K_0: +0 or a positive number; L finite (v_cmp_class masks)
+    const lanemask_t k0_folds_m = lanes_of_class(K_0, 0x1c0) & lanes_finite(L);
+    const bool k0_folds = (k0_folds_m >> (threadIdx.x & 63)) & 1;
 
     double snow = snow_init, soil = soil_init, s1 = s1_init, s2 = s2_init;
     double acc = 0.0;
@@ -339,12 +365,68 @@ hbvedu_kernel(
         // reference semantics 5e-15 -> 6e-15.  -DRR_FAITHFUL_QUOTIENTS=0 builds the
         // correctly rounded 3-FMA form, for which the box doubles as the
         // numerator's guard.)
-        const lanemask_t soil_m =
-            RR_LANES(soil >= soil_lo) & RR_LANES(soil <= soil_hi) & box_m;
+        const lanemask_t soil_m = RR_LANES(
+            (unsigned)__double2hiint(soil) - box_lo < box_span);
         // lanes that need the power: wet, or outside the box (votes are done
         // on lane masks, common.h)
         const lanemask_t need_m = RR_LANES(liquid_water != 0.0) | ~soil_m;
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
+#if RR_HBV_CONTRACT
+        // What the rest of the day needs besides the effective precipitation
+        // -- evaporation factor, overflow of the upper store, base-flow
+        // store -- does not wait for the power, and is written INSIDE both
+        // arms of the branch below rather than behind it: on a power day the
+        // scheduler then has a dozen independent instructions to put between
+        // the logarithm table's LDS read and the first use of its entry (a
+        // sweep of one or two waves per SIMD sits that latency out
+        // otherwise; same operations, same bits).
+        double pe, dry, over, s2_n;
+        auto independent_of_the_power = [&](auto wet_arm)
+            __attribute__((always_inline)) {
+            // potential / actual evapotranspiration (:102-108); the select
+            // picks the factor, 1 or soil/PWP, so that the product with pe
+            // goes into the soil update's FMA
+            // (1 + C dtemp) PE_m as PE_m + C (dtemp PE_m): the forcing
+            // record carries the product
+            pe = __builtin_fma(C, f.dtemp, f.pe_m);
+            // min(soil/PWP, 1) for a lane with a positive, usable PWP -- what
+            // the reference's `if soil > PWP` selects, in one instruction (a
+            // NaN soil has made soil_lw NaN already) --, the select itself
+            // for any other lane; a tame wave has only lanes of the first kind
+            if constexpr (decltype(tame)::value) {
+                const double ratio = inv_mul_core(soil, inv_PWP);
+                asm("v_min_f64 %0, %1, 1.0" : "=v"(dry) : "v"(ratio));
+            } else {
+                const double ratio = mul_by_inverse_m(soil, inv_PWP, pwp_m);
+                double least1;
+                asm("v_min_f64 %0, %1, 1.0" : "=v"(least1) : "v"(ratio));
+                dry = pwp_pos ? least1 : ((soil > PWP) ? 1.0 : ratio);
+            }
+            // near-surface reservoir's overflow (:114-115)
+            // (a tame wave -- K_0 not negative, L finite --: max(0, s1 - L)
+            // K_0 as max(0, s1 K_0 - L K_0), the product L K_0 a loop
+            // invariant; a lane's form does not depend on the loop copy its
+            // wave runs: in the general copy a lane with such K_0 and L takes
+            // the same value, any other lane the reference's sequence)
+            if constexpr (decltype(tame)::value) {
+                over = rr_hw_max(__builtin_fma(s1, K_0, neg_LK0), 0.0);
+            } else {
+                const double folded =
+                    rr_hw_max(__builtin_fma(s1, K_0, neg_LK0), 0.0);
+                over = k0_folds ? folded : nb_max(0.0, s1 - L) * K_0;
+            }
+            // base-flow reservoir (:121-123): s2 (1 - K_2) + s1 K_p
+            s2_n = __builtin_fma(s2, keep_2, s1 * K_p);
+            // (pins the four values to THIS arm: as plain common code hipcc
+            // sinks it out of both arms again, behind the power)
+            if constexpr (decltype(wet_arm)::value)
+                asm volatile("; power day" : "+v"(pe), "+v"(dry), "+v"(over),
+                             "+v"(s2_n));
+            else
+                asm volatile("; day without the power" : "+v"(pe), "+v"(dry),
+                             "+v"(over), "+v"(s2_n));
+        };
+#endif
         if (need_m & rr_exec()) {
 #if RR_FAITHFUL_QUOTIENTS
             // (a tame wave has checked its divisors once, before the loop)
@@ -366,10 +448,23 @@ hbvedu_kernel(
             double z;
             // (small sweeps, FORCING == 2: polynomial constants in VGPRs so
             // that the prefetched record fits the SGPR file without spills)
-#if RR_HBV_POW_LITE
+#if RR_HBV_POW_LITE && RR_HBV_CONTRACT && HBV_INDEPENDENT_IN_ARMS
+            // (the table read first, the day's independent part between it
+            // and the first use of the entry: nothing may be scheduled
+            // across the two barriers)
+            const FpPowLookup entry = fastpow_tab_lookup(wetness, powlog);
+            __builtin_amdgcn_sched_barrier(0);
+            independent_of_the_power(std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            double pw = fastpow_tab_lite_finish<FORCING >= 2>(entry, beta2_hi,
+                                                              &z);
+#elif RR_HBV_POW_LITE
             double pw = fastpow_tab_lite<FORCING >= 2>(wetness, beta2_hi,
                                                        powlog, &z);
 #else
+#if RR_HBV_CONTRACT && HBV_INDEPENDENT_IN_ARMS
+            independent_of_the_power(std::true_type{});
+#endif
             double pw = fastpow_tab_core<FORCING >= 2>(wetness, beta2_hi,
                                                        beta2_lo, powlog, &z);
 #endif
@@ -391,6 +486,13 @@ hbvedu_kernel(
             // on every day WITHOUT the power to join the two)
             asm("v_mul_f64 %0, %0, %1" : "+v"(prec_eff) : "v"(pw));
         }
+#if RR_HBV_CONTRACT && HBV_INDEPENDENT_IN_ARMS
+        else {
+            independent_of_the_power(std::false_type{});
+        }
+#elif RR_HBV_CONTRACT
+        independent_of_the_power(std::false_type{});
+#endif
         mid();
 
 #if RR_HBV_CONTRACT
@@ -400,37 +502,12 @@ hbvedu_kernel(
         // loop-invariant retention factors: 12 instructions instead of 23 a
         // day, every result within an ulp or two of the reference's.
         // -DRR_HBV_CONTRACT=0 builds the reference's own sequence below.
-        // potential / actual evapotranspiration (:102-108); the select picks
-        // the factor, 1 or soil/PWP, so that the product with pe goes into
-        // the soil update's FMA
-        // (1 + C dtemp) PE_m as PE_m + C (dtemp PE_m): the forcing
-        // record carries the product
-        const double pe = __builtin_fma(C, f.dtemp, f.pe_m);
-        // min(soil/PWP, 1) for a lane with a positive, usable PWP -- what the
-        // reference's `if soil > PWP` selects, in one instruction (a NaN soil
-        // has made soil_lw NaN already) --, the select itself for any other
-        // lane; a tame wave has only lanes of the first kind
-        double dry;
-        if constexpr (decltype(tame)::value) {
-            const double ratio = inv_mul_core(soil, inv_PWP);
-            asm("v_min_f64 %0, %1, 1.0" : "=v"(dry) : "v"(ratio));
-        } else {
-            const double ratio = mul_by_inverse_m(soil, inv_PWP, pwp_m);
-            double least;
-            asm("v_min_f64 %0, %1, 1.0" : "=v"(least) : "v"(ratio));
-            dry = pwp_pos ? least : ((soil > PWP) ? 1.0 : ratio);
-        }
-
         // soil moisture (:111)
         const double soil_n = __builtin_fma(-pe, dry, soil_lw - prec_eff);
 
         // near-surface reservoir (:114-118): s1 - s1 K_1 - s1 K_p as
         // s1 (1 - K_1 - K_p), the factor a loop invariant
-        const double over = nb_max(0.0, s1 - L) * K_0;
         const double s1_n = __builtin_fma(s1, keep_1, prec_eff - over);
-
-        // base-flow reservoir (:121-123), likewise s2 (1 - K_2) + s1 K_p
-        const double s2_n = __builtin_fma(s2, keep_2, s1 * K_p);
 
         // discharge mixes old and new states (:125-127)
         const double q =
@@ -608,9 +685,11 @@ hbvedu_kernel(
                     !__builtin_signbit(snow_init) &&
                     (rr_exec() & ~lanes_of_class(DD, 0x3c3)) == 0;
 #if RR_HBV_CONTRACT && RR_FAITHFUL_QUOTIENTS
-        // ... and both divisors usable, PWP positive (day_step)
+        // ... and both divisors usable, PWP positive; K_0 +0 or a positive
+        // number, L finite (day_step)
         tame_wave = tame_wave &&
-                    (rr_exec() & ~(fc_m & RR_LANES(pwp_pos))) == 0;
+                    (rr_exec() & ~(fc_m & RR_LANES(pwp_pos) &
+                                   k0_folds_m)) == 0;
 #endif
     }
     if constexpr (TAME) {
@@ -674,6 +753,25 @@ extern "C" size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N)
     return hbv_forcing_bytes(T, 1) + hbv_tile_bytes(N, 1);
 }
 
+// Pieces for a sweep of `waves` equal jobs on `slots` persistent waves
+// (slots / 2 < waves <= slots): with p pieces the p * waves items take
+// ceil(p * waves / slots) rounds of 1 / p of a job each; the smallest p (from
+// 4 to 48, pieces of at least 128 days) whose rounds come within 1 % of the
+// work itself, waves / slots -- or the best there is.  0: nothing to gain.
+static int hbv_small_pieces(int64_t waves, int64_t slots, int64_t T)
+{
+    if (waves <= 0 || waves >= slots) return 0;
+    const double ideal = (double)waves / (double)slots;
+    int best = 0;
+    double best_cost = 1.0;
+    for (int p = 4; p <= 48 && T / p >= 128; ++p) {
+        const double cost = (double)rr_ceil_div((int64_t)p * waves, slots) / p;
+        if (cost < best_cost - 1e-12) { best_cost = cost; best = p; }
+        if (cost <= ideal * 1.01) break;
+    }
+    return best_cost < 0.985 ? best : 0;
+}
+
 // Shared by the single- and multi-catchment entry points.
 static int hbv_launch(const double *temp, const double *prec,
                       const int8_t *month, const double *PE_m,
@@ -712,21 +810,44 @@ static int hbv_launch(const double *temp, const double *prec,
     // MI355X)
     const int64_t simds = rr_simd_count();
     const bool two_per_simd = waves > simds && waves <= 2 * simds;
-    int variant = (two_per_simd || waves > 10 * simds) ? 0 : 2;
+    // loop variant by sweep size: up to two waves per SIMD a day is a
+    // latency chain per wave, and the loop that asks for its record two days
+    // ahead (3) wins (round 4, kernel ms 0 / 3: 65k sets 3.04 / 2.48, 100k
+    // 3.01 / 2.59, 125k 3.08 / 2.88, 250k 6.00 / 5.87); the mid-day prefetch
+    // (2) up to ten; the plain loop beyond, where a SIMD always has a wave
+    // ready.  rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one.
+    int variant = waves <= 2 * simds ? 3 : (waves > 10 * simds ? 0 : 2);
     const int64_t pinned = rr_option(RR_OPT_HBV_VARIANT);
     if (pinned >= 0) variant = (int)pinned;
-    // time-tiled persistent form (hbvedu_kernel's TILED): for sweeps of many
-    // rounds of waves, where equal-length waves quantise the kernel time to
-    // whole wave slots (1M sets: 16 slots for 15.26 slots of work).
-    // RR_OPT_TIME_TILES: -1 by sweep size (4 pieces from ten waves per SIMD
-    // on), 0 never, k > 1 pieces.
+    // time-tiled persistent form (hbvedu_kernel's TILED), variants 0 and 3:
+    //  * sweeps of many rounds of waves, where equal-length waves quantise
+    //    the kernel time to whole wave slots (1M sets: 16 slots for 15.26
+    //    slots of work): four pieces, as many waves as are resident;
+    //  * sweeps of between one and two waves per SIMD (one GPU's shard of a
+    //    million sets over eight: 1,954 waves on 1,024 SIMDs, 2 slots for
+    //    1.91 slots of work): exactly two waves per SIMD and as many pieces
+    //    as make the items fill whole rounds of those slots
+    //    (hbv_small_pieces) -- MEASURED AND NOT USED (HBV_SMALL_TILES = 0):
+    //    with two waves on a SIMD nobody covers an item's own latencies
+    //    (ticket, flag, acquire, five state loads, parameters; at its end
+    //    the release that drains its stores): 125k sets 2.82 ms untiled,
+    //    3.31 with 11 pieces, 3.85 with 22, 5.24 with 44 -- about 50 us per
+    //    round of items, against the 0.13 ms the quantisation costs.  An
+    //    explicit RR_OPT_TIME_TILES = k still runs it.
+    // RR_OPT_TIME_TILES: -1 by sweep size, 0 never, k > 1 pieces.
     int pieces = 0;
+    int64_t resident_cap = 0;           // 0: what the occupancy query says
     {
         const int64_t opt = rr_option(RR_OPT_TIME_TILES);
-        if (variant == 0 && !two_per_simd && T > 16 &&
-            waves * (opt > 1 ? opt : 4) < 0x7fffffff) {
+        if ((variant == 0 || variant == 3) && T > 16 &&
+            waves * (opt > 1 ? opt : 64) < 0x7fffffff) {
             if (opt > 1) pieces = (int)opt;
-            else if (opt < 0 && waves > 10 * simds) pieces = 4;
+            else if (opt < 0 && variant == 0 && waves > 10 * simds) pieces = 4;
+#if HBV_SMALL_TILES
+            else if (opt < 0 && variant == 3 && two_per_simd)
+                pieces = hbv_small_pieces(waves, 2 * simds, T);
+#endif
+            if (pieces > 1 && waves <= 2 * simds) resident_cap = 2 * simds;
         }
     }
     int *queue = nullptr;
@@ -739,12 +860,12 @@ static int hbv_launch(const double *temp, const double *prec,
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
                  [&](auto Q, auto S, auto E) {
         auto go = [&](auto V, auto tame) {
-            if constexpr (V.value == 0 && tame.value) {
+            if constexpr ((V.value == 0 || V.value == 3) && tame.value) {
                 if (pieces > 1) {
                     auto kern = C == 1 ? hbvedu_kernel<Q.value, S.value,
-                                                       E.value, 0, true, 1>
+                                                       E.value, V.value, true, 1>
                                        : hbvedu_kernel<Q.value, S.value,
-                                                       E.value, 0, true, 2>;
+                                                       E.value, V.value, true, 2>;
                     // as many waves as are resident at once, no more
                     int per_cu = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
@@ -754,6 +875,8 @@ static int hbv_launch(const double *temp, const double *prec,
                         per_cu = 16;
                     }
                     int64_t resident = (int64_t)per_cu * (simds / 4);
+                    if (resident_cap > 0 && resident > resident_cap)
+                        resident = resident_cap;
                     const int64_t items = (int64_t)pieces * waves;
                     if (resident > items) resident = items;
                     kern<<<dim3((unsigned)resident), dim3(RR_BLOCK), 0, st>>>(
@@ -769,8 +892,6 @@ static int hbv_launch(const double *temp, const double *prec,
                     params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
                     odd_prec, nullptr, nullptr, 0, (int)C);
         };
-        // (measured, kernel ms with / without the second loop copy: 65k sets
-        // 3.14 / 3.22, 125k 3.76 / 3.70, 250k 7.45 / 7.62, 1M 27.4 / 27.8)
         if (variant == 1) go(std::integral_constant<int, 1>{}, std::false_type{});
         else if (variant == 2) go(std::integral_constant<int, 2>{}, std::true_type{});
         else if (variant == 3) go(std::integral_constant<int, 3>{}, std::true_type{});

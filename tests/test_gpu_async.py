@@ -103,6 +103,65 @@ def test_two_streams_overlap(env):
     assert torch.equal(q1, qa)
 
 
+@pytest.mark.timeout(300)
+def test_tiled_sweeps_share_the_gpu_without_deadlock(env):
+    """Time-tiled sweeps draw their work items as tickets from an atomic
+    counter (csrc/common.h "the time axis in pieces"), so an item only ever
+    waits for one that a RUNNING wave holds -- no assumption about the order
+    in which the dispatcher starts workgroups, or about who else is on the
+    GPU.  Here two tiled GR4J sweeps and a tiled Cemaneige and HBV-Edu sweep
+    run on four streams while a fifth holds every CU busy with a spin kernel
+    (rrdbg_spin_dev) for the first 30 ms: all complete, with the bits of the
+    untiled runs.  (Rounds 1-3 took the item from blockIdx and could only
+    bound the wait; the launch failed after 2^26 polls.)"""
+    import ctypes
+    torch, dev, models, syn, f = env
+    from rrmpg_amd import _lib
+    from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+    lib = _lib.load()
+    spin = lib.rrdbg_spin_dev
+    spin.restype = ctypes.c_int
+    spin.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]
+    n = 70_000                       # ~1100 waves: a bit more than one round
+    layers, _ = prepare_snow_inputs(f["prec"], f["temp"] - 3, f["tmin"] - 3,
+                                    f["tmax"] - 3, syn.STATION_HEIGHT, 0, 0,
+                                    list(syn.ALTITUDES))
+    jobs = []
+    for k in range(2):
+        jobs.append((dev.GR4JEnsemble(f["prec"], f["etp"], **syn.GR4J_INITS),
+                     dev.sample_params(models.GR4J(), n, 10 + k)))
+    jobs.append((dev.CemaneigeEnsemble(layers[0], layers[1], layers[2]),
+                 dev.sample_params(models.Cemaneige(), n, 12)))
+    jobs.append((dev.HBVEduEnsemble(f["temp"], f["prec"], f["month"],
+                                    f["PE_m"], f["T_m"], **syn.HBV_INITS),
+                 dev.sample_params(models.HBVEdu(), n, 13)))
+    with _lib.debug_option("time_tiles", 0), \
+            _lib.debug_option("hbv_variant", 0):
+        plain = []
+        for ens, p in jobs:
+            q = ens.new_output(n)
+            ens.run(p, q)
+            plain.append(q)
+        torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in jobs]
+    hold = torch.cuda.Stream()
+    for pieces in (4, 7):
+        outs = [ens.new_output(n) for ens, _ in jobs]
+        torch.cuda.synchronize()
+        with _lib.debug_option("time_tiles", pieces), \
+                _lib.debug_option("hbv_variant", 0):
+            _lib.check(spin(4096, 30_000, hold.cuda_stream), "rrdbg_spin_dev")
+            for (ens, p), q, st in zip(jobs, outs, streams):
+                with torch.cuda.stream(st):
+                    ens.run(p, q)
+            _lib.check(spin(2048, 5_000, hold.cuda_stream), "rrdbg_spin_dev")
+        torch.cuda.synchronize()
+        for (ens, _), q, want in zip(jobs, outs, plain):
+            if hasattr(ens, "check"):
+                ens.check()
+            assert torch.equal(q, want), (pieces, type(ens).__name__)
+
+
 def test_unusable_x4_is_reported_by_check(env, oracle):
     torch, dev, models, syn, f = env
     t = 400
