@@ -26,6 +26,53 @@ def demangle(names):
     return dict(zip(names, out))
 
 
+def loop_lane_moves(body):
+    """(all, hot): v_readlane / v_writelane instructions inside the kernel's
+    INNERMOST loops (the day loops) -- in any of their blocks, and in the
+    blocks laid out between a loop's header and its back edge only (the
+    unlikely slow blocks are placed behind the back edge, out of line).  The
+    asm comments of hipcc name every block's loop: "=>This Inner Loop Header"
+    / "in Loop: Header=BBx_y"."""
+    blocks, cur = [], None
+    for line in body.splitlines():
+        m = re.match(r"^(\.LBB\d+_\d+):(.*)$", line)
+        m2 = re.match(r"^; %bb\.\d+:(.*)$", line)
+        if m or m2:
+            cur = {"label": m.group(1)[2:] if m else None,      # "BBx_y"
+                   "note": (m or m2).group(2) if m else m2.group(1),
+                   "lines": []}
+            blocks.append(cur)
+        elif cur is not None:
+            cur["lines"].append(line)
+    inner = set()
+    for k, b in enumerate(blocks):
+        note = b["note"]
+        # the comment may continue on the following comment line
+        if "This Inner Loop Header" in note or (
+                b["lines"] and "This Inner Loop Header" in b["lines"][0]):
+            inner.add(b["label"])
+    total = hot = 0
+    for hdr in inner:
+        members = [k for k, b in enumerate(blocks)
+                   if b["label"] == hdr or
+                   ("Header=%s " % hdr) in (b["note"] + " ") or
+                   any(("Header=%s " % hdr) in (l + " ") for l in b["lines"][:1])]
+        if not members:
+            continue
+        latch = None
+        for k in members:
+            for l in blocks[k]["lines"]:
+                if re.search(r"s_c?branch\w*\s+\.%s\b" % re.escape(hdr), l):
+                    latch = k if latch is None else max(latch, k)
+        for k in members:
+            n = sum(1 for l in blocks[k]["lines"]
+                    if re.search(r"v_(?:read|write)lane_b32", l))
+            total += n
+            if latch is None or k <= latch:
+                hot += n
+    return total, hot
+
+
 def kernels_of(path):
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "k.s")
@@ -51,6 +98,7 @@ def kernels_of(path):
             scratch=num(r"; ScratchSize: (\d+)", info),
             occupancy=num(r"; Occupancy: (\d+)", info),
             lane_moves=len(re.findall(r"v_(?:read|write)lane_b32", body)),
+            loop_moves=loop_lane_moves(body),
             code=num(r"; codeLenInByte = (\d+)", info)))
     return rows
 
@@ -62,10 +110,16 @@ def main():
              "hipcc flags: `%s`.  Occupancy = waves per SIMD the register "
              "allocation permits (512 VGPRs per lane and SIMD); `lane moves` = "
              "v_readlane/v_writelane instructions in the kernel (SGPR spills "
-             "to VGPR lanes; each executed one is a VALU slot)." %
+             "to VGPR lanes; each executed one is a VALU slot); `in day "
+             "loops` = those of them inside the innermost loops, all blocks "
+             "/ the blocks on the loops' straight path only (the unlikely "
+             "slow blocks lie behind the back edge): what a wave executes "
+             "per day, against what it executes once per launch or work "
+             "item." %
              " ".join(FLAGS[:-2]), "",
              "| file | kernel | VGPRs | SGPRs | LDS B | scratch B | waves/SIMD "
-             "| lane moves | code B |", "|---|---|---|---|---|---|---|---|---|"]
+             "| lane moves | in day loops (all / straight path) | code B |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
     for f in sorted(os.listdir(CSRC)):
         if not f.endswith(".hip"):
             continue
@@ -76,9 +130,11 @@ def main():
             nice = re.sub(r"\(.*", "", nice).replace("void ", "")
             if wanted and not wanted.search(nice):
                 continue
-            lines.append("| %s | `%s` | %s | %s | %s | %s | %s | %s | %s |" % (
+            lines.append("| %s | `%s` | %s | %s | %s | %s | %s | %s | %d / %d "
+                         "| %s |" % (
                 f, nice, r["vgpr"], r["sgpr"], r["lds"], r["scratch"],
-                r["occupancy"], r["lane_moves"], r["code"]))
+                r["occupancy"], r["lane_moves"], r["loop_moves"][0],
+                r["loop_moves"][1], r["code"]))
     out = os.path.join(REPO, "profiles", "%s_isa_metadata.md" % tag)
     with open(out, "w") as fh:
         fh.write("\n".join(lines) + "\n")

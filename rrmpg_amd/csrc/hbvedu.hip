@@ -60,7 +60,22 @@ struct __attribute__((aligned(8))) HbvDay {
                    // rides along so the score needs no second load + wait
 };
 
+// Magnitude up to which a forcing value or an initial state counts as CIVIL
+// (see hbv_civil_lane): beyond it -- or not finite -- every lane of the launch
+// takes the reference's own sequence.
+#define HBV_CIVIL 1e6
+
 // blockIdx.y = catchment (forcing arrays are [C][T], monthly tables [C][12])
+// flags[c][block], one word per block of 256 days, written unconditionally
+// (nothing to zero beforehand):
+//   bit 0  a precipitation value that is negative or -0 (the wrapper rejects
+//          negative values; the C-ABI takes anything): rules out the
+//          kernel's TAME loop copy;
+//   bit 1  a forcing value (temperature, precipitation, temp - T_m, PE_m)
+//          that is not finite or beyond HBV_CIVIL: every lane of the launch
+//          then takes the reference's own sequence (hbv_civil_lane).
+// dtemp_raw[c][t] = temp - T_m[month] as the reference forms it, for that
+// sequence (the day record carries the product with PE_m).
 __global__ void hbv_pack_forcing(const double *__restrict__ temp,
                                  const double *__restrict__ prec,
                                  const int8_t *__restrict__ month,
@@ -68,32 +83,39 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
                                  const double *__restrict__ T_m,
                                  const double *__restrict__ qobs, int64_t T,
                                  HbvDay *__restrict__ days,
-                                 int *__restrict__ odd_prec)
+                                 int *__restrict__ flags,
+                                 double *__restrict__ dtemp_raw)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t c = blockIdx.y;
-    // odd_prec[c][block]: did this block of days see precipitation that is
-    // NaN, negative or -0 (the wrapper rejects negative values; the C-ABI
-    // takes anything)?  Rules out the kernel's TAME loop.  One flag per
-    // block, written unconditionally: nothing to zero beforehand.
-    const double pv = t < T ? prec[c * T + t] : 0.0;
-    const int odd = __syncthreads_or(!(pv >= 0.0) || __builtin_signbit(pv));
-    if (threadIdx.x == 0) odd_prec[c * gridDim.x + blockIdx.x] = odd;
-    if (t >= T) return;
-    const int64_t g = c * T + t;
+    const int64_t g = c * T + (t < T ? t : T - 1);
     int m = month[g];
     m = m < 0 ? 0 : (m > 11 ? 11 : m);   // memory safety only; the wrapper
                                          // has already validated 1..12
     HbvDay d;
     d.temp = temp[g];
     d.prec = prec[g];
-    d.dtemp = temp[g] - T_m[c * 12 + m];
+    const double dtemp = temp[g] - T_m[c * 12 + m];      // :102
     d.pe_m = PE_m[c * 12 + m];
+    d.dtemp = dtemp;
 #if RR_HBV_CONTRACT
     d.dtemp *= d.pe_m;
 #endif
     d.qobs = qobs ? qobs[g] : 0.0;
+    const bool odd = d.prec < 0.0 || (d.prec == 0.0 && __builtin_signbit(d.prec));
+    const bool uncivil = !(fabs(d.temp) <= HBV_CIVIL) ||
+                         !(fabs(d.prec) <= HBV_CIVIL) ||
+                         !(fabs(dtemp) <= HBV_CIVIL) ||
+                         !(fabs(d.pe_m) <= HBV_CIVIL) ||
+                         !(fabs(d.dtemp) <= HBV_CIVIL);
+    const int any_odd = __syncthreads_or(t < T && odd);
+    const int any_uncivil = __syncthreads_or(t < T && uncivil);
+    if (threadIdx.x == 0)
+        flags[c * gridDim.x + blockIdx.x] = (any_odd ? 1 : 0) |
+                                            (any_uncivil ? 2 : 0);
+    if (t >= T) return;
     days[g] = d;
+    dtemp_raw[g] = dtemp;
 }
 
 // The logarithm table of fastpow_tab_core (fastmath.h, pow_tables.h): 4 KiB
@@ -108,6 +130,80 @@ static __device__ __constant__ const FpPowLogEntry HBV_POWLOG_TABLE[FP_POWLOG_N]
 __device__ __attribute__((noinline)) double pow_general(double x, double y)
 {
     return pow(x, y);
+}
+
+// ---- which sets the fast forms serve, and the reference's own day ---------
+// The fast forms of the time loop are restatements of the reference's
+// statements that agree with them to an ulp or two AS LONG AS EVERYTHING IS A
+// NUMBER: a product that overflows on its own is still a number inside an
+// FMA, an infinite store times its retention factor is not the reference's
+// inf - inf, a run-away store (K_0 = 7.5) cancels to an exact zero in one
+// grouping and to 1e-11 in another.  So only CIVIL sets get them: parameters
+// inside a (generous) box of what the model's equations mean -- recession and
+// retention factors in [0, 1], 0 <= Beta <= 64, 0 <= C <= 1, field capacity
+// and wilting point in [1e-3, 1e6] mm, thresholds and the degree-day factor
+// within +-1e6 (DD not negative) -- with forcing and initial states that are
+// numbers of at most 1e6.  Every other set -- zeros, negatives, subnormals,
+// 1e+-200, infinities, NaN -- is computed with the reference's own sequence
+// (hbvedu_model.py:84-127) statement by statement: IEEE quotients, the
+// general pow, separate multiply and add (the file is built
+// -ffp-contract=off), so whatever the reference does with infinities and NaN,
+// day by day, this does too (tests/test_gpu_fuzz.py compares wild sets' NaN /
+// inf pattern with the oracle's over the whole series).
+// Which sequence a lane gets depends on ITS parameters (and on the launch's
+// forcing and initial states) only, never on its wave-mates.  The split is
+// made per WAVE between two kernels, so that the loops that matter carry
+// nothing of the other path: hbvedu_kernel<..., REFERENCE = false> runs the
+// waves whose lanes are all civil and skips the others; the instantiation
+// with REFERENCE = true, launched right behind it, skips the all-civil waves
+// and runs the others -- each lane its own sequence.  (Inlined into the fast
+// loops, or called from them, the reference's day cost the million-set sweep
+// 2-3 ms of 19.7: 17 VGPRs, a wave per SIMD; measured three ways in round 4.)
+__device__ __forceinline__ bool hbv_civil_lane(const double *__restrict__ p)
+{
+    const double T_t = p[0], DD = p[1], FC = p[2], Beta = p[3], C = p[4],
+                 PWP = p[5], K_0 = p[6], K_1 = p[7], K_2 = p[8], K_p = p[9],
+                 L = p[10];
+    // (NaN fails every comparison)
+    return fabs(T_t) <= HBV_CIVIL && DD >= 0.0 && DD <= HBV_CIVIL &&
+           !__builtin_signbit(DD) &&
+           FC >= 1e-3 && FC <= HBV_CIVIL && Beta >= 0.0 && Beta <= 64.0 &&
+           C >= 0.0 && C <= 1.0 && PWP >= 1e-3 && PWP <= HBV_CIVIL &&
+           K_0 >= 0.0 && K_0 <= 1.0 && !__builtin_signbit(K_0) &&
+           K_1 >= 0.0 && K_p >= 0.0 && K_1 + K_p <= 1.0 && K_2 >= 0.0 &&
+           K_2 <= 1.0 && fabs(L) <= HBV_CIVIL;
+}
+
+struct HbvRefDay { double snow, soil, s1, s2, q; };
+// One day of the reference's own sequence (hbvedu_model.py:84-127).
+__device__ __forceinline__ HbvRefDay hbv_reference_day(
+    const double *__restrict__ p, double temp, double prec, double dtemp,
+    double pe_m, double snow, double soil, double s1, double s2)
+{
+    const double T_t = p[0], DD = p[1], FC = p[2], Beta = p[3], C = p[4],
+                 PWP = p[5], K_0 = p[6], K_1 = p[7], K_2 = p[8], K_p = p[9],
+                 L = p[10];
+    HbvRefDay r;
+    double lw;
+    if (temp < T_t) {                                          // :87-91
+        r.snow = snow + prec;
+        lw = 0.0;
+    } else {                                                   // :92-96
+        const double melt = DD * (temp - T_t);
+        r.snow = nb_max(0.0, snow - melt);
+        lw = prec + nb_min(snow, melt);
+    }
+    const double prec_eff = lw * pow(soil / FC, Beta);         // :99
+    const double pe = (1 + C * dtemp) * pe_m;                  // :102
+    double ea;                                                 // :105-108
+    if (soil > PWP) ea = pe;
+    else ea = pe * (soil / PWP);
+    r.soil = soil + lw - prec_eff - ea;                        // :111
+    const double spill = nb_max(0.0, s1 - L) * K_0;
+    r.s1 = s1 + prec_eff - spill - s1 * K_1 - s1 * K_p;        // :114-118
+    r.s2 = s2 + s1 * K_p - s2 * K_2;                           // :121-123
+    r.q = spill + r.s1 * K_1 + r.s2 * K_2;                     // :125-127
+    return r;
 }
 
 // blockIdx.y = catchment.  A single-catchment launch has gridDim.y == 1; a
@@ -157,7 +253,7 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 #define HBV_INDEPENDENT_IN_ARMS 0
 #endif
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
-          bool TAME = true, int TILED = 0>
+          bool TAME = true, int TILED = 0, bool REFERENCE = false>
 __global__ __launch_bounds__(RR_BLOCK, (TILED ? HBV_TILED_MINWAVES : 1)) void
 hbvedu_kernel(
     const HbvDay *__restrict__ days, int64_t T, double snow_init,
@@ -166,9 +262,9 @@ hbvedu_kernel(
     int64_t N, double *__restrict__ qsim, double *__restrict__ snow_out,
     double *__restrict__ soil_out, double *__restrict__ s1_out,
     double *__restrict__ s2_out, int64_t ld, const double *__restrict__ qobs,
-    double *__restrict__ sse, const int *__restrict__ odd_prec,
-    int *__restrict__ queue, double *__restrict__ tile_state, int pieces,
-    int ncatch)
+    double *__restrict__ sse, const int *__restrict__ day_flags,
+    const double *__restrict__ dtemp_raw, int *__restrict__ queue,
+    double *__restrict__ tile_state, int pieces, int ncatch)
 {
     __shared__ FpPowLogEntry powlog[FP_POWLOG_N];
     for (int j = threadIdx.x; j < FP_POWLOG_N; j += RR_BLOCK)
@@ -207,6 +303,7 @@ hbvedu_kernel(
     if constexpr (TILED != 1) {
         const int64_t c = catchment;           // wave-uniform
         days += c * T;
+        if (REFERENCE) dtemp_raw += c * T;
         params += c * N * 11;
         const int64_t out_off = c * T * ld;
         if (WRITE_Q) qsim += out_off;
@@ -225,6 +322,35 @@ hbvedu_kernel(
     const double T_t = p[0], DD = p[1], FC = p[2], Beta = p[3], C = p[4],
                  PWP = p[5], K_0 = p[6], K_1 = p[7], K_2 = p[8], K_p = p[9],
                  L = p[10];
+    // Which kernel runs this wave (hbv_civil_lane): this one if REFERENCE
+    // says so.  (bit 1 of the pre-pass's flags: a forcing value that is not
+    // civil.)
+    bool lane_civil;
+    {
+        const int nb = (int)((T + 255) / 256);
+        const int *flags = day_flags + (int64_t)catchment * nb;
+        lanemask_t uncivil = 0;
+        for (int k = threadIdx.x; k - (int)threadIdx.x < nb; k += RR_BLOCK)
+            uncivil |= RR_LANES(k < nb && (flags[k] & 2) != 0);
+        lane_civil = uncivil == 0 && fabs(snow_init) <= HBV_CIVIL &&
+                     fabs(soil_init) <= HBV_CIVIL &&
+                     fabs(s1_init) <= HBV_CIVIL &&
+                     fabs(s2_init) <= HBV_CIVIL && hbv_civil_lane(p);
+        const bool wave_civil = (rr_exec() & ~RR_LANES(lane_civil)) == 0;
+        if (wave_civil == REFERENCE) {
+            // not this kernel's wave.  (A piece of the time axis still tells
+            // the next one, which is skipped just the same, not to wait.)
+            if constexpr (TILED) {
+                if (piece + 1 < pieces && threadIdx.x == 0)
+                    __hip_atomic_store(queue + 1 + slot, piece + 1,
+                                       __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            } else {
+                break;
+            }
+        }
+    }
 
     const InvDivisor inv_FC = make_inv_divisor(FC);
     const InvDivisor inv_PWP = make_inv_divisor(PWP);
@@ -538,9 +664,23 @@ hbvedu_kernel(
 
 #endif
 
-        snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
+        double q_c = q;
+        if constexpr (REFERENCE) {
+            // each lane its own sequence: a civil lane the fast forms (the
+            // bits it has in any other launch), every other lane the
+            // reference's own day, from the same start states
+            const HbvRefDay r = hbv_reference_day(
+                p, f.temp, f.prec, dtemp_raw[t], f.pe_m, snow, soil, s1, s2);
+            snow = lane_civil ? snow_n : r.snow;
+            soil = lane_civil ? soil_n : r.soil;
+            s1 = lane_civil ? s1_n : r.s1;
+            s2 = lane_civil ? s2_n : r.s2;
+            q_c = lane_civil ? q : r.q;
+        } else {
+            snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
+        }
 
-        if (WRITE_Q) rr_store_row(qsim + row, row_bytes, lane_off, q, true);
+        if (WRITE_Q) rr_store_row(qsim + row, row_bytes, lane_off, q_c, true);
         if (WRITE_S) {
             rr_store_row(snow_out + row, row_bytes, lane_off, snow);
             rr_store_row(soil_out + row, row_bytes, lane_off, soil);
@@ -548,7 +688,7 @@ hbvedu_kernel(
             rr_store_row(s2_out + row, row_bytes, lane_off, s2);
         }
         if (WITH_SSE) {
-            const double d = f.qobs - q;
+            const double d = f.qobs - q_c;
             acc = __builtin_fma(d, d, acc);   // one rounding per day
         }
         (void)t;
@@ -677,10 +817,10 @@ hbvedu_kernel(
     if constexpr (TAME) {
         // any flag of this catchment's pre-pass blocks set?
         const int nb = (int)((T + 255) / 256);
-        const int *flags = odd_prec + (int64_t)catchment * nb;
+        const int *flags = day_flags + (int64_t)catchment * nb;
         lanemask_t odd = 0;
         for (int k = threadIdx.x; k - (int)threadIdx.x < nb; k += RR_BLOCK)
-            odd |= RR_LANES(k < nb && flags[k] != 0);
+            odd |= RR_LANES(k < nb && (flags[k] & 1) != 0);
         tame_wave = odd == 0 && snow_init >= 0.0 &&
                     !__builtin_signbit(snow_init) &&
                     (rr_exec() & ~lanes_of_class(DD, 0x3c3)) == 0;
@@ -718,14 +858,16 @@ hbvedu_kernel(
   }
 }
 
-// forcing records (+ 2: the spare records the prefetching variants may touch)
-// and the pre-pass's flags of odd precipitation values (one int per 256 days)
+// forcing records (+ 2: the spare records the prefetching variants may
+// touch), the pre-pass's flags (one int per 256 days) and, behind them, the
+// raw temp - T_m series of the reference's own day
 static size_t hbv_forcing_bytes(int64_t T, int64_t C)
 {
     if (T < 1) T = 1;
     if (C < 1) C = 1;
     return rr_align256((size_t)(T * C + 2) * sizeof(HbvDay) +
-                       (size_t)rr_ceil_div(T, 256) * (size_t)C * sizeof(int));
+                       (size_t)rr_ceil_div(T, 256) * (size_t)C * sizeof(int)) +
+           rr_align256((size_t)T * (size_t)C * 8);
 }
 // the tiled kernel's work queue {counter, flag per job} and its hand-over
 // scratch [5][jobs * 64]
@@ -789,11 +931,15 @@ static int hbv_launch(const double *temp, const double *prec,
         return RR_E_SIZE;
     }
     HbvDay *days = (HbvDay *)workspace;
-    int *odd_prec = (int *)(days + (size_t)T * (size_t)C + 2);
+    int *day_flags = (int *)(days + (size_t)T * (size_t)C + 2);
+    double *dtemp_raw = (double *)((char *)workspace +
+                                   hbv_forcing_bytes(T, C) -
+                                   rr_align256((size_t)T * (size_t)C * 8));
     hipLaunchKernelGGL(hbv_pack_forcing,
                        dim3((unsigned)rr_ceil_div(T, 256), (unsigned)C),
                        dim3(256), 0, st, temp, prec, month, PE_m, T_m,
-                       (qobs && sse) ? qobs : nullptr, T, days, odd_prec);
+                       (qobs && sse) ? qobs : nullptr, T, days, day_flags,
+                       dtemp_raw);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK), (unsigned)C);
     const bool any_s = snow != nullptr;
     // forcing variant: 0 one scalar load at the top of each day; 1 LDS
@@ -882,7 +1028,8 @@ static int hbv_launch(const double *temp, const double *prec,
                     kern<<<dim3((unsigned)resident), dim3(RR_BLOCK), 0, st>>>(
                         days, T, snow_init, soil_init, s1_init, s2_init, inits,
                         params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
-                        odd_prec, queue, tile_state, pieces, (int)C);
+                        day_flags, dtemp_raw, queue, tile_state, pieces,
+                        (int)C);
                     return;
                 }
             }
@@ -890,7 +1037,7 @@ static int hbv_launch(const double *temp, const double *prec,
                 <<<grid, dim3(RR_BLOCK), 0, st>>>(
                     days, T, snow_init, soil_init, s1_init, s2_init, inits,
                     params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
-                    odd_prec, nullptr, nullptr, 0, (int)C);
+                    day_flags, dtemp_raw, nullptr, nullptr, 0, (int)C);
         };
         if (variant == 1) go(std::integral_constant<int, 1>{}, std::false_type{});
         else if (variant == 2) go(std::integral_constant<int, 2>{}, std::true_type{});
@@ -901,6 +1048,14 @@ static int hbv_launch(const double *temp, const double *prec,
         else if (two_per_simd) go(std::integral_constant<int, 0>{}, std::false_type{});
 #endif
         else go(std::integral_constant<int, 0>{}, std::true_type{});
+        // ... and, right behind it, the kernel of the waves that hold a set
+        // which is not civil (hbv_civil_lane): every other wave returns at
+        // once (30 us of a million-set sweep)
+        hbvedu_kernel<Q.value, S.value, E.value, 0, false, 0, true>
+            <<<grid, dim3(RR_BLOCK), 0, st>>>(
+                days, T, snow_init, soil_init, s1_init, s2_init, inits,
+                params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
+                day_flags, dtemp_raw, nullptr, nullptr, 0, (int)C);
     });
     RR_HIP(hipGetLastError());
     return RR_OK;
