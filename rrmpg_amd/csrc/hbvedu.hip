@@ -149,7 +149,7 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y)
 // general pow, separate multiply and add (the file is built
 // -ffp-contract=off), so whatever the reference does with infinities and NaN,
 // day by day, this does too (tests/test_gpu_fuzz.py compares wild sets' NaN /
-// inf pattern with the oracle's over the whole series).
+// inf pattern with the CPU restatement's over the whole series).
 // Which sequence a lane gets depends on ITS parameters (and on the launch's
 // forcing and initial states) only, never on its wave-mates.  The split is
 // made per WAVE between two kernels, so that the loops that matter carry
