@@ -114,7 +114,12 @@ __global__ void cema_gt_table(double *__restrict__ gtresh, int L, int nreg)
 // TILED: the time axis in pieces, one workgroup per ticket (common.h RrTiles:
 // million-set sweeps); handed over: both snow states of every layer and the
 // score sum.
-template <int L, bool TILED = false>
+// GTR (sweeps of at most two waves per SIMD): the melt thresholds in VGPR
+// pairs and the potential melt by select instead of a scalar load and an
+// exec-masked block per melting layer -- nobody hides the load's latency
+// there (125k sets, scores: 7.6 -> 6.9 ms); with a SIMD full of waves the
+// scalar form is the faster one (1M sets 34.1 vs 38.8 ms).  Same bits.
+template <int L, bool TILED = false, bool GTR = false>
 __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const double *__restrict__ days, const double *__restrict__ gtresh,
     int64_t T, double snow_pack_init, double thermal_state_init,
@@ -140,6 +145,8 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
     const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
     const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
+    CemaGtRegs<L> gt_regs;
+    if (GTR) cema_gt_to_regs<L>(gt_tab, gt_regs);
     double acc = 0.0;
     const bool wq = outflow != nullptr, ws = G_out != nullptr,
                we = sse != nullptr;
@@ -173,9 +180,10 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
 #pragma unroll
         for (int k = 0; k < D; ++k) rec[k] = days[t * D + k];
         const double q =
-            cema_day<L, decltype(is_first)::value, false, decltype(sane)::value>(
+            cema_day<L, decltype(is_first)::value, GTR,
+                     decltype(sane)::value>(
                 rec, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
-                omc, Kf, G, eTG);
+                omc, Kf, G, eTG, GTR ? &gt_regs : nullptr);
         // output rows: wave-uniform base + lane offset (common.h
         // rr_store_row): no per-lane address arithmetic, no exec masking of
         // the tail wave, and -- unlike eleven strength-reduced row pointers --
@@ -923,6 +931,10 @@ extern "C" int rr_cemaneige_simulate_dev(
                 <<<dim3((unsigned)((int64_t)tiles.pieces * grid.x)), block, 0,
                    st>>>(days, gt, T, snow_pack_init, thermal_state_init,
                          params, N, outflow, G, eTG, ld, qo, sse, tiles);
+        else if ((int64_t)grid.x <= 2 * (int64_t)rr_simd_count())
+            cemaneige_kernel<LL.value, false, true><<<grid, block, 0, st>>>(
+                days, gt, T, snow_pack_init, thermal_state_init, params, N,
+                outflow, G, eTG, ld, qo, sse, tiles);
         else
             cemaneige_kernel<LL.value><<<grid, block, 0, st>>>(
                 days, gt, T, snow_pack_init, thermal_state_init, params, N,

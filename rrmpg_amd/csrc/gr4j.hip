@@ -271,18 +271,31 @@ void gr4j_opt_kernel(
         }
     }
     int64_t row = first + (int64_t)k_begin * ld;
-    GrDay f;
-    f.net = dp[k_begin].net; f.qobs = dp[k_begin].qobs;
-    f.wet = dp[k_begin].wet; f.net_ok = dp[k_begin].net_ok;
-    auto day = [&](const double s_in, const double r_in,
-                   const typename UH::Slots &u_in, double &s_out,
-                   double &r_out, typename UH::Slots &u_out, int k)
+    // Two day records alternate with the two state generations: day k reads
+    // its record at its top and, in its middle, requests the record of day
+    // k + 2 into the same registers -- a day and a half ahead (the records of
+    // two more days than the run has are there to be touched).  Scalar loads
+    // return out of order, so every wait is for all of them: the `use` of the
+    // OTHER record right before the request makes that wait explicit where
+    // the record, asked for a day ago, has long arrived.  (Until round 4: one
+    // record, requested half a day ahead.)
+    GrDay fa, fb;
+    fa.net = dp[k_begin].net; fa.qobs = dp[k_begin].qobs;
+    fa.wet = dp[k_begin].wet; fa.net_ok = dp[k_begin].net_ok;
+    fb.net = dp[k_begin + 1].net; fb.qobs = dp[k_begin + 1].qobs;
+    fb.wet = dp[k_begin + 1].wet; fb.net_ok = dp[k_begin + 1].net_ok;
+    auto day = [&](GrDay &f, const GrDay &other, const double s_in,
+                   const double r_in, const typename UH::Slots &u_in,
+                   double &s_out, double &r_out, typename UH::Slots &u_out,
+                   int k)
         __attribute__((always_inline)) {
         const double net = f.net, qobs_k = f.qobs;
         const bool wet = f.wet != 0;
         const lanemask_t net_m = f.net_ok ? ~0ull : 0ull;
         auto fetch_next = [&]() {
-            day_ptr_t nx = dp + (k + 1);
+            asm volatile("" : : "s"(other.net), "s"(other.qobs),
+                         "s"(other.wet), "s"(other.net_ok));
+            day_ptr_t nx = dp + (k + 2);
             asm volatile("" : "+s"(nx));         // keeps the load at this spot
             f.net = nx->net; f.qobs = nx->qobs; f.wet = nx->wet;
             f.net_ok = nx->net_ok;
@@ -315,8 +328,8 @@ void gr4j_opt_kernel(
         row += ld;
     };
     for (int k = k_begin; k < k_end; k += 2) {
-        day(sa, ra, ua, sb, rb, ub, k);
-        if (k + 1 < k_end) day(sb, rb, ub, sa, ra, ua, k + 1);
+        day(fa, fb, sa, ra, ua, sb, rb, ub, k);
+        if (k + 1 < k_end) day(fb, fa, sb, rb, ub, sa, ra, ua, k + 1);
     }
     if (TILED != 0 && piece + 1 < tiles.pieces) {
         // (an even number of days: the states are back in generation a)
@@ -484,12 +497,12 @@ gr4j_pipe_kernel(
     }
 }
 
-// plan + day records (+ one spare record: the kernel requests day k+1's in
-// the middle of day k)
+// plan + day records (+ three spare records: the kernels request the record
+// of up to two days ahead, the last day included)
 static size_t gr4j_days_bytes(int64_t T)
 {
     if (T < 1) T = 1;
-    return 256 + rr_align256((size_t)(T + 1) * sizeof(GrDay));
+    return 256 + rr_align256((size_t)(T + 3) * sizeof(GrDay));
 }
 // ... + the tiled kernels' work queue and hand-over scratch (common.h RrTiles)
 #define GR4J_TILE_STATES (gr4j_tile_states<UhRegs<5>>())

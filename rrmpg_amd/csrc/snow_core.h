@@ -132,6 +132,9 @@ __device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 // in VGPR pairs, cema_gt_to_regs) instead of a scalar load from the table at
 // the point of use -- the small-sweep kernels, which have registers to spare
 // and nobody to hide a load's latency behind.
+#ifndef CEMA_GT_SELECT_FORM
+#define CEMA_GT_SELECT_FORM 1
+#endif
 template <int L>
 struct CemaGtRegs { double gt[L], rgt[L]; };
 
@@ -197,7 +200,7 @@ __device__ __forceinline__ double cema_day_io(
             if (e > 0) e = 0.0;
         }
         double pot_melt = 0.0;                             // :99-106
-        if (SANE && !FIRST && GT_REGS) {
+        if (SANE && !FIRST && GT_REGS && CEMA_GT_SELECT_FORM) {
             // (the small-sweep kernels evaluate it for every lane and select:
             // no exec-masked block, no branch over it -- at two waves per
             // SIMD the scalar work of a branch is not hidden: 125k sets
