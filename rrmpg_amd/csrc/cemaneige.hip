@@ -925,13 +925,19 @@ extern "C" int rr_cemaneige_simulate_dev(
             RR_HIP(hipMemsetAsync(tiles.queue, 0, rr_tile_queue_bytes(N), st));
         }
     }
+    // (RR_OPT_FUSED_VARIANT pins the form here too: 1 the many-waves kernel,
+    // 2 / 3 the small-sweep one)
+    const int64_t pinned = rr_option(RR_OPT_FUSED_VARIANT);
+    const bool small_form =
+        pinned == 1 ? false : (pinned == 2 || pinned == 3) ? true
+        : (int64_t)grid.x <= 2 * (int64_t)rr_simd_count();
     dispatch_layers((int)L, [&](auto LL) {
         if (tiles.pieces > 1)
             cemaneige_kernel<LL.value, true>
                 <<<dim3((unsigned)((int64_t)tiles.pieces * grid.x)), block, 0,
                    st>>>(days, gt, T, snow_pack_init, thermal_state_init,
                          params, N, outflow, G, eTG, ld, qo, sse, tiles);
-        else if ((int64_t)grid.x <= 2 * (int64_t)rr_simd_count())
+        else if (small_form)
             cemaneige_kernel<LL.value, false, true><<<grid, block, 0, st>>>(
                 days, gt, T, snow_pack_init, thermal_state_init, params, N,
                 outflow, G, eTG, ld, qo, sse, tiles);

@@ -385,6 +385,17 @@ def test_cemaneige_vs_oracle(models, oracle):
                                         return_storages=True)
         for k, (a, b) in enumerate(zip(out, ref)):
             snow_same(a, b, exact=(k == 2), what=nl)
+        # the kernel's two forms (melt thresholds from the scalar cache: the
+        # many-waves form; in VGPR pairs, potential melt by select: sweeps of
+        # at most two waves per SIMD, the default at this size): same bits
+        from rrmpg_amd import _lib
+        with _lib.debug_option("fused_variant", 1):
+            many = models.Cemaneige().simulate(
+                p["prec"][:900], p["temp"][:900], p["tmin"][:900],
+                p["tmax"][:900], 500, 3.0, -1.0, altitudes=alts,
+                return_storages=True, params=_records(models.Cemaneige, fl))
+        for a, b in zip(out, many):
+            assert np.array_equal(a, b), nl
     # more than 8 layers: states move from registers to an HBM scratch, the
     # results stay the same
     from rrmpg_amd.models import cemaneige_utils as cu
