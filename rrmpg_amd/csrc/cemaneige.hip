@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "snow_core.h"
+#include "gr4j_reference.h"
 
 // days: [T][D] doubles, D = cema_record_len(L, with_etp) (snow_core.h):
 //   [0,L) snow, [L,2L) rain, [2L,3L) mean_temp, [3L] etp, then the day's
@@ -39,7 +40,8 @@ __global__ void cema_pack(const double *__restrict__ prec,
                           const double *__restrict__ frac,
                           const double *__restrict__ etp, int64_t T, int L,
                           int D, double *__restrict__ days,
-                          unsigned long long *__restrict__ insane)
+                          unsigned long long *__restrict__ insane,
+                          int *__restrict__ uncivil)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= T * L) return;
@@ -56,6 +58,13 @@ __global__ void cema_pack(const double *__restrict__ prec,
     if (etp && l == 0) d[3 * L] = etp[t];
     if (!(snow >= 0.0 && snow <= 1e290) || !(fabs(temp) <= 1e300))
         atomicAdd(insane, 1ull);
+    // forcing the GR4J half's fast forms are not meant for
+    // (gr4j_reference.h): with any, every set takes the reference's sequence
+    if (uncivil &&
+        (!gr4j_civil_forcing(snow) || !gr4j_civil_forcing(rain) ||
+         !gr4j_civil_forcing(temp) ||
+         (etp && l == 0 && !gr4j_civil_forcing(etp[t]))))
+        atomicAdd(uncivil, 1);
 }
 
 // The trailing slot of every record: the day's observed discharge
@@ -731,7 +740,7 @@ int rr_cema_prepass(const double *prec, const double *mean_temp,
                         const double *frac, const double *etp,
                         const double *qobs, int64_t T, int L, void *workspace,
                         hipStream_t st, double **days_out, double **gt_out,
-                        double **state_out)
+                        double **state_out, int *uncivil)
 {
     const int D = cema_record_len(L, etp != nullptr);
     double *gt = (double *)((char *)workspace + 512);
@@ -740,7 +749,7 @@ int rr_cema_prepass(const double *prec, const double *mean_temp,
     RR_HIP(hipMemsetAsync(insane, 0, sizeof(*insane), st));
     hipLaunchKernelGGL(cema_pack, dim3((unsigned)rr_ceil_div(T * L, 256)),
                        dim3(256), 0, st, prec, mean_temp, frac, etp, T, L, D,
-                       days, insane);
+                       days, insane, uncivil);
     hipLaunchKernelGGL(cema_day_meta, dim3((unsigned)rr_ceil_div(T, 256)),
                        dim3(256), 0, st, days, T, D, qobs);
     hipLaunchKernelGGL(cema_gtresh, dim3((unsigned)L), dim3(256), 0, st, days,
@@ -950,6 +959,67 @@ extern "C" int rr_cemaneige_simulate_dev(
     return RR_OK;
 }
 
+// ---- the reference's own GR4J sequence for the sets that are not civil ------
+// (gr4j_reference.h)  One lane per set, launched behind the fast kernels; a
+// civil set's lane returns at once.  Every other one runs the snow routine as
+// the fast kernels do (it is the reference's sequence but for two quotients
+// taken as one multiply) and the reference's own run_gr4j on its outflow
+// (cemaneigegr4j_model.py:57-62), and overwrites its columns and its score.
+template <int L>
+__global__ __launch_bounds__(RR_BLOCK) void cemaneigegr4j_reference_kernel(
+    CoupledOut o, const double *__restrict__ days,
+    const double *__restrict__ gtresh, int64_t T, double snow_pack_init,
+    double thermal_state_init, double s_init, double r_init,
+    const double *__restrict__ params, int64_t N,
+    const int *__restrict__ plan, double *__restrict__ sse)
+{
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    if (gr4j_plan_tier(plan[0], plan[1], 0, plan[2]) < 0) return;
+    const double *p = params + i * 6;
+    if (plan[3] == 0 && gr4j_civil_set(p[2], p[3], p[4], s_init, r_init) &&
+        gr4j_civil_snow_par(p[0]) && gr4j_civil_snow_par(p[1]) &&
+        gr4j_civil_snow_par(snow_pack_init) &&
+        gr4j_civil_snow_par(thermal_state_init))
+        return;
+    Gr4jRef g;
+    if (!g.init(p[2], p[3], p[4], p[5], s_init, r_init)) return;
+    const double CTG = p[0], Kf = p[1], omc = 1 - CTG;
+    double G[L], eTG[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
+    const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
+    const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
+    constexpr int D = cema_record_len(L, true);
+    double acc = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+        double rec[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) rec[k] = days[t * D + k];
+        const double liquid = t == 0
+            ? cema_day<L, true>(rec, gt_tab, gt_ok, snow_pack_init,
+                                thermal_state_init, CTG, omc, Kf, G, eTG)
+            : cema_day<L, false>(rec, gt_tab, gt_ok, snow_pack_init,
+                                 thermal_state_init, CTG, omc, Kf, G, eTG);
+        const double q = g.day(liquid, rec[3 * L]);
+        if (o.qsim) o.qsim[t * o.ld + i] = q;
+        if (o.G) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                o.G[(t * L + l) * o.ld + i] = G[l];
+                o.eTG[(t * L + l) * o.ld + i] = eTG[l];
+            }
+            o.s_store[t * o.ld + i] = g.s;
+            o.r_store[t * o.ld + i] = g.r;
+        }
+        if (sse) {
+            const double d = rec[D - 1] - q;     // the day's observation
+            acc = __builtin_fma(d, d, acc);
+        }
+    }
+    if (sse) sse[i] = acc;
+}
+
 extern "C" int rr_cemaneigegr4j_simulate_dev(
     const double *prec, const double *mean_temp, const double *etp,
     const double *frac_solid_prec, int64_t T, int64_t L,
@@ -996,7 +1066,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
     double *days, *gt, *state;
     rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp,
                          (qobs && sse) ? qobs : nullptr, T, (int)L, workspace,
-                         st, &days, &gt, &state);
+                         st, &days, &gt, &state, (int *)workspace + 3);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
@@ -1107,6 +1177,11 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                     qsim != nullptr, G != nullptr, qo, sse, uh_mem,
                     RrTiles{nullptr, nullptr, 0});
         });
+        // ... and behind them the sets that are not civil
+        // (gr4j_reference.h)
+        cemaneigegr4j_reference_kernel<LL.value><<<grid, block, 0, st>>>(
+            out, days, gt, T, snow_pack_init, thermal_state_init, s_init,
+            r_init, params, N, d_plan, qo ? sse : nullptr);
     });
     RR_HIP(hipGetLastError());
     return RR_OK;

@@ -10,6 +10,7 @@
 // (gr4j_core.h).  The shared {prec, etp} day record is wave-uniform and is
 // fetched with one scalar s_load_dwordx4 per day.
 #include "gr4j_core.h"
+#include "gr4j_reference.h"
 
 // One day of shared forcing as the kernel wants it (fetched by value with one
 // s_load_dwordx8 per day).  Which branch of the reference's net-rainfall /
@@ -27,14 +28,19 @@ struct __attribute__((aligned(32))) GrDay {
     int pad[2];
 };
 
+// plan[3] counts the forcing values that are not civil (gr4j_reference.h):
+// with any, every set of the launch gets the reference's own sequence.
 __global__ void gr4j_pack_forcing(const double *__restrict__ prec,
                                   const double *__restrict__ etp,
                                   const double *__restrict__ qobs, int64_t T,
-                                  GrDay *__restrict__ days)
+                                  GrDay *__restrict__ days,
+                                  int *__restrict__ plan)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const double p = prec[t], e = etp[t];
+    if (!gr4j_civil_forcing(p) || !gr4j_civil_forcing(e))
+        atomicAdd(&plan[3], 1);
     GrDay d;
     d.wet = p >= e;
     d.net = d.wet ? p - e : e - p;
@@ -497,6 +503,44 @@ gr4j_pipe_kernel(
     }
 }
 
+// ---- the reference's own sequence for the sets that are not civil ---------
+// (gr4j_reference.h)  One lane per set, launched behind the fast kernels;
+// a civil set's lane returns at once, every other one runs the reference's
+// run_gr4j and overwrites its columns and its score.  A launch whose plan
+// runs nothing (a set without unit-hydrograph ordinates) writes nothing here
+// either.
+__global__ __launch_bounds__(RR_BLOCK) void gr4j_reference_kernel(
+    const double *__restrict__ prec, const double *__restrict__ etp,
+    int64_t T, double s_init, double r_init,
+    const double *__restrict__ params, int64_t N,
+    const int *__restrict__ plan, double *__restrict__ qsim,
+    double *__restrict__ s_store, double *__restrict__ r_store, int64_t ld,
+    const double *__restrict__ qobs, double *__restrict__ sse)
+{
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    if (gr4j_plan_tier(plan[0], plan[1], 0, plan[2]) < 0) return;
+    const double *p = params + i * 4;
+    if (plan[3] == 0 && gr4j_civil_set(p[0], p[1], p[2], s_init, r_init))
+        return;
+    Gr4jRef g;
+    if (!g.init(p[0], p[1], p[2], p[3], s_init, r_init)) return;
+    double acc = 0.0;
+    for (int64_t k = 0; k < T; ++k) {
+        const double q = g.day(prec[k], etp[k]);
+        if (qsim) qsim[k * ld + i] = q;
+        if (s_store) {
+            s_store[k * ld + i] = g.s;
+            r_store[k * ld + i] = g.r;
+        }
+        if (sse) {
+            const double d = qobs[k] - q;
+            acc = __builtin_fma(d, d, acc);
+        }
+    }
+    if (sse) sse[i] = acc;
+}
+
 // plan + day records (+ three spare records: the kernels request the record
 // of up to two days ahead, the last day included)
 static size_t gr4j_days_bytes(int64_t T)
@@ -620,7 +664,7 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     if (qobs && sse)
         RR_HIP(hipMemsetAsync(sse, 0xFF, (size_t)N * sizeof(double), st));
     hipLaunchKernelGGL(gr4j_pack_forcing, dim3((unsigned)rr_ceil_div(T, 256)),
-                       dim3(256), 0, st, prec, etp, qobs, T, days);
+                       dim3(256), 0, st, prec, etp, qobs, T, days, d_plan);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const bool q = qsim != nullptr, s = s_store != nullptr, e = qobs && sse;
     const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
@@ -719,6 +763,10 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
                     qsim, s_store, r_store, ld, qobs, sse, uh_mem);
         });
     });
+    // ... and behind them the sets that are not civil (gr4j_reference.h)
+    gr4j_reference_kernel<<<grid, block, 0, st>>>(
+        prec, etp, T, s_init, r_init, params, N, d_plan, qsim, s_store,
+        r_store, ld, e ? qobs : nullptr, e ? sse : nullptr);
     RR_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -40,7 +40,8 @@ static __host__ __device__ constexpr int cema_record_len(int L, bool with_etp)
 int rr_cema_prepass(const double *prec, const double *mean_temp,
                     const double *frac, const double *etp, const double *qobs,
                     int64_t T, int L, void *workspace, hipStream_t st,
-                    double **days_out, double **gt_out, double **state_out);
+                    double **days_out, double **gt_out, double **state_out,
+                    int *uncivil = nullptr);
 
 static inline size_t cema_days_bytes(int64_t T, int64_t L, bool with_etp)
 {

@@ -4,6 +4,7 @@
 // CemaneigeHystGR4JIce).  One fused kernel template, one lane per parameter
 // set, all snow states in registers; see snow_core.h / gr4j_core.h.
 #include "snow_core.h"
+#include "gr4j_reference.h"
 
 // ===========================================================================
 // Next tier: SWE-SCA hysteresis snow routine, ice
@@ -280,6 +281,113 @@ snow_gr4j_kernel(
     if (we && active) sse[i] = acc;
 }
 
+// ---- the reference's own GR4J sequence for the sets that are not civil ------
+// (gr4j_reference.h)  One lane per set, launched behind the fast kernels; a
+// civil set's lane returns at once.  Every other one runs the snow routine
+// (and the ice melt) as the fast kernels do and the reference's own run_gr4j
+// on their outflow (cemaneigehystgr4j_model.py:74-78,
+// cemaneigegr4jice_model.py:88-92), and overwrites its columns and its score.
+template <int L, bool HYST, bool ICE>
+__global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_reference_kernel(
+    SnowOut o, const double *__restrict__ days,
+    const double *__restrict__ gtresh, const double *__restrict__ frac_ice,
+    int64_t T, double snow_pack_init, double thermal_state_init,
+    double sca_init, double s_init, double r_init,
+    const double *__restrict__ params, SnowParLayout lay, int64_t N,
+    const int *__restrict__ plan, double *__restrict__ sse)
+{
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    if (gr4j_plan_tier(plan[0], plan[1], 0, plan[2]) < 0) return;
+    const double *p = params + i * lay.npar;
+    bool snow_civil = gr4j_civil_snow_par(p[0]) && gr4j_civil_snow_par(p[1]) &&
+                      gr4j_civil_snow_par(snow_pack_init) &&
+                      gr4j_civil_snow_par(thermal_state_init) &&
+                      gr4j_civil_snow_par(sca_init);
+    if (HYST)
+        snow_civil = snow_civil && gr4j_civil_snow_par(p[2]) &&
+                     gr4j_civil_snow_par(p[3]);
+    if (ICE) snow_civil = snow_civil && gr4j_civil_snow_par(p[lay.i_ddf]);
+    if (plan[3] == 0 && snow_civil &&
+        gr4j_civil_set(p[lay.i_x1], p[lay.i_x1 + 1], p[lay.i_x1 + 2], s_init,
+                       r_init))
+        return;
+    Gr4jRef g;
+    if (!g.init(p[lay.i_x1], p[lay.i_x1 + 1], p[lay.i_x1 + 2],
+                p[lay.i_x1 + 3], s_init, r_init))
+        return;
+    const double CTG = p[0], Kf = p[1], omc = 1 - CTG;
+    const double Rsp = HYST ? p[3] : 0.0;
+    const InvDivisor inv_Thacc = make_inv_divisor(HYST ? p[2] : 1.0);
+    const lanemask_t thacc_m = RR_LANES(inv_Thacc.ok);
+    const double ddf = ICE ? p[lay.i_ddf] : 0.0;
+    double G[L], eTG[L], sca[L], swe_max[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        G[l] = 0.0; eTG[l] = 0.0; sca[l] = 0.0; swe_max[l] = 0.0;
+    }
+    const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
+    const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
+    const double *psol = gtresh + L;
+    const double sca_prev0 = (T == 1) ? sca_init : 0.0;
+    constexpr int D = cema_record_len(L, true);
+    double acc = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+        double day[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) day[k] = days[t * D + k];
+        double snowmelt;
+        if constexpr (HYST) {
+            snowmelt = t == 0
+                ? cema_hyst_day<L, true>(day, psol, snow_pack_init,
+                                         thermal_state_init, sca_prev0, CTG,
+                                         omc, Kf, inv_Thacc, thacc_m, Rsp, G,
+                                         eTG, sca, swe_max)
+                : cema_hyst_day<L, false>(day, psol, snow_pack_init,
+                                          thermal_state_init, sca_prev0, CTG,
+                                          omc, Kf, inv_Thacc, thacc_m, Rsp, G,
+                                          eTG, sca, swe_max);
+        } else {
+            snowmelt = t == 0
+                ? cema_day<L, true>(day, gt_tab, gt_ok, snow_pack_init,
+                                    thermal_state_init, CTG, omc, Kf, G, eTG)
+                : cema_day<L, false>(day, gt_tab, gt_ok, snow_pack_init,
+                                     thermal_state_init, CTG, omc, Kf, G, eTG);
+        }
+        double liquid = snowmelt;
+        double ice_total = 0.0;
+        if constexpr (ICE) {            // icemelt_model.py:55-63
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                double melt = ddf * day[2 * L + l];
+                if (melt < 0) melt = 0.0;
+                const double lw = (G[l] > 1) ? 0.0 : melt;
+                ice_total += lw * frac_ice[l];
+            }
+            liquid = snowmelt + ice_total;
+        }
+        const double q = g.day(liquid, day[3 * L]);
+        if (o.qsim) o.qsim[t * o.ld + i] = q;
+        if (o.G) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                o.G[(t * L + l) * o.ld + i] = G[l];
+                o.eTG[(t * L + l) * o.ld + i] = eTG[l];
+                if (HYST) o.sca[(t * L + l) * o.ld + i] = sca[l];
+            }
+            o.s_store[t * o.ld + i] = g.s;
+            o.r_store[t * o.ld + i] = g.r;
+            if (ICE) o.icemelt[t * o.ld + i] = ice_total;
+            if (HYST && ICE) o.snowmelt[t * o.ld + i] = snowmelt;
+        }
+        if (sse) {
+            const double d = day[D - 1] - q;   // the day's observation
+            acc = __builtin_fma(d, d, acc);
+        }
+    }
+    if (sse) sse[i] = acc;
+}
+
 // ---- more than RR_CEMANEIGE_MAX_LAYERS elevation layers ----------------------
 // The same day step with a run-time layer count (as cemaneige_dyn_kernel does
 // for the plain snow routine): the per-layer states -- G, eTG and, with the
@@ -479,7 +587,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     double *days, *gt, *state;
     rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp,
                          (qobs && sse) ? qobs : nullptr, T, (int)L, workspace,
-                         st, &days, &gt, &state);
+                         st, &days, &gt, &state, (int *)workspace + 3);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
@@ -511,6 +619,13 @@ static int snow_gr4j_dev(const char *who, const double *prec,
                          lay, N, d_plan, force_lds, qsim != nullptr,
                          G != nullptr, qo, sse, uh_mem);
         });
+        // ... and behind them the sets that are not civil
+        // (gr4j_reference.h)
+        snow_gr4j_reference_kernel<LL.value, HYST, ICE>
+            <<<grid, block, 0, st>>>(
+                out, days, gt, frac_ice, T, snow_pack_init,
+                thermal_state_init, sca_init, s_init, r_init, params, lay, N,
+                d_plan, qo ? sse : nullptr);
     });
     RR_HIP(hipGetLastError());
     return RR_OK;

@@ -33,52 +33,6 @@ def _jitter(rng, x):
     return np.where(x == 0, x, y)
 
 
-RUNAWAY = 1e5       # mm: beyond this a series is on its way to overflow
-
-
-def _overflow_horizon(flat, refs):
-    """First day from which a set is NOT compared, per set (T = never).
-
-    The HBV-Edu and GR4J kernels contract a product into the sum that takes
-    it (one FMA, one rounding) and regroup s - s K_1 - s K_p as
-    s (1 - K_1 - K_p), x - x (1 - y) as x y.  Each is the same number as the
-    reference's sequence to an ulp or two -- and a different object once
-    infinities are involved:
-      * inside an FMA a product that exceeds 1.8e308 is still a number; on
-        its own, as the reference computes it, it is inf -- and inf minus
-        another overflowed product is NaN where the FMA says +-inf;
-      * an infinite store times a finite factor is an infinity, times 0 it
-        is NaN; the reference's s - s K_1 is inf - inf = NaN, its
-        inf * (1 - 0) is inf.
-    So the two can disagree on whether a run that has left the numbers reads
-    inf or NaN, and on nothing else.  A set whose reference series holds an
-    infinity is compared up to the day before the first one; a set that can
-    overflow (a finite parameter beyond 1e100 -- the wild values 1e200,
-    +-1e308) up to the day before its first non-finite value; a run-away set
-    (K_0 = 7.5 multiplies a difference by -6.5 a day: a series that passes
-    1e5 mm is on its way to overflow, and where the reference's own sequence
-    cancels to an exact zero another rounding of the same statement leaves
-    1e-11) up to the day before it passes 1e5.  Every other set -- NaN,
-    zero, negative-zero and subnormal parameters included, and infinite ones
-    that never reach a store -- day by day, NaN pattern and all."""
-    flat = np.asarray(flat)
-    t, n = np.asarray(refs[0]).shape[0], flat.shape[0]
-    prone = (np.isfinite(flat) & (np.abs(flat) > 1e100)).any(axis=1)
-    first = np.full(n, t)
-    first_inf = np.full(n, t)
-    with np.errstate(all="ignore"):
-        for r in refs:
-            r = np.asarray(r).reshape(t, -1, n)
-            gone = (~np.isfinite(r) | (np.abs(r) > RUNAWAY)).any(axis=1)
-            first = np.minimum(first, np.where(gone.any(axis=0),
-                                               gone.argmax(axis=0), t))
-            inf = np.isinf(r).any(axis=1)
-            first_inf = np.minimum(first_inf, np.where(inf.any(axis=0),
-                                                       inf.argmax(axis=0), t))
-            prone |= (np.isfinite(r) & (np.abs(r) > RUNAWAY)).any(axis=(0, 1))
-    return np.minimum(np.where(prone, first, t), first_inf)
-
-
 def _lost_days(b, runs):
     """First day from which a WILD set has lost its digits, per set (T =
     never): the day one of the oracle's own perturbed `runs` (the one-ulp
@@ -88,8 +42,12 @@ def _lost_days(b, runs):
     blow-up at the end must not hide a chaotic phase of millimetres).
     K_0 = 7.5 with a threshold in the loop is chaotic: one ulp decides which
     days the store spills, and a week later the runs are whole millimetres
-    -- or an overflow -- apart.  Such a set is compared up to that day, like
-    _overflow_horizon's sets; in-bounds sets are never excused."""
+    -- or an overflow -- apart.  Such a set is compared up to that day (the
+    only rule that ever stops following the oracle, and it is about the
+    ORACLE's conditioning: there is no rule for overflow any more -- sets
+    that are not civil run the reference's own sequence on the GPU,
+    csrc/hbvedu.hip hbv_civil_lane, csrc/gr4j_reference.h); in-bounds sets
+    are never excused."""
     b = np.asarray(b)
     T, n = b.shape[0], b.shape[-1]
     with np.errstate(all="ignore"):
@@ -113,8 +71,7 @@ def _lost_days(b, runs):
 
 
 def _same(a, b, what, b_perturbed=None, horizon=None, chaos=None):
-    """horizon: _overflow_horizon's days (sets are only compared before
-    theirs).
+    """horizon: _lost_days' days (sets are only compared before theirs).
     b_perturbed: the oracle's own result(s) for slightly perturbed inputs
     (one array or a list): initial states moved by one ulp, the forcing
     jittered by one ulp per day (_jitter), the parameters moved by one ulp (a
@@ -458,16 +415,16 @@ def test_gr4j_fuzz(models, oracle, gr4j_variant):
         ref = oracle.simulate_gr4j(g["prec"][:t], g["etp"][:t], (0.6, 0.7),
                                    flat, return_storage=True, nthreads=8)
     pr = probes(flat)
-    hz = _overflow_horizon(flat, ref)
-    assert (hz[::2] == t).all() and (hz[1::2] == t).mean() > 0.4
+    # (no overflow rule: a set that is not civil -- csrc/gr4j_reference.h --
+    # is computed with the reference's own sequence, infinities and NaN where
+    # and as the reference produces them, compared over the whole series)
     for sl in (slice(0, 640), slice(0, 64)):   # both start at an even set
         out = models.GR4J().simulate(g["prec"][:t], g["etp"][:t], 0.6, 0.7,
                                      return_storage=True,
                                      params=_records(models.GR4J, flat[sl]))
         for j, (a, b, n) in enumerate(zip(out, ref,
                                           ["qsim", "s_store", "r_store"])):
-            _same(a, b[:, sl], "gr4j " + n, [q[j][:, sl] for q in pr],
-                  horizon=hz[sl])
+            _same(a, b[:, sl], "gr4j " + n, [q[j][:, sl] for q in pr])
     # register tiers too: all x4 <= 3 / <= 5 / <= 10
     for cap in (2.9, 4.9, 9.9):
         f2 = flat.copy()
@@ -477,8 +434,7 @@ def test_gr4j_fuzz(models, oracle, gr4j_variant):
                                        (0.6, 0.7), f2, nthreads=8)
         out = models.GR4J().simulate(g["prec"][:t], g["etp"][:t], 0.6, 0.7,
                                      params=_records(models.GR4J, f2))
-        _same(out, ref, "gr4j tier %g" % cap, [q[0] for q in probes(f2)],
-              horizon=_overflow_horizon(f2, [ref]))
+        _same(out, ref, "gr4j tier %g" % cap, [q[0] for q in probes(f2)])
 
 
 def test_snow_models_fuzz(models, oracle):
@@ -527,15 +483,11 @@ def test_snow_models_fuzz(models, oracle):
         out, _ = core.run(hyst, ice, layers, fice if ice else None, inits,
                           _records(cls, flat), True, True, None)
         gr4j_part = ("qsim", "s_store", "r_store")
-        # (the snow states are bit-exact throughout; the GR4J half runs the
-        # contracted arithmetic, see _overflow_horizon)
-        hz = _overflow_horizon(flat, [ref[k] for k in gr4j_part])
-        assert (hz[::2] == t).all()
+        # (no overflow rule: see test_gr4j_fuzz)
         for k, a in out.items():
             if a is not None:
                 _same(a, ref[k], "%s %s" % (cls.__name__, k),
-                      [ref2[k], ref3[k], ref4[k]] if k in gr4j_part else None,
-                      horizon=hz if k in gr4j_part else None)
+                      [ref2[k], ref3[k], ref4[k]] if k in gr4j_part else None)
     # Cemaneige alone with wild CTG / Kf
     flat = _wild_params(rng, np.array([0., 0.]), np.array([1., 10.]), 320)
     with np.errstate(all="ignore"):
@@ -584,13 +536,11 @@ def test_cemaneigegr4j_fuzz(models, oracle, fused_variant):
     out, _ = fmod._run(layers, inits, _records(models.CemaneigeGR4J, flat),
                        True, True, None)
     gr4j_part = ("qsim", "s_store", "r_store")
-    hz = _overflow_horizon(flat, [ref[0], ref[3], ref[4]])
-    assert (hz[::2] == t).all() and (hz[1::2] == t).mean() > 0.4
+    # (no overflow rule: see test_gr4j_fuzz)
     for a, b, b2, b3, b4, n in zip(out, ref, ref2, ref3, ref4,
                                    ["qsim", "G", "eTG", "s_store", "r_store"]):
         _same(a, b, "cemaneigegr4j " + n,
-              [b2, b3, b4] if n in gr4j_part else None,
-              horizon=hz if n in gr4j_part else None)
+              [b2, b3, b4] if n in gr4j_part else None)
 
 
 @pytest.mark.parametrize("poison", ["nan_temp", "inf_temp", "negative_snow",
