@@ -241,6 +241,13 @@ __device__ __forceinline__ HbvRefDay hbv_reference_day(
 #ifndef HBV_SMALL_TILES
 #define HBV_SMALL_TILES 0
 #endif
+// (measurement switch, off: two votes -- any lane wet? any lane outside the
+// box? --, each a compare's own mask against zero, instead of one on their
+// scalar combination.  hipcc builds a select chain around them: 125k sets
+// 2.82 -> 3.00 ms, 1M 19.7 -> 20.0)
+#ifndef HBV_SPLIT_NEED_VOTE
+#define HBV_SPLIT_NEED_VOTE 0
+#endif
 // Measurement switch, off: 1 writes the part of the day that does not wait
 // for the power (evaporation factor, overflow, base-flow store) INSIDE both
 // arms of the power branch, fenced by scheduling barriers between the
@@ -495,7 +502,7 @@ hbvedu_kernel(
             (unsigned)__double2hiint(soil) - box_lo < box_span);
         // lanes that need the power: wet, or outside the box (votes are done
         // on lane masks, common.h)
-        const lanemask_t need_m = RR_LANES(liquid_water != 0.0) | ~soil_m;
+        const lanemask_t wet_m = RR_LANES(liquid_water != 0.0);
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
 #if RR_HBV_CONTRACT
         // What the rest of the day needs besides the effective precipitation
@@ -553,7 +560,14 @@ hbvedu_kernel(
                              "+v"(over), "+v"(s2_n));
         };
 #endif
-        if (need_m & rr_exec()) {
+#if HBV_SPLIT_NEED_VOTE
+        // (two votes, each a compare's own lane mask against zero, instead of
+        // one on their combination: no scalar or / and-with-exec between the
+        // compares and the branch)
+        if (wet_m != 0 || RR_ANY_OUTSIDE(soil_m)) {
+#else
+        if ((wet_m | ~soil_m) & rr_exec()) {
+#endif
 #if RR_FAITHFUL_QUOTIENTS
             // (a tame wave has checked its divisors once, before the loop)
             double wetness;
