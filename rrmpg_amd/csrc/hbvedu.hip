@@ -248,17 +248,6 @@ __device__ __forceinline__ HbvRefDay hbv_reference_day(
 #ifndef HBV_SPLIT_NEED_VOTE
 #define HBV_SPLIT_NEED_VOTE 0
 #endif
-// Measurement switch, off: 1 writes the part of the day that does not wait
-// for the power (evaporation factor, overflow, base-flow store) INSIDE both
-// arms of the power branch, fenced by scheduling barriers between the
-// logarithm table's LDS read and the first use of its entry -- the idea: a
-// sweep of one or two waves per SIMD sits that latency out.  Measured, A/B in
-// one call (round 4): 65k sets 2.44 -> 2.49 ms, 125k 2.85 -> 2.91, 250k 5.73
-// -> 7.1, 1M 19.8 -> 20.2 (hipcc hoists half of the part above the branch
-// again and pays a register copy per day for the rest).
-#ifndef HBV_INDEPENDENT_IN_ARMS
-#define HBV_INDEPENDENT_IN_ARMS 0
-#endif
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
           bool TAME = true, int TILED = 0, bool REFERENCE = false>
 __global__ __launch_bounds__(RR_BLOCK, (TILED ? HBV_TILED_MINWAVES : 1)) void
@@ -505,17 +494,13 @@ hbvedu_kernel(
         const lanemask_t wet_m = RR_LANES(liquid_water != 0.0);
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
 #if RR_HBV_CONTRACT
-        // What the rest of the day needs besides the effective precipitation
-        // -- evaporation factor, overflow of the upper store, base-flow
-        // store -- does not wait for the power, and is written INSIDE both
-        // arms of the branch below rather than behind it: on a power day the
-        // scheduler then has a dozen independent instructions to put between
-        // the logarithm table's LDS read and the first use of its entry (a
-        // sweep of one or two waves per SIMD sits that latency out
-        // otherwise; same operations, same bits).
+        // (measured and removed in round 4: this part of the day written
+        // inside both arms of the power's branch, fenced by scheduling
+        // barriers behind the power's LDS table read -- hipcc hoists half of
+        // it above the branch again: 125k sets 2.85 -> 2.91 ms, 1M 19.8 ->
+        // 20.2)
         double pe, dry, over, s2_n;
-        auto independent_of_the_power = [&](auto wet_arm)
-            __attribute__((always_inline)) {
+        auto independent_of_the_power = [&]() __attribute__((always_inline)) {
             // potential / actual evapotranspiration (:102-108); the select
             // picks the factor, 1 or soil/PWP, so that the product with pe
             // goes into the soil update's FMA
@@ -550,14 +535,6 @@ hbvedu_kernel(
             }
             // base-flow reservoir (:121-123): s2 (1 - K_2) + s1 K_p
             s2_n = __builtin_fma(s2, keep_2, s1 * K_p);
-            // (pins the four values to THIS arm: as plain common code hipcc
-            // sinks it out of both arms again, behind the power)
-            if constexpr (decltype(wet_arm)::value)
-                asm volatile("; power day" : "+v"(pe), "+v"(dry), "+v"(over),
-                             "+v"(s2_n));
-            else
-                asm volatile("; day without the power" : "+v"(pe), "+v"(dry),
-                             "+v"(over), "+v"(s2_n));
         };
 #endif
 #if HBV_SPLIT_NEED_VOTE
@@ -588,23 +565,10 @@ hbvedu_kernel(
             double z;
             // (small sweeps, FORCING == 2: polynomial constants in VGPRs so
             // that the prefetched record fits the SGPR file without spills)
-#if RR_HBV_POW_LITE && RR_HBV_CONTRACT && HBV_INDEPENDENT_IN_ARMS
-            // (the table read first, the day's independent part between it
-            // and the first use of the entry: nothing may be scheduled
-            // across the two barriers)
-            const FpPowLookup entry = fastpow_tab_lookup(wetness, powlog);
-            __builtin_amdgcn_sched_barrier(0);
-            independent_of_the_power(std::true_type{});
-            __builtin_amdgcn_sched_barrier(0);
-            double pw = fastpow_tab_lite_finish<FORCING >= 2>(entry, beta2_hi,
-                                                              &z);
-#elif RR_HBV_POW_LITE
+#if RR_HBV_POW_LITE
             double pw = fastpow_tab_lite<FORCING >= 2>(wetness, beta2_hi,
                                                        powlog, &z);
 #else
-#if RR_HBV_CONTRACT && HBV_INDEPENDENT_IN_ARMS
-            independent_of_the_power(std::true_type{});
-#endif
             double pw = fastpow_tab_core<FORCING >= 2>(wetness, beta2_hi,
                                                        beta2_lo, powlog, &z);
 #endif
@@ -626,12 +590,8 @@ hbvedu_kernel(
             // on every day WITHOUT the power to join the two)
             asm("v_mul_f64 %0, %0, %1" : "+v"(prec_eff) : "v"(pw));
         }
-#if RR_HBV_CONTRACT && HBV_INDEPENDENT_IN_ARMS
-        else {
-            independent_of_the_power(std::false_type{});
-        }
-#elif RR_HBV_CONTRACT
-        independent_of_the_power(std::false_type{});
+#if RR_HBV_CONTRACT
+        independent_of_the_power();
 #endif
         mid();
 
