@@ -129,6 +129,7 @@ static inline double fp_from_hilo_(int hi, int lo) {
 #endif
 
 #include "pow_tables.h"
+#include "exp2_table.h"
 
 // Core: valid for finite x > 0.  Returns x**y if |y*log2 x| < 1000; *z_out
 // receives y*log2(x) (rounded) for the caller's range guard.
@@ -340,9 +341,21 @@ FP_FN FpPowLookup fastpow_tab_lookup(double x, const FpPowLogEntry *tab)
     e.lnc = tab[i].lnc;
     return e;
 }
-template <bool VCONST = false>
+// EXPTAB (`exptab`: FP_EXP2_N doubles, exp2_table.h, LDS on the device): the
+// exponential 2^zz table-driven as well -- zz = k/64 + r, |r| <= 1/128,
+// 2^zz = 2^(k >> 6) * T[k & 63] * (1 + r q(r)) with q of degree 4 (0.02 ulp
+// of truncation): six arithmetic instructions where the polynomial on
+// |q0| <= 1/2 takes twelve, for one more table read and two integer
+// instructions.  The kernels of the large sweeps use it (energy per set-day is
+// their currency); a sweep of one or two waves per SIMD
+// would sit out the second table read's latency and keeps the polynomial.
+// About one ulp more than the polynomial form (the table entry's rounding and
+// the last multiply-add's): inside the stated bound, measured by
+// tests/native/fastmath_harness.cpp ("lite_tab_*").
+template <bool VCONST = false, bool EXPTAB = false>
 FP_FN double fastpow_tab_lite_finish(const FpPowLookup &e, double y2,
-                                     double *z_out)
+                                     double *z_out,
+                                     const double *exptab = nullptr)
 {
     const double r = FP_FMA(e.z, e.invc, -1.0);
     const double t = FP_FMA(e.kd, FP_LN2, e.lnc);
@@ -357,6 +370,18 @@ FP_FN double fastpow_tab_lite_finish(const FpPowLookup &e, double y2,
     const double zz = y2 * l;
     *z_out = zz;
 
+    if (EXPTAB) {
+        const double kd = FP_RINT(zz * (double)FP_EXP2_N);
+        const double rr = FP_FMA(kd, -1.0 / FP_EXP2_N, zz);  // exact
+        const int k = (int)kd;
+        const double tj = exptab[k & (FP_EXP2_N - 1)];
+        double q = FP_EXP2_C4;
+        q = FP_FMA_K(q, rr, FP_EXP2_C3);
+        q = FP_FMA_K(q, rr, FP_EXP2_C2);
+        q = FP_FMA_K(q, rr, FP_EXP2_C1);
+        q = FP_FMA_K(q, rr, FP_EXP2_C0);
+        return FP_LDEXP(FP_FMA(tj, rr * q, tj), k >> 6);     // arithmetic shift
+    }
     const double n = FP_RINT(zz);
     const double q0 = zz - n;                         // |.| <= 0.5
     double q = 4.4549605981865186e-10;
@@ -372,6 +397,13 @@ FP_FN double fastpow_tab_lite_finish(const FpPowLookup &e, double y2,
     q = FP_FMA_K(q, q0, 0.6931471805599453);
     q = FP_FMA(q, q0, 1.0);                           // inline constant
     return FP_LDEXP(q, (int)n);
+}
+template <bool VCONST = false, bool EXPTAB = false>
+FP_FN double fastpow_tab_lite_x(double x, double y2, const FpPowLogEntry *tab,
+                                const double *exptab, double *z_out)
+{
+    return fastpow_tab_lite_finish<VCONST, EXPTAB>(fastpow_tab_lookup(x, tab),
+                                                   y2, z_out, exptab);
 }
 template <bool VCONST = false>
 FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,

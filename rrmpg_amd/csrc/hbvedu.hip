@@ -123,6 +123,12 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
 // indexes it with its own subinterval, which only LDS serves at full rate).
 static __device__ __constant__ const FpPowLogEntry HBV_POWLOG_TABLE[FP_POWLOG_N] =
     FP_POWLOG_TABLE_INIT;
+// ... and the table 2^(j/64) of its table-driven exponential (exp2_table.h)
+#ifndef HBV_EXP2_TAB
+#define HBV_EXP2_TAB 1
+#endif
+static __device__ __constant__ const double HBV_EXP2_TABLE[FP_EXP2_N] =
+    FP_EXP2_TABLE_INIT;
 
 // General pow for the (never expected) arguments outside fastpow's domain.
 // Out of line on purpose: inlined, OCML's pow raised the kernel from ~100 to
@@ -263,8 +269,12 @@ hbvedu_kernel(
     double *__restrict__ tile_state, int pieces, int ncatch)
 {
     __shared__ FpPowLogEntry powlog[FP_POWLOG_N];
+    __shared__ double exptab[HBV_EXP2_TAB ? FP_EXP2_N : 1];
     for (int j = threadIdx.x; j < FP_POWLOG_N; j += RR_BLOCK)
         powlog[j] = HBV_POWLOG_TABLE[j];
+    if (HBV_EXP2_TAB)
+        for (int j = threadIdx.x; j < FP_EXP2_N; j += RR_BLOCK)
+            exptab[j] = HBV_EXP2_TABLE[j];
     __syncthreads();
     const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
     // TILED == 2: several catchments (the jobs of catchment c are the slots
@@ -566,8 +576,8 @@ hbvedu_kernel(
             // (small sweeps, FORCING == 2: polynomial constants in VGPRs so
             // that the prefetched record fits the SGPR file without spills)
 #if RR_HBV_POW_LITE
-            double pw = fastpow_tab_lite<FORCING >= 2>(wetness, beta2_hi,
-                                                       powlog, &z);
+            double pw = fastpow_tab_lite_x<FORCING >= 2, HBV_EXP2_TAB != 0>(
+                wetness, beta2_hi, powlog, exptab, &z);
 #else
             double pw = fastpow_tab_core<FORCING >= 2>(wetness, beta2_hi,
                                                        beta2_lo, powlog, &z);

@@ -117,6 +117,41 @@ int main(int argc, char **argv) {
                 const double over = rel / (4 + 3 * fabs(zl) + 0.25 * fabs(y));
                 if (over > lbound) lbound = over;
             }
+        // ... and with the table-driven exp2 (fastpow_tab_lite_x<.., true>,
+        // the large sweeps' form): the same bound
+        static const double exptab[FP_EXP2_N] = FP_EXP2_TABLE_INIT;
+        double tw2[2] = {0, 0}, tbound = 0, tdiff = 0;
+        s = 88172645463325252ULL;
+        for (int set = 0; set < 2; ++set)
+            for (long i = 0; i < n; ++i) {
+                double x, y;
+                if (set == 0) { x = 0.05 + 1.45 * u01(); y = 0.5 + 7.5 * u01(); }
+                else { x = exp2(-9 + 18 * u01()); y = -64 + 128 * u01(); }
+                double y2h, y2l, zl2, zl3;
+                fastpow_tab_exponent(y, &y2h, &y2l);
+                const double got =
+                    fastpow_tab_lite_x<false, true>(x, y2h, tab, exptab, &zl2);
+                if (!fastpow_tab_ok(x, zl2)) continue;
+                const long double want = powl((long double)x, (long double)y);
+                const double rel = (double)(fabsl((long double)got - want) /
+                                            want) * 0x1p53;
+                if (rel > tw2[set]) tw2[set] = rel;
+                const double over = rel / (4 + 3 * fabs(zl2) + 0.25 * fabs(y));
+                if (over > tbound) tbound = over;
+                // against the polynomial form: the exponential's own share
+                const double poly = fastpow_tab_lite(x, y2h, tab, &zl3);
+                const double d = fabs(got - poly) / poly * 0x1p53;
+                if (d > tdiff) tdiff = d;
+            }
+        double zt;
+        int tex = fastpow_tab_lite_x<false, true>(1.0, 3.7 * FP_INVLN2HI, tab,
+                                                  exptab, &zt) == 1.0 &&
+                  fastpow_tab_lite_x<false, true>(2.5, 0.0, tab, exptab,
+                                                  &zt) == 1.0;
+        printf("lite_tab_worst_rel53_sane %.2f\nlite_tab_worst_rel53_box %.2f\n"
+               "lite_tab_worst_over_bound_x100 %.0f\nlite_tab_exact_ok %d\n"
+               "lite_tab_vs_poly_rel53 %.2f\n",
+               tw2[0], tw2[1], tbound * 100, tex, tdiff);
         double zl;
         int lex = fastpow_tab_lite(1.0, 3.7 * FP_INVLN2HI, tab, &zl) == 1.0 &&
                   fastpow_tab_lite(2.5, 0.0, tab, &zl) == 1.0;

@@ -45,6 +45,12 @@ def test_fastpow_accuracy(tmp_path):
     assert float(vals["lite_worst_rel53_box"]) < 4 + 3 * 576, out
     assert int(vals["lite_worst_over_bound_x100"]) <= 100, out
     assert int(vals["lite_exact_ok"]) == 1, out
+    # the same power with the table-driven exp2 (the large sweeps' form)
+    assert float(vals["lite_tab_worst_rel53_sane"]) < 100, out
+    assert float(vals["lite_tab_worst_rel53_box"]) < 4 + 3 * 576, out
+    assert int(vals["lite_tab_worst_over_bound_x100"]) <= 100, out
+    assert int(vals["lite_tab_exact_ok"]) == 1, out
+    assert float(vals["lite_tab_vs_poly_rel53"]) < 4, out
     assert float(vals["worst_ulp_tanh_gr4j"]) < 3.0, out
     assert float(vals["worst_ulp_tanh_wide"]) < 3.0, out
     assert int(vals["tanh_special_ok"]) == 1, out
