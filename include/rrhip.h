@@ -39,14 +39,17 @@
  * the GR4J family, 1e-14 Cemaneige) -- power, tanh and roots are not libm's,
  * quotients by per-set constants are one multiply by the rounded reciprocal,
  * a product that feeds a sum is one FMA (each form has
- * a build flag that restores the reference's own sequence).  HBV-Edu sets
- * outside a generous box of meaningful parameters (recession factors outside
- * [0, 1], negative or huge Beta, 1e+-200, infinities, NaN) are computed with
- * the reference's own statement sequence, so their infinities and NaN appear
- * where and as the reference produces them.  In the GR4J family a run that
- * overflows (parameters like 1e200, an infinite parameter reaching a store)
- * may read inf where the reference reads NaN, or the other way round, from
- * the day it leaves the numbers.
+ * a build flag that restores the reference's own sequence).  Sets outside
+ * a generous box of meaningful parameters and states (recession factors
+ * outside [0, 1], negative or huge Beta, 1e+-200, infinities, NaN; in the
+ * GR4J family x1..x3, the initial stores and every snow parameter / initial
+ * snow state beyond 1e6 in magnitude or not a number; forcing that is not a
+ * number of at most 1e6) are computed with the reference's own statement
+ * sequence in a second kernel behind the fast one, so their infinities and
+ * NaN appear where and as the reference produces them, day by day.  The one
+ * population that keeps the fast forms regardless is GR4J-family sets with
+ * x4 > 20 days (the reference path holds 20-day unit hydrographs in
+ * registers) and Cemaneige stacks of more than 8 layers.
  *
  * Two families:
  *   rr_<model>_simulate      host pointers; synchronous; the library moves
