@@ -85,6 +85,10 @@ def parse_args():
     ap.add_argument("--hbv-variant", type=int, default=-1,
                     help="measurement hook: pin the HBV-Edu kernel variant "
                          "(rr_debug_set_option RR_OPT_HBV_VARIANT)")
+    ap.add_argument("--row-pitch", type=int, default=0,
+                    help="measurement hook: row pitch of the output arrays in "
+                         "doubles is rounded up to this (default: "
+                         "rrmpg_amd.device's 16 = 128 B; 1 = dense [T][N])")
     ap.add_argument("--time-tiles", type=int, default=-1,
                     help="measurement hook: RR_OPT_TIME_TILES (0 untiled, k > 1 "
                          "pieces of the time axis; default by sweep size)")
@@ -227,6 +231,8 @@ def build_workload(args, device, rank, n, first, total_sets):
         p0 = params[:1].contiguous()
     # synthetic observations: the sweep's first set's run + 10 % noise (the
     # same series on every rank with the device sampler)
+    if getattr(args, "row_pitch", 0) > 0:
+        ens.ROW_PITCH = args.row_pitch
     q0 = ens.new_output(1)
     ens.run(p0, q0)
     torch.cuda.synchronize(device)

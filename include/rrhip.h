@@ -21,7 +21,12 @@
  *     gr4j.py:57-60, cemaneige.py:64-65, cemaneigegr4j.py:67-72);
  *   - 2-D outputs are [T][ld] row-major with the parameter-set axis
  *     contiguous (the reference's qsim[T, N], hbvedu.py:191); 3-D storages
- *     are [T][L][ld] (reference: cemaneige.py:219-224).  ld >= N;
+ *     are [T][L][ld] (reference: cemaneige.py:219-224).  ld >= N.  For the
+ *     device entry points, make ld a multiple of 16 doubles (128 B) and the
+ *     output pointers 128-byte aligned when N is large: a wave stores 512
+ *     contiguous bytes of a row, and rows that start off a 64-byte boundary
+ *     (dense ld = N with N % 8 != 0) cost a million-set sweep up to 40 %
+ *     (profiles/r04_row_pitch.txt).  Correctness does not depend on it;
  *   - any output pointer may be NULL = "do not materialise it"
  *     (return_storage=False in the reference);
  *   - qobs/sse: if both non-NULL the kernel also accumulates, in time order,

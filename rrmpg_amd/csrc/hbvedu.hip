@@ -944,9 +944,14 @@ static int hbv_launch(const double *temp, const double *prec,
     // latency chain per wave, and the loop that asks for its record two days
     // ahead (3) wins (round 4, kernel ms 0 / 3: 65k sets 3.04 / 2.48, 100k
     // 3.01 / 2.59, 125k 3.08 / 2.88, 250k 6.00 / 5.87); the mid-day prefetch
-    // (2) up to ten; the plain loop beyond, where a SIMD always has a wave
-    // ready.  rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one.
-    int variant = waves <= 2 * simds ? 3 : (waves > 10 * simds ? 0 : 2);
+    // (2) up to six; the plain loop in time tiles beyond, where a SIMD
+    // always has a wave ready (kernel ms 2 untiled / 0 in four pieces: 375k
+    // sets 7.99 / 8.20, 400k 9.21 / 8.60, 500k 10.71 / 10.00, 750k 15.53 /
+    // 14.85: profiles/r04_mid_sizes.txt; the launch of
+    // equal-length waves moves in rounds of four waves per SIMD, which tiles
+    // smooth).  rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one.
+    const int64_t many_waves = 6 * simds;
+    int variant = waves <= 2 * simds ? 3 : (waves > many_waves ? 0 : 2);
     const int64_t pinned = rr_option(RR_OPT_HBV_VARIANT);
     if (pinned >= 0) variant = (int)pinned;
     // time-tiled persistent form (hbvedu_kernel's TILED), variants 0 and 3:
@@ -972,7 +977,7 @@ static int hbv_launch(const double *temp, const double *prec,
         if ((variant == 0 || variant == 3) && T > 16 &&
             waves * (opt > 1 ? opt : 64) < 0x7fffffff) {
             if (opt > 1) pieces = (int)opt;
-            else if (opt < 0 && variant == 0 && waves > 10 * simds) pieces = 4;
+            else if (opt < 0 && variant == 0 && waves > many_waves) pieces = 4;
 #if HBV_SMALL_TILES
             else if (opt < 0 && variant == 3 && two_per_simd)
                 pieces = hbv_small_pieces(waves, 2 * simds, T);

@@ -71,10 +71,22 @@ class _Ensemble:
             flat = np.ascontiguousarray(params, dtype=np.float64)
         return torch.from_numpy(flat.copy()).to(self.device)
 
+    # Row pitch of the outputs handed out here, in doubles: 128 B.  A wave
+    # stores 512 contiguous bytes of a row; with a dense pitch that is not a
+    # multiple of 64 B every such store straddles two partly written memory
+    # lines and a million-set sweep loses up to 40 % (measured:
+    # profiles/r04_row_pitch.txt).  The C-ABI takes any ld >= N.
+    ROW_PITCH = 16
+
     def new_output(self, num_sets, rows_per_t=1):
-        shape = ((self.num_timesteps, num_sets) if rows_per_t == 1 else
-                 (self.num_timesteps, rows_per_t, num_sets))
-        return torch.empty(shape, dtype=torch.float64, device=self.device)
+        """[T, num_sets] (or [T, rows_per_t, num_sets]) output tensor whose
+        rows start on 128-byte boundaries: a view of a buffer with the row
+        pitch rounded up to ``ROW_PITCH`` doubles."""
+        ld = -(-max(int(num_sets), 1) // self.ROW_PITCH) * self.ROW_PITCH
+        shape = ((self.num_timesteps, ld) if rows_per_t == 1 else
+                 (self.num_timesteps, rows_per_t, ld))
+        return torch.empty(shape, dtype=torch.float64,
+                           device=self.device)[..., :num_sets]
 
     def _check_tensor(self, t, shape, what):
         """The kernels take raw pointers: a tensor of the wrong dtype, device,

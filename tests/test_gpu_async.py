@@ -249,6 +249,16 @@ def test_resident_ensembles_validate_their_tensors(env):
     ens.run(p, wide[:, 28:128])
     torch.cuda.synchronize()
     assert torch.equal(wide[:, 28:128], q) and float(wide[:, :28].sum()) == 0
+    # new_output's rows start on 128-byte boundaries whatever N is; a dense
+    # [T][N] array takes the same values
+    q99 = ens.new_output(99)
+    assert q99.shape == (t, 99) and q99.stride() == (112, 1)
+    assert q99.data_ptr() % 128 == 0
+    dense = torch.empty((t, 99), dtype=torch.float64, device="cuda")
+    ens.run(p[:99].contiguous(), q99)
+    ens.run(p[:99].contiguous(), dense)
+    torch.cuda.synchronize()
+    assert torch.equal(q99, dense) and torch.equal(q99, q[:, :99])
 
 
 def test_device_snow_layers_match_reference_preprocessing(env):
