@@ -46,10 +46,9 @@ __global__ __launch_bounds__(RR_BLOCK) void abc_kernel_wide(
 #pragma unroll
         for (int j = 0; j < SPL; j += 2) {
             if (act[j + 1])
-                *reinterpret_cast<double2 *>(base + off + j) =
-                    make_double2(v[j], v[j + 1]);
+                rr_out2(base + off + j, v[j], v[j + 1]);
             else if (act[j])
-                base[off + j] = v[j];
+                rr_out(&base[off + j], v[j]);
         }
     };
 
@@ -111,8 +110,8 @@ __global__ __launch_bounds__(RR_BLOCK) void abc_kernel_x1(
     double s = initial_state, e = 0.0;
     int64_t off = i;
     if (active) {
-        if (Q) qsim[off] = 0.0;
-        if (S) storage[off] = s;
+        if (Q) rr_out(&qsim[off], 0.0);
+        if (S) rr_out(&storage[off], s);
     }
     if (E) {
         const double d = qobs[0] - 0.0;
@@ -125,8 +124,8 @@ __global__ __launch_bounds__(RR_BLOCK) void abc_kernel_x1(
         const double q = k * pr + c * s;
         s = m * s + a * pr;
         if (active) {
-            if (Q) qsim[off] = q;
-            if (S) storage[off] = s;
+            if (Q) rr_out(&qsim[off], q);
+            if (S) rr_out(&storage[off], s);
         }
         if (E) {
             const double d = qobs[t] - q;

@@ -400,15 +400,15 @@ cemaneigegr4j_kernel(
             o.qsim = po->qsim; o.G = po->G; o.eTG = po->eTG;
             o.s_store = po->s_store; o.r_store = po->r_store;
             const int64_t ld = po->ld;
-            if (wq) o.qsim[t * ld + i] = q;
+            if (wq) rr_out(&o.qsim[t * ld + i], q);
             if (ws) {
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    o.G[(t * L + l) * ld + i] = G[l];
-                    o.eTG[(t * L + l) * ld + i] = eTG[l];
+                    rr_out(&o.G[(t * L + l) * ld + i], G[l]);
+                    rr_out(&o.eTG[(t * L + l) * ld + i], eTG[l]);
                 }
-                o.s_store[t * ld + i] = s;
-                o.r_store[t * ld + i] = r;
+                rr_out(&o.s_store[t * ld + i], s);
+                rr_out(&o.r_store[t * ld + i], r);
             }
         }
         // (as a branch on the run-time flag; unconditional -- as in
@@ -578,15 +578,15 @@ cemaneigegr4j_opt_kernel(
             o.qsim = po->qsim; o.G = po->G; o.eTG = po->eTG;
             o.s_store = po->s_store; o.r_store = po->r_store;
             const int64_t ld = po->ld;
-            if (wq) o.qsim[t * ld + i] = q;
+            if (wq) rr_out(&o.qsim[t * ld + i], q);
             if (ws) {
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    o.G[(t * L + l) * ld + i] = G[l];
-                    o.eTG[(t * L + l) * ld + i] = eTG[l];
+                    rr_out(&o.G[(t * L + l) * ld + i], G[l]);
+                    rr_out(&o.eTG[(t * L + l) * ld + i], eTG[l]);
                 }
-                o.s_store[t * ld + i] = s;
-                o.r_store[t * ld + i] = r;
+                rr_out(&o.s_store[t * ld + i], s);
+                rr_out(&o.r_store[t * ld + i], r);
             }
         }
         if (we) {
@@ -646,8 +646,8 @@ __device__ __forceinline__ double cema_day_dyn(
         Gs[l * stride] = g;
         Es[l * stride] = e;
         if (write) {
-            G_out[l * out_stride] = g;
-            eTG_out[l * out_stride] = e;
+            rr_out(&G_out[l * out_stride], g);
+            rr_out(&eTG_out[l * out_stride], e);
         }
         c += rain + melt;
     }
@@ -703,10 +703,10 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
                                 ws && active);
         if constexpr (coupled) q = gr4j_step<UH, GR4J_CONSTS_JIT>(P, s, r, uh, q, day[3 * L]);
         if (active) {
-            if (wq) qsim[t * ld + i] = q;
+            if (wq) rr_out(&qsim[t * ld + i], q);
             if (coupled && ws) {
-                s_store[t * ld + i] = s;
-                r_store[t * ld + i] = r;
+                rr_out(&s_store[t * ld + i], s);
+                rr_out(&r_store[t * ld + i], r);
             }
         }
         if (we) {
@@ -1002,15 +1002,15 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneigegr4j_reference_kernel(
             : cema_day<L, false>(rec, gt_tab, gt_ok, snow_pack_init,
                                  thermal_state_init, CTG, omc, Kf, G, eTG);
         const double q = g.day(liquid, rec[3 * L]);
-        if (o.qsim) o.qsim[t * o.ld + i] = q;
+        if (o.qsim) rr_out(&o.qsim[t * o.ld + i], q);
         if (o.G) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                o.G[(t * L + l) * o.ld + i] = G[l];
-                o.eTG[(t * L + l) * o.ld + i] = eTG[l];
+                rr_out(&o.G[(t * L + l) * o.ld + i], G[l]);
+                rr_out(&o.eTG[(t * L + l) * o.ld + i], eTG[l]);
             }
-            o.s_store[t * o.ld + i] = g.s;
-            o.r_store[t * o.ld + i] = g.r;
+            rr_out(&o.s_store[t * o.ld + i], g.s);
+            rr_out(&o.r_store[t * o.ld + i], g.r);
         }
         if (sse) {
             const double d = rec[D - 1] - q;     // the day's observation

@@ -221,10 +221,47 @@ __device__ __forceinline__ double mul_by_inverse_m(double a,
 // scalar (a flat pointer per lane costs a 64-bit VALU add per day), and the
 // descriptor's size drops the columns past N in hardware, so the tail wave
 // needs no exec masking either.  `bytes` = 8 * min(64, N - first column).
+//
+// Every output element is written once and never read by the sweep: the
+// stores are NON-TEMPORAL (streamed past the L2's write-back lines).  With
+// plain stores the million-set sweeps that write qsim are a third slower
+// (HBV-Edu 19.2 -> 29.5 ms, 125k sets 2.78 -> 4.3: profiles/
+// r04_streaming_stores.txt); -DRR_OUT_NT=0 restores them.
+#ifndef RR_OUT_NT
+#define RR_OUT_NT 1
+#endif
+// cache-policy bits of the row stores (gfx94x / gfx950: 1 = sc0, 2 = nt,
+// 16 = sc1).  nt + sc1 measured against nt alone: HBV-Edu headline 19.55 ->
+// 19.18 ms, 125k sets 2.86 -> 2.82; nt + sc0 no different from nt
+// (profiles/r04_streaming_stores.txt).
+#ifndef RR_OUT_AUX
+#define RR_OUT_AUX 18
+#endif
+__device__ __forceinline__ void rr_out(double *p, double v)
+{
+#if RR_OUT_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+// two adjacent columns as one 16-byte store (p 16-byte aligned)
+typedef double rr_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rr_out2(double *p, double a, double b)
+{
+    rr_v2d v;
+    v.x = a;
+    v.y = b;
+#if RR_OUT_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<rr_v2d *>(p));
+#else
+    *reinterpret_cast<rr_v2d *>(p) = v;
+#endif
+}
 typedef int rr_v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void rr_store_row(double *row_base, unsigned bytes,
                                              int lane_byte_off, double v,
-                                             bool nontemporal = false)
+                                             bool nontemporal = RR_OUT_NT != 0)
 {
     // word 3: DATA_FORMAT = 32-bit, raw addressing (the value the compiler's
     // own buffer intrinsics use on gfx90a / gfx94x / gfx950)
@@ -234,7 +271,7 @@ __device__ __forceinline__ void rr_store_row(double *row_base, unsigned bytes,
     d.x = __double2loint(v);
     d.y = __double2hiint(v);
     if (nontemporal)
-        __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_byte_off, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_byte_off, 0, RR_OUT_AUX);
     else
         __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_byte_off, 0, 0);
 }

@@ -528,10 +528,10 @@ __global__ __launch_bounds__(RR_BLOCK) void gr4j_reference_kernel(
     double acc = 0.0;
     for (int64_t k = 0; k < T; ++k) {
         const double q = g.day(prec[k], etp[k]);
-        if (qsim) qsim[k * ld + i] = q;
+        if (qsim) rr_out(&qsim[k * ld + i], q);
         if (s_store) {
-            s_store[k * ld + i] = g.s;
-            r_store[k * ld + i] = g.r;
+            rr_out(&s_store[k * ld + i], g.s);
+            rr_out(&r_store[k * ld + i], g.r);
         }
         if (sse) {
             const double d = qobs[k] - q;

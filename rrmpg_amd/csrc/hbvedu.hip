@@ -124,6 +124,10 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
 static __device__ __constant__ const FpPowLogEntry HBV_POWLOG_TABLE[FP_POWLOG_N] =
     FP_POWLOG_TABLE_INIT;
 // ... and the table 2^(j/64) of its table-driven exponential (exp2_table.h)
+// qsim's rows stored non-temporal (1) or as plain write-back stores (0)
+#ifndef HBV_Q_NT
+#define HBV_Q_NT 1
+#endif
 #ifndef HBV_EXP2_TAB
 #define HBV_EXP2_TAB 1
 #endif
@@ -664,7 +668,7 @@ hbvedu_kernel(
             snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
         }
 
-        if (WRITE_Q) rr_store_row(qsim + row, row_bytes, lane_off, q_c, true);
+        if (WRITE_Q) rr_store_row(qsim + row, row_bytes, lane_off, q_c, HBV_Q_NT != 0);
         if (WRITE_S) {
             rr_store_row(snow_out + row, row_bytes, lane_off, snow);
             rr_store_row(soil_out + row, row_bytes, lane_off, soil);

@@ -243,18 +243,18 @@ snow_gr4j_kernel(
             o.sca = po->sca; o.icemelt = po->icemelt;
             o.snowmelt = po->snowmelt;
             const int64_t ld = po->ld;
-            if (wq) o.qsim[t * ld + i] = q;
+            if (wq) rr_out(&o.qsim[t * ld + i], q);
             if (ws) {
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    o.G[(t * L + l) * ld + i] = G[l];
-                    o.eTG[(t * L + l) * ld + i] = eTG[l];
-                    if (HYST) o.sca[(t * L + l) * ld + i] = sca[l];
+                    rr_out(&o.G[(t * L + l) * ld + i], G[l]);
+                    rr_out(&o.eTG[(t * L + l) * ld + i], eTG[l]);
+                    if (HYST) rr_out(&o.sca[(t * L + l) * ld + i], sca[l]);
                 }
-                o.s_store[t * ld + i] = s;
-                o.r_store[t * ld + i] = r;
-                if (ICE) o.icemelt[t * ld + i] = ice_total;
-                if (HYST && ICE) o.snowmelt[t * ld + i] = snowmelt;
+                rr_out(&o.s_store[t * ld + i], s);
+                rr_out(&o.r_store[t * ld + i], r);
+                if (ICE) rr_out(&o.icemelt[t * ld + i], ice_total);
+                if (HYST && ICE) rr_out(&o.snowmelt[t * ld + i], snowmelt);
             }
         }
         if (we) {
@@ -367,18 +367,18 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_reference_kernel(
             liquid = snowmelt + ice_total;
         }
         const double q = g.day(liquid, day[3 * L]);
-        if (o.qsim) o.qsim[t * o.ld + i] = q;
+        if (o.qsim) rr_out(&o.qsim[t * o.ld + i], q);
         if (o.G) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                o.G[(t * L + l) * o.ld + i] = G[l];
-                o.eTG[(t * L + l) * o.ld + i] = eTG[l];
-                if (HYST) o.sca[(t * L + l) * o.ld + i] = sca[l];
+                rr_out(&o.G[(t * L + l) * o.ld + i], G[l]);
+                rr_out(&o.eTG[(t * L + l) * o.ld + i], eTG[l]);
+                if (HYST) rr_out(&o.sca[(t * L + l) * o.ld + i], sca[l]);
             }
-            o.s_store[t * o.ld + i] = g.s;
-            o.r_store[t * o.ld + i] = g.r;
-            if (ICE) o.icemelt[t * o.ld + i] = ice_total;
-            if (HYST && ICE) o.snowmelt[t * o.ld + i] = snowmelt;
+            rr_out(&o.s_store[t * o.ld + i], g.s);
+            rr_out(&o.r_store[t * o.ld + i], g.r);
+            if (ICE) rr_out(&o.icemelt[t * o.ld + i], ice_total);
+            if (HYST && ICE) rr_out(&o.snowmelt[t * o.ld + i], snowmelt);
         }
         if (sse) {
             const double d = day[D - 1] - q;   // the day's observation
@@ -502,9 +502,9 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
                 ice_total += lw * frac_ice[l];
             }
             if (ws && active) {
-                o.G[(t * L + l) * ld + i] = g;
-                o.eTG[(t * L + l) * ld + i] = e;
-                if (HYST) o.sca[(t * L + l) * ld + i] = sc;
+                rr_out(&o.G[(t * L + l) * ld + i], g);
+                rr_out(&o.eTG[(t * L + l) * ld + i], e);
+                if (HYST) rr_out(&o.sca[(t * L + l) * ld + i], sc);
             }
             c += rain + melt;
         }
@@ -513,12 +513,12 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
         const double q = gr4j_step<UH, ICE ? GR4J_CONSTS_JIT_EXP : GR4J_CONSTS_JIT>(
             P, s, r, uh, liquid, day[3 * L]);
         if (active) {
-            if (wq) o.qsim[t * ld + i] = q;
+            if (wq) rr_out(&o.qsim[t * ld + i], q);
             if (ws) {
-                o.s_store[t * ld + i] = s;
-                o.r_store[t * ld + i] = r;
-                if (ICE) o.icemelt[t * ld + i] = ice_total;
-                if (HYST && ICE) o.snowmelt[t * ld + i] = snowmelt;
+                rr_out(&o.s_store[t * ld + i], s);
+                rr_out(&o.r_store[t * ld + i], r);
+                if (ICE) rr_out(&o.icemelt[t * ld + i], ice_total);
+                if (HYST && ICE) rr_out(&o.snowmelt[t * ld + i], snowmelt);
             }
         }
         if (we) {
