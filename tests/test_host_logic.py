@@ -511,3 +511,31 @@ def test_bench_socket_sampler_without_hwmon():
     with s:
         pass
     assert s.record() is None or s.record()["samples"] >= 1
+
+
+def test_resident_outputs_start_rows_on_128_byte_boundaries():
+    """device.new_output hands out [T, N] views of a buffer whose row pitch
+    is rounded up to 16 doubles (a wave's 512-byte store must not straddle
+    partly written memory lines: profiles/r04_row_pitch.txt), and the shape
+    checks of ``run`` accept such views.  No GPU needed: the logic is
+    exercised on CPU tensors."""
+    import types
+    import torch
+    from rrmpg_amd import device as dev
+    ens = types.SimpleNamespace(num_timesteps=7, device=torch.device("cpu"),
+                                ROW_PITCH=dev._Ensemble.ROW_PITCH)
+    for n, pitch in ((1, 16), (15, 16), (16, 16), (99, 112), (1000, 1008),
+                     (1_000_001, 1_000_016)):
+        q = dev._Ensemble.new_output(ens, n)
+        assert q.shape == (7, n) and q.stride() == (pitch, 1)
+        assert q.dtype == torch.float64
+    g = dev._Ensemble.new_output(ens, 99, 5)
+    assert g.shape == (7, 5, 99) and g.stride() == (5 * 112, 112, 1)
+    # one call's outputs share the pitch; a dense array beside a padded one
+    # is refused
+    q, s = (dev._Ensemble.new_output(ens, 99) for _ in range(2))
+    ens._check_tensor = types.MethodType(dev._Ensemble._check_tensor, ens)
+    assert dev._Ensemble._check_outputs(ens, 99, (q, s), (g,), 5) == 112
+    with pytest.raises(ValueError, match="row stride"):
+        dev._Ensemble._check_outputs(
+            ens, 99, (q, torch.empty((7, 99), dtype=torch.float64)))
