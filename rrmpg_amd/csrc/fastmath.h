@@ -371,16 +371,26 @@ FP_FN double fastpow_tab_lite_finish(const FpPowLookup &e, double y2,
     *z_out = zz;
 
     if (EXPTAB) {
-        const double kd = FP_RINT(zz * (double)FP_EXP2_N);
-        const double rr = FP_FMA(kd, -1.0 / FP_EXP2_N, zz);  // exact
+        // The reduced argument is carried as d = N r = N zz - k (a plain
+        // difference of the two values the rounding needs anyway; exact) and
+        // the coefficients as c_j / N^(j+1): every Horner value is the one of
+        // the polynomial in r times a power of two, d q'(d) IS r q(r), the
+        // result has the same bits -- and the subtraction has no constant
+        // operand.  (As r = fma(k, -1/N, zz) hipcc spends a v_mov_b64 per
+        // evaluation to give the VOP2 v_fmac_f64, the only encoding that
+        // takes the literal, its accumulator.)
+        constexpr double I = 1.0 / FP_EXP2_N;            // a power of two
+        const double sN = zz * (double)FP_EXP2_N;
+        const double kd = FP_RINT(sN);
+        const double d = sN - kd;                        // exact
         const int k = (int)kd;
         const double tj = exptab[k & (FP_EXP2_N - 1)];
-        double q = FP_EXP2_C4;
-        q = FP_FMA_K(q, rr, FP_EXP2_C3);
-        q = FP_FMA_K(q, rr, FP_EXP2_C2);
-        q = FP_FMA_K(q, rr, FP_EXP2_C1);
-        q = FP_FMA_K(q, rr, FP_EXP2_C0);
-        return FP_LDEXP(FP_FMA(tj, rr * q, tj), k >> 6);     // arithmetic shift
+        double q = FP_EXP2_C4 * (I * I * I * I * I);
+        q = FP_FMA_K(q, d, FP_EXP2_C3 * (I * I * I * I));
+        q = FP_FMA_K(q, d, FP_EXP2_C2 * (I * I * I));
+        q = FP_FMA_K(q, d, FP_EXP2_C1 * (I * I));
+        q = FP_FMA_K(q, d, FP_EXP2_C0 * I);
+        return FP_LDEXP(FP_FMA(tj, d * q, tj), k >> 6);      // arithmetic shift
     }
     const double n = FP_RINT(zz);
     const double q0 = zz - n;                         // |.| <= 0.5

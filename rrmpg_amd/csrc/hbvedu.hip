@@ -255,6 +255,12 @@ __device__ __forceinline__ HbvRefDay hbv_reference_day(
 // box? --, each a compare's own mask against zero, instead of one on their
 // scalar combination.  hipcc builds a select chain around them: 125k sets
 // 2.82 -> 3.00 ms, 1M 19.7 -> 20.0)
+// The tame loop copy's snow routine as one transfer out of the pack, the
+// cold lanes' share written under an exec mask (day_step).  0: the select
+// form (an A/B switch).
+#ifndef HBV_SNOW_TRANSFER
+#define HBV_SNOW_TRANSFER 1
+#endif
 #ifndef HBV_SPLIT_NEED_VOTE
 #define HBV_SPLIT_NEED_VOTE 0
 #endif
@@ -472,13 +478,49 @@ hbvedu_kernel(
         // snow routine (hbvedu_model.py:87-96)
         const double melt = DD * (f.temp - T_t);
         const bool cold = f.temp < T_t;
-        const double snow_n = cold ? snow + f.prec : nb_max(0.0, snow - melt);
-        double least;
-        if constexpr (decltype(tame)::value)
-            asm("v_min_f64 %0, %1, %2" : "=v"(least) : "v"(snow), "v"(melt));
-        else
-            least = nb_min(snow, melt);
-        const double liquid_water = cold ? 0.0 : f.prec + least;
+        double snow_n, liquid_water;
+        if constexpr (decltype(tame)::value && HBV_SNOW_TRANSFER) {
+            // The snow routine of a tame wave as ONE quantity m that leaves
+            // the pack for the soil: min(snow, melt) on a day that is not
+            // cold, -prec (the precipitation stays) on a cold one --
+            //     snow' = snow - m,   liquid_water = prec + m.
+            // Bit for bit the reference's four expressions: a tame wave's
+            // pack, melt and precipitation are finite numbers (civil lanes,
+            // civil forcing), the pack and the precipitation not negative
+            // and not -0, so  snow - min(snow, melt)  is  snow - melt  where
+            // that is positive and +0 where max(0, .) would have cut it off
+            // (x - x = +0; a melt of -0 against any pack gives the pack
+            // back);  snow - (-prec)  is  snow + prec;  prec + (-prec) = +0
+            // is the reference's `liquid_water = 0`.
+            // The cold lanes' m is written by a v_mov_b64 under an exec mask
+            // -- one instruction where a 64-bit select costs two VOP3
+            // v_cndmask_b32 (8.6 cycles, profiles/ubench/valu_cost.hip), and
+            // the two selects, the second difference and the maximum of the
+            // general form are not evaluated at all: 6 vector instructions
+            // instead of 10 for the snow routine.
+            double m;
+            asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(snow), "v"(melt));
+            const lanemask_t cold_m = RR_LANES(cold);
+            const double neg_prec = -f.prec;          // wave-uniform (SGPRs)
+            lanemask_t saved;
+            asm("s_and_saveexec_b64 %1, %2\n\t"
+                "v_mov_b64 %0, %3\n\t"
+                "s_mov_b64 exec, %1"
+                : "+v"(m), "=&s"(saved)
+                : "s"(cold_m), "s"(neg_prec)
+                : "scc");
+            snow_n = snow - m;
+            liquid_water = f.prec + m;
+        } else {
+            snow_n = cold ? snow + f.prec : nb_max(0.0, snow - melt);
+            double least;
+            if constexpr (decltype(tame)::value)
+                asm("v_min_f64 %0, %1, %2"
+                    : "=v"(least) : "v"(snow), "v"(melt));
+            else
+                least = nb_min(snow, melt);
+            liquid_water = cold ? 0.0 : f.prec + least;
+        }
         // first operation of the soil update (:111), taken here so that
         // liquid_water itself is dead after the power block (it lives on as
         // prec_eff, in place, on the days without the power)
@@ -593,8 +635,19 @@ hbvedu_kernel(
             // is outside the box the wave also evaluates the general pow and
             // every lane fastpow cannot serve takes it.
             if (RR_ANY_OUTSIDE(soil_m)) {
-                const double general = pow_general(wetness, Beta);
-                pw = fastpow_tab_ok(wetness, z) ? pw : general;
+                // (a tame wave forms the quotient a second time here, from a
+                // copy of soil the compiler cannot see through: the first one
+                // then dies in the table lookup, which splits it in place --
+                // alive until here it costs the likely path a v_mov_b32 per
+                // evaluation)
+                double w = wetness;
+                if constexpr (decltype(tame)::value && RR_FAITHFUL_QUOTIENTS) {
+                    double soil_again = soil;
+                    asm volatile("" : "+v"(soil_again));
+                    w = inv_mul_core(soil_again, inv_FC);
+                }
+                const double general = pow_general(w, Beta);
+                pw = fastpow_tab_ok(w, z) ? pw : general;
             }
             // lanes of this wave that did not need the power sit inside the
             // box with liquid_water == 0: their pw is finite (|z| <= 64 * 9.1)
