@@ -199,6 +199,11 @@ int rr_check_common(const char *who, int64_t T, int64_t N, int64_t ld,
                      (long long)N);
         return RR_E_SIZE;
     }
+    if (T > 2000000000) {
+        // (the kernels count days in 32 bits)
+        rr_set_error("%s: T = %lld exceeds 2e9 timesteps", who, (long long)T);
+        return RR_E_SIZE;
+    }
     if (ld < N) {
         rr_set_error("%s: ld=%lld < N=%lld", who, (long long)ld, (long long)N);
         return RR_E_SIZE;

@@ -168,6 +168,8 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     const int64_t hs = (int64_t)njobs * RR_BLOCK;
     if constexpr (TILED) {
         rr_tile_range(0, (int)T, tiles.pieces, piece, 1, t_begin, t_end);
+        t_begin = __builtin_amdgcn_readfirstlane(t_begin);
+        t_end = __builtin_amdgcn_readfirstlane(t_end);
         if (piece > 0) {
             rr_tile_wait(tiles, job, piece);
 #pragma unroll
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
             // (opaque day index: the addresses are formed here, on the days
             // and in the mode that stores, instead of as eleven induction
             // pointers advanced every day)
-            int64_t ts = t;
+            int64_t ts = __builtin_amdgcn_readfirstlane((int)t);
             asm volatile("" : "+s"(ts));
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -222,14 +224,23 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
     // the snow routine (any sane run) and for the rest
     // (a piece that starts at day 0 peels it; the others start mid-run)
     const bool from_start = t_begin == 0 && t_begin < t_end;
+    // The day count is compared in 32 bits: there is no 64-bit signed scalar
+    // compare, and the vector one (v_mov_b64 + v_cmp_ge_i64) costs the loop
+    // two vector instructions a day -- 1M sets 29.7 -> 28.6 ms, scores 27.0
+    // -> 25.8.  (Not in the small-sweep form: 125k sets 6.49 -> 6.62 ms with
+    // the scalar compare, measured twice.)
+    auto more = [&](int64_t t) __attribute__((always_inline)) {
+        if constexpr (GTR) return t < (int64_t)t_end;
+        else return (int)t < t_end;
+    };
     if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
                           thermal_state_init)) {
         if (from_start) one_day(std::true_type{}, std::true_type{}, 0);
-        for (int64_t t = t_begin + (from_start ? 1 : 0); t < t_end; ++t)
+        for (int64_t t = t_begin + (from_start ? 1 : 0); more(t); ++t)
             one_day(std::false_type{}, std::true_type{}, t);
     } else {
         if (from_start) one_day(std::true_type{}, std::false_type{}, 0);
-        for (int64_t t = t_begin + (from_start ? 1 : 0); t < t_end; ++t)
+        for (int64_t t = t_begin + (from_start ? 1 : 0); more(t); ++t)
             one_day(std::false_type{}, std::false_type{}, t);
     }
     if (TILED && piece + 1 < tiles.pieces) {
@@ -596,9 +607,14 @@ cemaneigegr4j_opt_kernel(
     };
     auto run = [&](auto sane) __attribute__((always_inline)) {
         one_day(std::true_type{}, sane, A, B, 0);        // day 0, peeled
-        for (int64_t t = 1; t < T; t += 2) {
+        // (the day count compared in 32 bits: there is no 64-bit signed
+        // scalar compare, and the vector one costs two instructions a day;
+        // the launcher rejects T >= 2^31)
+        const int Ti = (int)T;
+        for (int64_t t = 1; (int)t < Ti; t += 2) {
             one_day(std::false_type{}, sane, B, A, t);
-            if (t + 1 < T) one_day(std::false_type{}, sane, A, B, t + 1);
+            if ((int)t + 1 < Ti)
+                one_day(std::false_type{}, sane, A, B, t + 1);
         }
     };
     // (two copies of the time loop, see cemaneige_kernel)

@@ -255,7 +255,19 @@ __device__ __forceinline__ double cema_day_io(
             const double gq = mul_by_inverse_m(g, inv_gt, gt_ok, votes);
             const double ratio =                           // :109-112
                 SANE ? rr_hw_min(gq, 1.0) : ((g < inv_gt.b) ? gq : 1.0);
-            melt = __builtin_fma(0.9, ratio, 0.1) * pot_melt;  // :115
+            // (one v_fma_f64 with 0.9 in an SGPR pair and 0.1 in a VGPR
+            // pair: from __builtin_fma hipcc holds them in those very
+            // registers and then issues v_mov_b64 + v_fmac_f64, the VOP2 form
+            // whose sum is its destination)
+            // (not in the small-sweep form, GT_REGS: 125k sets 6.50 -> 6.65
+            // ms with it)
+            double factor;
+            if constexpr (GT_REGS)
+                factor = __builtin_fma(0.9, ratio, 0.1);
+            else
+                asm("v_fma_f64 %0, %1, %2, %3"
+                    : "=v"(factor) : "v"(ratio), "s"(0.9), "v"(0.1));
+            melt = factor * pot_melt;                      // :115
 #else
             const double gq = div_by_invariant_m(g, gr4j_num_mask(g), inv_gt,
                                                  gt_ok, 0x1p900, votes);
