@@ -296,7 +296,7 @@ void gr4j_opt_kernel(
                    int k)
         __attribute__((always_inline)) {
         const double net = f.net, qobs_k = f.qobs;
-        const bool wet = f.wet != 0;
+        const Gr4jUniformWet wet = {f.wet};     // (gr4j_core.h)
         const lanemask_t net_m = f.net_ok ? ~0ull : 0ull;
         auto fetch_next = [&]() {
             asm volatile("" : : "s"(other.net), "s"(other.qobs),

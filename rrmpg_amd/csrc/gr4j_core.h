@@ -669,14 +669,31 @@ struct Gr4jNoHook {
 // the halves in different waves of a workgroup, a few days apart; everybody
 // else calls them back to back through gr4j_step_net.  Same instruction
 // sequence either way, so the results are bit-identical.
+// `wet` as a Gr4jUniformWet (the plain GR4J kernel, whose pre-pass decides it
+// once per day for every set -- the forcing is shared): the day record's 0 / 1
+// in a scalar register.  The branch's two outcomes are then formed with that
+// word's masks -- the sign of the store's change flipped by one v_xor_b32, the
+// excess kept or zeroed by two v_and_b32 -- instead of three v_cndmask_b32 on
+// a lane mask that is all ones or all zeros (VOP3: twice the issue time of
+// the VOP2 forms; profiles/ubench/valu_cost.hip).  The same bits.
+struct Gr4jUniformWet { int word; };
 template <class UH, int CONSTS_ = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook,
-          class V = CarefulVotes>
+          class V = CarefulVotes, class W = bool>
 __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
-                                                  double net, bool wet,
+                                                  double net, W wet_arg,
                                                   lanemask_t net_m,
                                                   MID &&mid = MID(),
                                                   V &&votes = V())
 {
+    constexpr bool uniform_wet = std::is_same<W, Gr4jUniformWet>::value;
+    bool wet;
+    int wet_word = 0;
+    if constexpr (uniform_wet) {
+        wet_word = wet_arg.word;
+        wet = wet_word != 0;
+    } else {
+        wet = wet_arg;
+    }
     constexpr bool rational_tanh =
         RR_GR4J_TANH_RATIONAL && CONSTS_ != GR4J_CONSTS_JIT_EXP;
     constexpr int CONSTS =
@@ -715,13 +732,30 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
 #else
     const double sx = inv_div_core(s, P.inv_x1);
 #endif
-    double c, k;
-    gr4j_store_coefficients(wet, s, P.x1, sx, c, k);
+    double c, k, den;
 #if RR_GR4J_CONTRACT
-    const double den = __builtin_fma(k, E, D);
+    if constexpr (uniform_wet) {
+        // (the denominator inside the day's own arm of the wave-uniform
+        // branch: joined behind it, k = sx / k = 1 - sx costs the wet arm a
+        // v_mov_b64 a day)
+        if (wet) {
+            c = P.x1 * __builtin_fma(-sx, sx, 1.0);
+            den = FP_FMA_CV(sx, E, D);        // (three-address: no copy)
+            asm("" : "+v"(den));    // (or hipcc joins the two again)
+        } else {
+            c = s * (2 - sx);
+            den = FP_FMA_CV(1 - sx, E, D);
+            asm("" : "+v"(den));
+        }
+    } else {
+        gr4j_store_coefficients(wet, s, P.x1, sx, c, k);
+        den = __builtin_fma(k, E, D);
+    }
 #else
-    const double den = D + k * E;
+    gr4j_store_coefficients(wet, s, P.x1, sx, c, k);
+    den = D + k * E;
 #endif
+    (void)k;
     const lanemask_t fast = gr4j_num_lanes(s) & P.x1_m & a_small &
                             RR_LANES(fabs(den) >= 0x1p-100);
     double frac = fast_div_core(c * E, den);
@@ -761,7 +795,15 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     // s - e_s + p_s (:114) and p_n - p_s (:123) with the branch's zeros
     // dropped (x - 0 and x + 0 are x)
     double sn, excess;
-    if (wet) {
+    if constexpr (uniform_wet) {
+        const int flip = (int)((unsigned)(wet_word ^ 1) << 31);
+        const int keep = -wet_word;                 // all ones on a wet day
+        sn = s + __hiloint2double(__double2hiint(frac) ^ flip,
+                                  __double2loint(frac));
+        const double e = net - frac;
+        excess = __hiloint2double(__double2hiint(e) & keep,
+                                  __double2loint(e) & keep);
+    } else if (wet) {
         sn = s + frac;
         excess = net - frac;
     } else {
