@@ -502,6 +502,14 @@ constexpr bool coupled_has_optimistic()
                       std::is_same<UH, UhRegs<5>>::value);
 }
 
+// The optimistic fused kernels' production store in its wave-uniform form on
+// the days every lane of the wave agrees on wet / dry (one_day).  Measured
+// and left off: the vote and the second copy of the production store cost
+// what the selects did -- 1M sets 73.9 -> 74.3 ms, 125k 10.72 -> 11.12
+// (profiles/r04_uniform_wet_ab.txt).
+#ifndef COUPLED_UNIFORM_WET
+#define COUPLED_UNIFORM_WET 0
+#endif
 #ifndef COUPLED_OPT_MINWAVES
 #define COUPLED_OPT_MINWAVES 3
 #endif
@@ -563,12 +571,40 @@ cemaneigegr4j_opt_kernel(
             for (int k = 0; k < D; ++k) day[k] = nx[k];
         };
         const bool wet = liquid >= etp_t;                   // gr4j_model.py:89
+#if COUPLED_UNIFORM_WET
+        // liquid - etp on a wet day, etp - liquid = -(liquid - etp) on a dry
+        // one (:90, :102): the magnitude of one difference (x - x = +0; the
+        // sets of this kernel are civil, no NaN)
+        const double net = fabs(liquid - etp_t);
+#else
         const double net = wet ? liquid - etp_t : etp_t - liquid;
+#endif
         const lanemask_t net_m = gr4j_num_lanes(net);
         OptimisticVotes votes;
         double s = in.s, r = in.r;
-        double p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
-                                                 fetch_next, votes);
+        double p_r;
+#if COUPLED_UNIFORM_WET
+        // Most days every lane of a wave is on the same side of :89 (the
+        // evapotranspiration is shared, the snow routines' outflows differ
+        // by little): such a wave takes the production store's wave-uniform
+        // form (gr4j_core.h Gr4jUniformWet: one arm of the store's
+        // coefficients, masks for the outcome) instead of evaluating both
+        // arms and selecting per lane -- seven v_cndmask_b32 and as many
+        // v_mov_b32 of constants a day.  The same bits either way.
+        const lanemask_t wet_m = RR_LANES(wet);
+        if (wet_m == 0 || wet_m == rr_exec()) {
+            const Gr4jUniformWet uw = {wet_m != 0 ? 1 : 0};
+            p_r = gr4j_production<UH, CONSTS>(P, s, net, uw, net_m,
+                                              fetch_next, votes);
+        } else {
+            asm volatile("");                       // keep this a branch
+            p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
+                                              fetch_next, votes);
+        }
+#else
+        p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
+                                          fetch_next, votes);
+#endif
         double q = gr4j_routing<UH>(P, r, uh, in.u, out.u, p_r, votes);
         if (RR_VOTES_FAILED(votes)) {
             // some lane left a fast form's domain: the GR4J day again from

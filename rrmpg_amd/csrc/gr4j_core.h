@@ -677,6 +677,12 @@ struct Gr4jNoHook {
 // a lane mask that is all ones or all zeros (VOP3: twice the issue time of
 // the VOP2 forms; profiles/ubench/valu_cost.hip).  The same bits.
 struct Gr4jUniformWet { int word; };
+// gr4j_step (the coupled kernels' day) can look for such days itself.
+// Measured and left off: hysteresis 147.1 -> 145.8 ms, ice melt 87.0 -> 88.7
+// (profiles/r04_uniform_wet_ab.txt).
+#ifndef GR4J_STEP_UNIFORM_WET
+#define GR4J_STEP_UNIFORM_WET 0
+#endif
 template <class UH, int CONSTS_ = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook,
           class V = CarefulVotes, class W = bool>
 __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
@@ -939,7 +945,26 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
 {
     const bool wet = prec >= etp;                               // :89
     const double net = wet ? prec - etp : etp - prec;           // :90, :102
-    return gr4j_step_net<UH, CONSTS>(P, s, r, uh, net, wet,
-                                        gr4j_num_lanes(net),
+    const lanemask_t net_m = gr4j_num_lanes(net);
+#if GR4J_STEP_UNIFORM_WET
+    // (the coupled kernels: on most days every lane of a wave is on the same
+    // side of :89 -- the evapotranspiration is shared --, and such a wave
+    // takes the production store's wave-uniform form, Gr4jUniformWet above,
+    // instead of both arms and per-lane selects.  The same bits.)
+    const lanemask_t wet_m = RR_LANES(wet);
+    double p_r;
+    if (wet_m == 0 || wet_m == rr_exec()) {
+        const Gr4jUniformWet uw = {wet_m != 0 ? 1 : 0};
+        p_r = gr4j_production<UH, CONSTS>(P, s, net, uw, net_m,
+                                          static_cast<MID &&>(mid));
+    } else {
+        asm volatile("");                           // keep this a branch
+        p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
+                                          static_cast<MID &&>(mid));
+    }
+    return gr4j_routing<UH>(P, r, uh, p_r);
+#else
+    return gr4j_step_net<UH, CONSTS>(P, s, r, uh, net, wet, net_m,
                                         static_cast<MID &&>(mid));
+#endif
 }
