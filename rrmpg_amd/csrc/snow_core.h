@@ -28,7 +28,10 @@ size_t rr_gr4j_uh_scratch_bytes(int64_t N, double max_x4);
 // `temp > 0` off the vector unit: as w = (temp > 0) ? 0.0 : NaN formed by four
 // scalar integer instructions, with `e == w` as the whole melt condition, one
 // vector compare per layer and day is saved and every snow kernel is 1-2 %
-// slower.  profiles/README.md.)
+// slower; as a signed compare of the temperature's high word (round 4: one
+// s_cmp) hipcc makes it a scalar branch INSIDE the masked melt block -- a
+// taken branch on every warm day, 10 cycles for the compare's 4 -- dropped on
+// reading the ISA.  profiles/README.md.)
 static __host__ __device__ constexpr int cema_record_len(int L, bool with_etp)
 {
     return 3 * L + (with_etp ? 1 : 0) + 1;
@@ -133,6 +136,14 @@ __device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 // in VGPR pairs, cema_gt_to_regs) instead of a scalar load from the table at
 // the point of use -- the small-sweep kernels, which have registers to spare
 // and nobody to hide a load's latency behind.
+// The pack's update and the layer sum of the outflow formed inside the melt
+// block only (cema_day_io; needs the faithful forms' block).  Measured and
+// left off: two vector instructions fewer on a layer's idle days bought
+// Cemaneige 1M sets 28.92 -> 28.68 ms and cost the small sweeps (125k sets
+// 6.49 -> 6.60, fused 10.75 -> 11.0; profiles/r04_lazy_sums_ab.txt).
+#ifndef CEMA_LAZY_SUMS
+#define CEMA_LAZY_SUMS 0
+#endif
 #ifndef CEMA_GT_SELECT_FORM
 #define CEMA_GT_SELECT_FORM 1
 #endif
@@ -226,6 +237,21 @@ __device__ __forceinline__ double cema_day_io(
             SANE ? RR_LANES(pot_melt == 0.0)
                  : (RR_LANES(pot_melt == 0.0) & RR_LANES(g >= 0.0));
         double melt = pot_melt;
+#if CEMA_LAZY_SUMS
+        // On the idle days -- melt a zero in every lane -- g - melt is g and
+        // the layer adds its (wave-uniform) rain to the running sum: ONE
+        // vector instruction, issued before the branch; a wave that melts
+        // overwrites the sum with c + (rain + melt) and takes the melt off
+        // the pack inside the block.  (x - 0 = x and x + 0 = x for every x a
+        // pack or a rain can be: neither is ever -0.)
+        double c_next = 0.0;
+        if (l > 0) {
+            c_next = c + rain;
+            // (pinned: hipcc otherwise carries the ADDEND through the branch
+            // -- a v_mov_b64 of the rain on the idle side -- and adds behind)
+            asm("" : "+v"(c_next));
+        }
+#endif
         if (rr_exec() & ~idle) {
             // G / G_tresh: the threshold is fixed for the whole run, so the
             // quotient is the 3-instruction correctly rounded form of
@@ -253,8 +279,13 @@ __device__ __forceinline__ double cema_day_io(
             // value)
 #if RR_SNOW_FAITHFUL
             const double gq = mul_by_inverse_m(g, inv_gt, gt_ok, votes);
+            // (the faithful quotient of a pack a few ulp below its threshold
+            // can round to 1 + ulp, and a ratio above 1 would melt more than
+            // the potential melt, the pack: it is capped in both forms -- a
+            // NaN quotient stays NaN in the general one, as the reference's)
             const double ratio =                           // :109-112
-                SANE ? rr_hw_min(gq, 1.0) : ((g < inv_gt.b) ? gq : 1.0);
+                SANE ? rr_hw_min(gq, 1.0)
+                     : ((g < inv_gt.b) ? ((gq > 1.0) ? 1.0 : gq) : 1.0);
             // (one v_fma_f64 with 0.9 in an SGPR pair and 0.1 in a VGPR
             // pair: from __builtin_fma hipcc holds them in those very
             // registers and then issues v_mov_b64 + v_fmac_f64, the VOP2 form
@@ -268,6 +299,10 @@ __device__ __forceinline__ double cema_day_io(
                 asm("v_fma_f64 %0, %1, %2, %3"
                     : "=v"(factor) : "v"(ratio), "s"(0.9), "v"(0.1));
             melt = factor * pot_melt;                      // :115
+#if CEMA_LAZY_SUMS
+            g = g - melt;                                  // :118
+            if (l > 0) c_next = c + (rain + melt);         // :121, :125
+#endif
 #else
             const double gq = div_by_invariant_m(g, gr4j_num_mask(g), inv_gt,
                                                  gt_ok, 0x1p900, votes);
@@ -276,10 +311,16 @@ __device__ __forceinline__ double cema_day_io(
             melt = (0.9 * ratio + 0.1) * pot_melt;         // :115
 #endif
         }
+#if CEMA_LAZY_SUMS
+        G[l] = g;
+        eTG[l] = e;
+        c = (l == 0) ? rain + melt : c_next;
+#else
         g = g - melt;                                      // :118
         G[l] = g;
         eTG[l] = e;
         c = (l == 0) ? rain + melt : c + (rain + melt);    // :121, :125
+#endif
     }
     return cema_layer_mean<L>(c, votes);
 }
