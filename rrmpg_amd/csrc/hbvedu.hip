@@ -255,6 +255,11 @@ __device__ __forceinline__ HbvRefDay hbv_reference_day(
 // box? --, each a compare's own mask against zero, instead of one on their
 // scalar combination.  hipcc builds a select chain around them: 125k sets
 // 2.82 -> 3.00 ms, 1M 19.7 -> 20.0)
+// The tame loop copy forms the soil's and the near-surface store's updates
+// inside the arms of the power's branch (day_step).  0: behind it.
+#ifndef HBV_SPLIT_TAIL
+#define HBV_SPLIT_TAIL 1
+#endif
 // The tame loop copy's snow routine as one transfer out of the pack, the
 // cold lanes' share written under an exec mask (day_step).  0: the select
 // form (an A/B switch).
@@ -524,8 +529,20 @@ hbvedu_kernel(
         // first operation of the soil update (:111), taken here so that
         // liquid_water itself is dead after the power block (it lives on as
         // prec_eff, in place, on the days without the power)
-        double soil_lw = soil + liquid_water;
-        asm("" : "+v"(soil_lw));      // (evaluated HERE, not sunk below)
+        // (the plain loop only: in the loops that request the next record in
+        // the middle of the day -- the sweeps of few waves per SIMD -- the
+        // second copy of that request cost more than the three instructions:
+        // 125k sets 2.63 -> 2.75 ms, 65k 2.37 -> 2.62)
+        // (nor in the multi-catchment launch: 125 x 10k sets, scores, 17.96
+        // -> 18.29)
+        constexpr bool split_tail = decltype(tame)::value && HBV_SPLIT_TAIL &&
+                                    RR_HBV_CONTRACT && FORCING == 0 &&
+                                    TILED != 2;
+        double soil_lw = soil;
+        if constexpr (!split_tail) {
+            soil_lw = soil + liquid_water;
+            asm("" : "+v"(soil_lw));  // (evaluated HERE, not sunk below)
+        }
 
         // effective precipitation (:99): liquid_water * (soil/FC)**Beta.
         // On dry or frozen days liquid_water is exactly 0 for every lane of
@@ -593,6 +610,9 @@ hbvedu_kernel(
             s2_n = __builtin_fma(s2, keep_2, s1 * K_p);
         };
 #endif
+#if RR_HBV_CONTRACT
+        double soil_n, s1_n;
+#endif
 #if HBV_SPLIT_NEED_VOTE
         // (two votes, each a compare's own lane mask against zero, instead of
         // one on their combination: no scalar or / and-with-exec between the
@@ -601,6 +621,12 @@ hbvedu_kernel(
 #else
         if ((wet_m | ~soil_m) & rr_exec()) {
 #endif
+            if constexpr (split_tail) {
+                // (first operation of the soil update, before liquid_water
+                // becomes prec_eff in place)
+                soil_lw = soil + liquid_water;
+                asm("" : "+v"(soil_lw));
+            }
 #if RR_FAITHFUL_QUOTIENTS
             // (a tame wave has checked its divisors once, before the loop)
             double wetness;
@@ -656,30 +682,54 @@ hbvedu_kernel(
             // gives the product a register of its own and pays a v_mov_b64
             // on every day WITHOUT the power to join the two)
             asm("v_mul_f64 %0, %0, %1" : "+v"(prec_eff) : "v"(pw));
+#if RR_HBV_CONTRACT
+            if constexpr (split_tail) {
+                // (the tame copy: the rest of the day inside the branch's
+                // arm, see below)
+                independent_of_the_power();
+                mid();
+                soil_n = __builtin_fma(-pe, dry, soil_lw - prec_eff);
+                s1_n = __builtin_fma(s1, keep_1, prec_eff - over);
+                asm("" : "+v"(soil_n), "+v"(s1_n));
+            }
+#endif
         }
 #if RR_HBV_CONTRACT
-        independent_of_the_power();
-#endif
-        mid();
-
-#if RR_HBV_CONTRACT
+        else if constexpr (split_tail) {
+            // (a day without the power, see below)
+            independent_of_the_power();
+            mid();
+            soil_n = __builtin_fma(-pe, dry, soil);
+            s1_n = __builtin_fma(s1, keep_1, -over);
+            asm("" : "+v"(soil_n), "+v"(s1_n));
+        }
         // The reservoir updates with their multiply-adds CONTRACTED -- each
         // product fused into the sum that takes it, one rounding instead of
         // two -- and the two linear stores regrouped around their
         // loop-invariant retention factors: 12 instructions instead of 23 a
         // day, every result within an ulp or two of the reference's.
         // -DRR_HBV_CONTRACT=0 builds the reference's own sequence below.
-        // soil moisture (:111)
-        const double soil_n = __builtin_fma(-pe, dry, soil_lw - prec_eff);
-
-        // near-surface reservoir (:114-118): s1 - s1 K_1 - s1 K_p as
-        // s1 (1 - K_1 - K_p), the factor a loop invariant
-        const double s1_n = __builtin_fma(s1, keep_1, prec_eff - over);
+        // soil moisture (:111); near-surface reservoir (:114-118): s1 - s1
+        // K_1 - s1 K_p as s1 (1 - K_1 - K_p), the factor a loop invariant
+        //
+        // The tame copy forms both INSIDE the arms of the power's branch: on
+        // a day without the power -- three days of five -- the liquid water is
+        // a zero in every lane and the soil inside the box (a positive
+        // number), so soil + 0 - 0 is the soil and 0 - over is -over: three
+        // vector instructions that day does not issue.  (The asm pins keep
+        // hipcc from joining the arms again behind a register copy.)
+        if constexpr (!split_tail) {
+            independent_of_the_power();
+            mid();
+            soil_n = __builtin_fma(-pe, dry, soil_lw - prec_eff);
+            s1_n = __builtin_fma(s1, keep_1, prec_eff - over);
+        }
 
         // discharge mixes old and new states (:125-127)
         const double q =
             __builtin_fma(s2_n, K_2, __builtin_fma(s1_n, K_1, over));
 #else
+        mid();
         // potential / actual evapotranspiration (:102-108)
         const double pe = (1 + C * f.dtemp) * f.pe_m;
 #if RR_FAITHFUL_QUOTIENTS
