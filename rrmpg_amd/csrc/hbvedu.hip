@@ -536,8 +536,13 @@ hbvedu_kernel(
         // (nor in the multi-catchment launch: 125 x 10k sets, scores, 17.96
         // -> 18.29)
         constexpr bool split_tail = decltype(tame)::value && HBV_SPLIT_TAIL &&
-                                    RR_HBV_CONTRACT && FORCING == 0 &&
+                                    RR_HBV_CONTRACT &&
+                                    (FORCING == 0 || HBV_SPLIT_TAIL > 1) &&
                                     TILED != 2;
+        // (HBV_SPLIT_TAIL = 2: the other loops as well, their record request
+        // behind the join instead of in both arms -- measured: 125k sets
+        // unchanged, 65k and 375k 2 % slower, profiles/r04_hbv_split_tail_ab.txt)
+        constexpr bool mid_in_arms = FORCING == 0;
         double soil_lw = soil;
         if constexpr (!split_tail) {
             soil_lw = soil + liquid_water;
@@ -687,7 +692,7 @@ hbvedu_kernel(
                 // (the tame copy: the rest of the day inside the branch's
                 // arm, see below)
                 independent_of_the_power();
-                mid();
+                if constexpr (mid_in_arms) mid();
                 soil_n = __builtin_fma(-pe, dry, soil_lw - prec_eff);
                 s1_n = __builtin_fma(s1, keep_1, prec_eff - over);
                 asm("" : "+v"(soil_n), "+v"(s1_n));
@@ -698,11 +703,12 @@ hbvedu_kernel(
         else if constexpr (split_tail) {
             // (a day without the power, see below)
             independent_of_the_power();
-            mid();
+            if constexpr (mid_in_arms) mid();
             soil_n = __builtin_fma(-pe, dry, soil);
             s1_n = __builtin_fma(s1, keep_1, -over);
             asm("" : "+v"(soil_n), "+v"(s1_n));
         }
+        if constexpr (split_tail && !mid_in_arms) mid();
         // The reservoir updates with their multiply-adds CONTRACTED -- each
         // product fused into the sum that takes it, one rounding instead of
         // two -- and the two linear stores regrouped around their
