@@ -1036,23 +1036,22 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneigegr4j_reference_kernel(
         return;
     Gr4jRef g;
     if (!g.init(p[2], p[3], p[4], p[5], s_init, r_init)) return;
-    const double CTG = p[0], Kf = p[1], omc = 1 - CTG;
+    const double CTG = p[0], Kf = p[1];
     double G[L], eTG[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
-    const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
-    const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
     constexpr int D = cema_record_len(L, true);
     double acc = 0.0;
     for (int64_t t = 0; t < T; ++t) {
         double rec[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) rec[k] = days[t * D + k];
+        // (the reference's own snow day too: its outflow to the bit)
         const double liquid = t == 0
-            ? cema_day<L, true>(rec, gt_tab, gt_ok, snow_pack_init,
-                                thermal_state_init, CTG, omc, Kf, G, eTG)
-            : cema_day<L, false>(rec, gt_tab, gt_ok, snow_pack_init,
-                                 thermal_state_init, CTG, omc, Kf, G, eTG);
+            ? cema_ref_day<L, true>(rec, gtresh, snow_pack_init,
+                                    thermal_state_init, CTG, Kf, G, eTG)
+            : cema_ref_day<L, false>(rec, gtresh, snow_pack_init,
+                                     thermal_state_init, CTG, Kf, G, eTG);
         const double q = g.day(liquid, rec[3 * L]);
         if (o.qsim) rr_out(&o.qsim[t * o.ld + i], q);
         if (o.G) {

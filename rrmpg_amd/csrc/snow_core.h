@@ -338,6 +338,54 @@ __device__ __forceinline__ double cema_day(
 }
 
 
+// The reference's own snow day (cemaneige_model.py:85-125), statement by
+// statement -- IEEE quotients G / G_tresh and c / L, 0.9 ratio + 0.1 as a
+// multiply and an add (the files are built -ffp-contract=off), the layer sum
+// started from 0.0 as np.mean starts it -- for the one-lane-per-set kernels
+// that run the sets the fast forms are not meant for
+// (cemaneigegr4j_reference_kernel, snow_gr4j_reference_kernel): the outflow
+// they hand to the reference's GR4J day is the reference's to the bit.  It
+// has to be: a set with x1 = 1e308 forms tanh(p_n / x1) among the subnormals,
+// p_n - p_s is then a rounding residue of +-1e-17 mm, and under a negative x3
+// its SIGN decides whether the routing store's exchange term is a NaN the
+// next day (tests/test_gpu_fuzz.py, seed 200: one ulp of the outflow turned
+// a discharge of 9e302 into 0).  gt: G_tresh[L] as cema_gtresh wrote it
+// (summed left to right like the reference's mean).
+template <int L, bool FIRST>
+__device__ __forceinline__ double cema_ref_day(
+    const double *__restrict__ day, const double *__restrict__ gt,
+    double snow_pack_init, double thermal_state_init, double CTG, double Kf,
+    double (&G)[L], double (&eTG)[L])
+{
+    double c = 0.0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const double snow = day[l], rain = day[L + l], temp = day[2 * L + l];
+        double g, e;
+        if (FIRST) {                                       // :85-96
+            g = snow_pack_init;
+            e = thermal_state_init;
+        } else {
+            g = G[l] + snow;
+            e = CTG * eTG[l] + (1 - CTG) * temp;
+        }
+        if (e > 0) e = 0.0;
+        double pot_melt = 0.0;                             // :99-106
+        if (e == 0 && temp > 0) {
+            pot_melt = Kf * temp;
+            if (pot_melt > g) pot_melt = g;
+        }
+        const double G_tresh = gt[l];
+        const double ratio = (g < G_tresh) ? g / G_tresh : 1.0;  // :109-112
+        const double melt = (0.9 * ratio + 0.1) * pot_melt;      // :115
+        g = g - melt;                                      // :118
+        G[l] = g;
+        eTG[l] = e;
+        c += rain + melt;                                  // :121, :125
+    }
+    return c / (double)L;
+}
+
 // Whether the wave may run the SANE form of cema_day: the conditions of its
 // comment, for every lane and for the whole forcing (`gtresh` + 4L + 1: the
 // pre-pass's count of temperatures that are not finite and snowfalls that are

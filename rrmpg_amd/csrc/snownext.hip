@@ -326,8 +326,6 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_reference_kernel(
     for (int l = 0; l < L; ++l) {
         G[l] = 0.0; eTG[l] = 0.0; sca[l] = 0.0; swe_max[l] = 0.0;
     }
-    const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
-    const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
     const double *psol = gtresh + L;
     const double sca_prev0 = (T == 1) ? sca_init : 0.0;
     constexpr int D = cema_record_len(L, true);
@@ -348,11 +346,12 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_reference_kernel(
                                           omc, Kf, inv_Thacc, thacc_m, Rsp, G,
                                           eTG, sca, swe_max);
         } else {
+            // (the reference's own snow day too: its outflow to the bit)
             snowmelt = t == 0
-                ? cema_day<L, true>(day, gt_tab, gt_ok, snow_pack_init,
-                                    thermal_state_init, CTG, omc, Kf, G, eTG)
-                : cema_day<L, false>(day, gt_tab, gt_ok, snow_pack_init,
-                                     thermal_state_init, CTG, omc, Kf, G, eTG);
+                ? cema_ref_day<L, true>(day, gtresh, snow_pack_init,
+                                        thermal_state_init, CTG, Kf, G, eTG)
+                : cema_ref_day<L, false>(day, gtresh, snow_pack_init,
+                                         thermal_state_init, CTG, Kf, G, eTG);
         }
         double liquid = snowmelt;
         double ice_total = 0.0;
