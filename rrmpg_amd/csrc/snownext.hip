@@ -34,7 +34,12 @@
 // <= G and `melt = min(melt, G)` (:151) is the identity; and the two
 // maxima / minima of non-negative numbers (:128, :134-137) are the hardware's.
 // Ten vector instructions per layer and day, bit-identical by construction.
-template <int L, bool FIRST, bool SANE = false>
+// REF (the one-lane kernel of the sets the fast forms are not meant for,
+// snow_gr4j_reference_kernel): the layer sum from 0.0 and the IEEE quotient
+// c / L as the reference's mean forms them, and a plain snow_balance / Thacc
+// -- the outflow is then the reference's to the bit (snow_core.h
+// cema_ref_day says why it has to be).
+template <int L, bool FIRST, bool SANE = false, bool REF = false>
 __device__ __forceinline__ double cema_hyst_day(
     const double *__restrict__ day, const double *__restrict__ psol,
     double snow_pack_init, double thermal_state_init,
@@ -73,9 +78,12 @@ __device__ __forceinline__ double cema_hyst_day(
             // (a day without snowfall or melt has snow_balance == 0; the
             // balance is not negative here, so the cheap integer form of the
             // numerator vote -- +0 or [2^-900, 2^196) -- applies)
-            sc = prev + div_by_invariant_m(
-                            snow_balance, gr4j_num_mask(snow_balance),
-                            inv_Thacc, thacc_m);
+            if constexpr (REF)
+                sc = prev + snow_balance / inv_Thacc.b;
+            else
+                sc = prev + div_by_invariant_m(
+                                snow_balance, gr4j_num_mask(snow_balance),
+                                inv_Thacc, thacc_m);
             swe_max[l] = SANE ? rr_hw_max(swe_max[l], g)
                               : nb_max(swe_max[l], g);
         } else {                                           // :130-142
@@ -99,9 +107,11 @@ __device__ __forceinline__ double cema_hyst_day(
         G[l] = g;
         eTG[l] = e;
         sca[l] = sc;
-        c = (l == 0) ? rain + melt : c + (rain + melt);    // :162, :166
+        if constexpr (REF) c += rain + melt;
+        else c = (l == 0) ? rain + melt : c + (rain + melt);  // :162, :166
     }
-    return cema_layer_mean<L>(c);
+    if constexpr (REF) return c / (double)L;
+    else return cema_layer_mean<L>(c);
 }
 
 // Whether the wave may run the SANE form of cema_hyst_day (its comment).
@@ -337,11 +347,11 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_reference_kernel(
         double snowmelt;
         if constexpr (HYST) {
             snowmelt = t == 0
-                ? cema_hyst_day<L, true>(day, psol, snow_pack_init,
+                ? cema_hyst_day<L, true, false, true>(day, psol, snow_pack_init,
                                          thermal_state_init, sca_prev0, CTG,
                                          omc, Kf, inv_Thacc, thacc_m, Rsp, G,
                                          eTG, sca, swe_max)
-                : cema_hyst_day<L, false>(day, psol, snow_pack_init,
+                : cema_hyst_day<L, false, false, true>(day, psol, snow_pack_init,
                                           thermal_state_init, sca_prev0, CTG,
                                           omc, Kf, inv_Thacc, thacc_m, Rsp, G,
                                           eTG, sca, swe_max);
