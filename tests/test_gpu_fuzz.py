@@ -851,3 +851,60 @@ def test_kernel_variants_agree_bit_for_bit(models):
                                     0.5, rec, False, False, qobs)
             for a, b in zip(list(out) + [sse, sse2], base + [base[-1]]):
                 assert np.array_equal(a, b), "GR4J tiles %d" % tiles
+
+
+def test_reference_kernels_hand_gr4j_the_reference_snow_outflow(models,
+                                                                oracle):
+    """Soak seed 200, set 281 of the ice-melt coupling, kept as a case of
+    its own: x1 = 1e308 mm forms tanh(p_n / x1) among the subnormals, so
+    p_n - p_s is a rounding residue of +-1e-17 mm whose sign one ulp of the
+    snow outflow decides; under x3 = -0.25 a positive residue left in the
+    routing store makes the next day's exchange term x2 (r / x3)**3.5 a NaN,
+    which numba's max(0, .) swallows together with the day's discharge -- 0
+    where the reference has 9e302.  The one-lane kernels of the sets that are
+    not civil therefore run the reference's own snow day (csrc/snow_core.h
+    cema_ref_day, csrc/snownext.hip cema_hyst_day<.., REF>): the routing
+    store is empty on the very days the reference's is, and the discharge
+    follows it.  No probes, no excuses: rtol 1e-9 on every day (pow / tanh
+    of the device library against glibc's), zeros and non-finite values in
+    the same places."""
+    from rrmpg_amd.models import _snowgr4j as core
+    h = golden("syn_cemaneigehystgr4j")
+    t = 500
+    layers = tuple(h[k][:t] for k in ("layer_prec", "layer_mean",
+                                      "frac_solid", "etp"))
+    forcing = (layers[0], layers[1], layers[3], layers[2])
+    fice = np.array([0.0, 0.1, 0.3, 0.6, 0.9])
+    inits = (3.0, -0.2, 0.4, 0.5, 0.6)
+    ice_set = [0.40534207254510635, -1e308, 1e308, -2.9360458153483835,
+               -0.25, 9.7846766997872123, 1e-200]
+    # the same set behind the hysteresis routine (Thacc, Rsp in bounds)
+    for (hyst, ice), cls, row in [
+            ((False, True), models.CemaneigeGR4JIce, ice_set),
+            ((True, True), models.CemaneigeHystGR4JIce,
+             ice_set[:2] + [300.0, 0.4] + ice_set[2:]),
+            ((True, False), models.CemaneigeHystGR4J,
+             ice_set[:2] + [300.0, 0.4] + ice_set[2:6])]:
+        # (an in-bounds neighbour on either side: the set sits in a wave
+        # with civil ones, as in the soak)
+        civil = [0.5, 4.0] + ([300.0, 0.4] if hyst else []) + \
+                [350.0, 0.5, 90.0, 2.2] + ([5.0] if ice else [])
+        flat = np.array([civil, row, civil])
+        with np.errstate(all="ignore"):
+            ref = oracle.simulate_snow_gr4j(
+                hyst, ice, *forcing, inits, flat,
+                frac_ice=fice if ice else None, return_storages=True,
+                nthreads=1)
+        out, _ = core.run(hyst, ice, layers, fice if ice else None, inits,
+                          _records(cls, flat), True, True, None)
+        for k in ("qsim", "s_store", "r_store"):
+            a, b = np.asarray(out[k])[..., 1], np.asarray(ref[k])[..., 1]
+            what = "%s %s" % (cls.__name__, k)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), what
+            assert np.array_equal(np.isinf(a), np.isinf(b)), what
+            assert np.array_equal(a == 0, b == 0), what + ": zeros"
+            fin = np.isfinite(b)
+            with np.errstate(all="ignore"):
+                assert np.all(np.abs(a[fin] - b[fin]) <=
+                              1e-9 * np.abs(b[fin])), what
+        assert np.isfinite(np.asarray(ref["qsim"])[..., 1]).any()
