@@ -423,6 +423,115 @@ FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,
                                            z_out);
 }
 
+// ---------------------------------------------------------------------------
+// (soil / FC) ** Beta for HBV-Edu's effective precipitation
+// (hbvedu_model.py:99), round 5: the power of a QUOTIENT BY A LOOP INVARIANT,
+// evaluated on the numerator alone --
+//     (soil / FC) ** Beta = 2 ** ((Beta / ln 2) (ln soil - ln FC)),
+//     N zz = sN = fma(y2N, ln soil, -cF),   y2N = N Beta / ln 2,
+//                                           cF  = y2N ln FC   (per lane, once)
+// -- so the quotient is never formed (one multiply and one link of the
+// dependent chain less), with both halves table-driven in plain double:
+//   * ln soil: soil = 2^e m, m in [1/2, 1) (v_frexp_exp / v_frexp_mant -- two
+//     instructions where the bit-pattern split of fastpow_tab_lookup takes
+//     five), the top 9 mantissa bits select {invc, lnc} (pow2_tables.h, 512
+//     entries of 16 bytes: one ds_read_b128), r = fma(m, invc, -1), |r| <=
+//     2^-10, ln(1 + r) = r + r^2 (A0 + A1 r + A2 r^2) (4.5e-17 absolute: two
+//     Horner steps where 128 subintervals needed five);
+//   * 2 ** (sN / N), N = 256: k = RN(sN) and the table index come out of ONE
+//     addition -- t = sN + 1.5 2^52 holds k in its low mantissa bits (round
+//     to nearest even of the hardware), kd = t - 1.5 2^52, d = sN - kd exact
+//     -- instead of v_ldexp + v_rndne + v_cvt; q of degree 3 on |d| / N <=
+//     1/512 (fit error 5e-18).
+// 28 vector instructions where fastpow_tab_lite_x behind the quotient took
+// 34.  What the subtraction ln soil - ln FC costs: the rounding of ln soil (a
+// few 2^-53 |ln soil|) is no longer relative to |ln(soil / FC)|, so the
+// relative error of the result is at most
+//     (6 + 3 |zz| + |y| (1 + 3 |log2 FC| + 3 |log2 soil|)) 2^-53,  zz = y log2 x
+// -- 5e-15 in a sane run's box (Beta <= 6, FC <= 1000 mm), 1e-12 at the far
+// corners of the guard box (Beta = 64, FC = 1e6) -- against the 1e-10 the
+// discharge has to meet; measured by tests/native/fastmath_harness.cpp
+// ("soil_*").  Domain: soil a positive normal number, |sN| < 1000 N
+// (fastpow_soil_ok); y2N and cF finite.
+#include "pow2_tables.h"
+struct FpSoilEntry { double invc, lnc; };
+#define FP_SOIL_MAGIC 0x1.8p52
+static_assert(FP_SOIL_LOG_A0 == -0.5, "the inline constant below");
+#if !defined(__HIPCC__)
+static inline int fp_soil_lo32_(double t) {
+    uint64_t b; memcpy(&b, &t, 8); return (int)(uint32_t)b;
+}
+#endif
+// ln x for a positive normal x, the first half of fastpow_soil
+template <bool VCONST = false>
+FP_FN double fastpow_soil_log(double x, const FpSoilEntry *tabl)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double m = FP_FREXP_MANT(x);
+    const double ed = (double)FP_FREXP_EXP(x);
+    const int i = (FP_HI32(x) >> (20 - FP_SOIL_LOG_BITS)) & (FP_SOIL_LOG_N - 1);
+#elif defined(__HIPCC__)
+    const double m = x, ed = 0.0;
+    const int i = 0;
+#else
+    int e_;
+    const double m = frexp(x, &e_);
+    const double ed = (double)e_;
+    const int i = (FP_HI32(x) >> (20 - FP_SOIL_LOG_BITS)) & (FP_SOIL_LOG_N - 1);
+#endif
+    const FpSoilEntry en = tabl[i];
+    const double r = FP_FMA(m, en.invc, -1.0);
+    const double t = FP_FMA(ed, FP_SOIL_LN2, en.lnc);
+    double h = FP_SOIL_LOG_A2;
+    h = FP_FMA_K(h, r, FP_SOIL_LOG_A1);
+    h = FP_FMA(h, r, -0.5);                           // inline constant (A0)
+    return t + FP_FMA(r * r, h, r);
+}
+// the per-lane constants: y2N = N Beta / ln 2, cF = y2N ln FC (ln FC by the
+// same table-driven logarithm: the kernels need no second one).  An FC that
+// is not a positive normal number gives cF = NaN, and fastpow_soil_ok then
+// rejects every result.
+FP_FN void fastpow_soil_exponent(double y, double fc, const FpSoilEntry *tabl,
+                                 double *y2N, double *cF)
+{
+    const double h = (y * FP_INVLN2HI) * (double)FP_SOIL_EXP_N;
+    const bool ok = (fc >= 0x1p-1022) && (fc < __builtin_inf());
+    *y2N = h;
+    *cF = ok ? h * fastpow_soil_log<false>(ok ? fc : 1.0, tabl)
+             : __builtin_nan("");
+}
+template <bool VCONST = false>
+FP_FN double fastpow_soil(double x, double y2N, double cF,
+                          const FpSoilEntry *tabl, const double *tabe,
+                          double *sN_out)
+{
+    const double l = fastpow_soil_log<VCONST>(x, tabl);
+    const double sN = FP_FMA(y2N, l, -cF);
+    *sN_out = sN;
+    const double tm = sN + FP_SOIL_MAGIC;
+    const double kd = tm - FP_SOIL_MAGIC;
+    const double d = sN - kd;                         // exact
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int k = FP_LO32(tm);
+#elif defined(__HIPCC__)
+    const int k = 0;
+#else
+    const int k = fp_soil_lo32_(tm);
+#endif
+    const double tj = tabe[k & (FP_SOIL_EXP_N - 1)];
+    constexpr double I = 1.0 / FP_SOIL_EXP_N;         // a power of two
+    double q = FP_SOIL_EXP_C3 * (I * I * I * I);
+    q = FP_FMA_K(q, d, FP_SOIL_EXP_C2 * (I * I * I));
+    q = FP_FMA_K(q, d, FP_SOIL_EXP_C1 * (I * I));
+    q = FP_FMA_K(q, d, FP_SOIL_EXP_C0 * I);
+    return FP_LDEXP(FP_FMA(tj, d * q, tj), k >> FP_SOIL_EXP_BITS);
+}
+FP_FN bool fastpow_soil_ok(double x, double sN)
+{
+    return (x >= 0x1p-1022) && (x < __builtin_inf()) &&
+           (__builtin_fabs(sN) < 1000.0 * FP_SOIL_EXP_N);
+}
+
 // Where fastpow_tab_core's result may be used: x a positive NORMAL number
 // (the bit-pattern split does not handle subnormals), |z| < 1000.
 FP_FN bool fastpow_tab_ok(double x, double z)

@@ -43,6 +43,12 @@
 #ifndef RR_HBV_CONTRACT
 #define RR_HBV_CONTRACT 1
 #endif
+// (round 5) the power evaluated on the soil alone, fastmath.h fastpow_soil:
+// no quotient, 512 / 256-entry tables, 28 instead of 34 instructions.
+// 0: round 4's fastpow_tab_lite_x behind the quotient soil * RN(1 / FC).
+#ifndef RR_HBV_POW_SOIL
+#define RR_HBV_POW_SOIL 1
+#endif
 // (the tame loop copy also for sweeps of exactly two waves per SIMD: since
 // the copy saves a select, a compare and two branches a day it wins there
 // too -- 125k sets 3.46 -> 3.26 ms, 100k 3.34 -> 3.14)
@@ -121,8 +127,10 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
 // The logarithm table of fastpow_tab_core (fastmath.h, pow_tables.h): 4 KiB
 // in constant memory, copied into LDS by every wave at kernel start (each lane
 // indexes it with its own subinterval, which only LDS serves at full rate).
+#if !RR_HBV_POW_SOIL
 static __device__ __constant__ const FpPowLogEntry HBV_POWLOG_TABLE[FP_POWLOG_N] =
     FP_POWLOG_TABLE_INIT;
+#endif
 // ... and the table 2^(j/64) of its table-driven exponential (exp2_table.h)
 // qsim's rows stored non-temporal (1) or as plain write-back stores (0)
 #ifndef HBV_Q_NT
@@ -131,8 +139,17 @@ static __device__ __constant__ const FpPowLogEntry HBV_POWLOG_TABLE[FP_POWLOG_N]
 #ifndef HBV_EXP2_TAB
 #define HBV_EXP2_TAB 1
 #endif
+#if !RR_HBV_POW_SOIL
 static __device__ __constant__ const double HBV_EXP2_TABLE[FP_EXP2_N] =
     FP_EXP2_TABLE_INIT;
+#else
+// the two tables of fastpow_soil (pow2_tables.h): 8 + 2 KiB in LDS, sixteen
+// single-wave workgroups per CU = four waves per SIMD
+static __device__ __constant__ const FpSoilEntry HBV_SOIL_LOG_TABLE[FP_SOIL_LOG_N] =
+    FP_SOIL_LOG_TABLE_INIT;
+static __device__ __constant__ const double HBV_SOIL_EXP_TABLE[FP_SOIL_EXP_N] =
+    FP_SOIL_EXP_TABLE_INIT;
+#endif
 
 // General pow for the (never expected) arguments outside fastpow's domain.
 // Out of line on purpose: inlined, OCML's pow raised the kernel from ~100 to
@@ -269,6 +286,23 @@ __device__ __forceinline__ HbvRefDay hbv_reference_day(
 #ifndef HBV_SPLIT_NEED_VOTE
 #define HBV_SPLIT_NEED_VOTE 0
 #endif
+// Every wave reads a slice of the day records with ordinary vector loads when
+// it starts, so that the scalar loads of the time loop find their lines in
+// this XCD's L2 (see the kernel's prologue).  0: off (an A/B switch).
+#ifndef HBV_WARM_L2
+#define HBV_WARM_L2 0
+#endif
+// timing experiments only (wrong results): 1 every day takes the power's
+// branch, 2 no day does
+#ifndef HBV_WARM_L2_LOADS
+#define HBV_WARM_L2_LOADS 8
+#endif
+#ifndef HBV_FULL_EXEC
+#define HBV_FULL_EXEC 1
+#endif
+#ifndef HBV_EXP_FORCE
+#define HBV_EXP_FORCE 0
+#endif
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
           bool TAME = true, int TILED = 0, bool REFERENCE = false>
 __global__ __launch_bounds__(RR_BLOCK, (TILED ? HBV_TILED_MINWAVES : 1)) void
@@ -283,6 +317,14 @@ hbvedu_kernel(
     const double *__restrict__ dtemp_raw, int *__restrict__ queue,
     double *__restrict__ tile_state, int pieces, int ncatch)
 {
+#if RR_HBV_POW_SOIL
+    __shared__ FpSoilEntry soillog[FP_SOIL_LOG_N];
+    __shared__ double soilexp[FP_SOIL_EXP_N];
+    for (int j = threadIdx.x; j < FP_SOIL_LOG_N; j += RR_BLOCK)
+        soillog[j] = HBV_SOIL_LOG_TABLE[j];
+    for (int j = threadIdx.x; j < FP_SOIL_EXP_N; j += RR_BLOCK)
+        soilexp[j] = HBV_SOIL_EXP_TABLE[j];
+#else
     __shared__ FpPowLogEntry powlog[FP_POWLOG_N];
     __shared__ double exptab[HBV_EXP2_TAB ? FP_EXP2_N : 1];
     for (int j = threadIdx.x; j < FP_POWLOG_N; j += RR_BLOCK)
@@ -290,6 +332,7 @@ hbvedu_kernel(
     if (HBV_EXP2_TAB)
         for (int j = threadIdx.x; j < FP_EXP2_N; j += RR_BLOCK)
             exptab[j] = HBV_EXP2_TABLE[j];
+#endif
     __syncthreads();
     const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
     // TILED == 2: several catchments (the jobs of catchment c are the slots
@@ -300,6 +343,36 @@ hbvedu_kernel(
     const double *const params0 = params, *const qobs0 = qobs;
     double *const qsim0 = qsim, *const snow0 = snow_out, *const soil0 = soil_out,
                  *const s10 = s1_out, *const s20 = s2_out, *const sse0 = sse;
+    if constexpr (HBV_WARM_L2 != 0 && !REFERENCE) {
+        // The day records are read through the scalar cache, whose misses go
+        // to the L2 of the wave's XCD -- and the records have just been
+        // written by the pre-pass, on whatever XCD its blocks ran: the first
+        // touch of a 64-byte line (1.6 days) in an XCD goes out to the
+        // Infinity Cache / HBM, which takes longer than the day or two the
+        // prefetching loops ask ahead.  A sweep of many waves per SIMD never
+        // notices (another wave issues); with one or two, every wave of the
+        // XCD sits behind the one that leads.  So the waves of an XCD
+        // (workgroups are dealt round-robin: XCD = linear id % 8) share out
+        // the lines among themselves, one ordinary load per lane, at most
+        // eight per wave, interleaved so that a partial cover is an even
+        // one: a few microseconds once, and the time loop's scalar loads are
+        // L2 hits from then on.  A prefetch only: nothing depends on which
+        // XCD a wave really runs on.
+        const int64_t ctotal = TILED == 2 ? ncatch : (int64_t)gridDim.y;
+        const int64_t nlines =
+            (T * ctotal * (int64_t)sizeof(HbvDay) + 63) / 64;
+        const int64_t wg = blockIdx.x + (int64_t)blockIdx.y * gridDim.x;
+        const int64_t R = ((int64_t)gridDim.x * gridDim.y + 7) / 8;
+        const int64_t r = wg >> 3;
+        const char *base = (const char *)days;
+        double w = 0.0;
+#pragma unroll
+        for (int m = 0; m < HBV_WARM_L2_LOADS; ++m) {
+            const int64_t line = ((int64_t)m * RR_BLOCK + threadIdx.x) * R + r;
+            if (line < nlines) w += *(const double *)(base + line * 64);
+        }
+        asm volatile("" : : "v"(w));
+    }
   for (;;) {           // TILED: one work item per trip; otherwise one trip
     int job = blockIdx.x, piece = 0, slot = 0, catchment = blockIdx.y;
     if constexpr (TILED) {
@@ -391,9 +464,15 @@ hbvedu_kernel(
         box_ok ? (unsigned)__double2hiint(FC * 0x1p9) - box_lo : 0u;
     // (opaque to the compiler, which would otherwise re-derive both every day)
     asm("" : "+v"(box_lo), "+v"(box_span));
+#if RR_HBV_POW_SOIL
+    // N Beta / ln 2 and its product with ln FC, for fastpow_soil
+    double beta_y2N, beta_cF;
+    fastpow_soil_exponent(Beta, FC, soillog, &beta_y2N, &beta_cF);
+#else
     // Beta / ln 2 as a double-double, for fastpow_tab_core
     double beta2_hi, beta2_lo;
     fastpow_tab_exponent(Beta, &beta2_hi, &beta2_lo);
+#endif
     // loop-invariant lane masks for the wave votes (common.h)
     const lanemask_t fc_m = RR_LANES(inv_FC.ok), pwp_m = RR_LANES(inv_PWP.ok);
     const bool pwp_pos = inv_PWP.ok && PWP > 0.0;
@@ -623,6 +702,14 @@ hbvedu_kernel(
         // one on their combination: no scalar or / and-with-exec between the
         // compares and the branch)
         if (wet_m != 0 || RR_ANY_OUTSIDE(soil_m)) {
+#elif HBV_EXP_FORCE == 1
+        if (((wet_m | ~soil_m) & rr_exec()) | 1) {
+#elif HBV_EXP_FORCE == 2
+        if (((wet_m | ~soil_m) & rr_exec()) & 0) {
+#elif HBV_FULL_EXEC
+        // (every wave runs with all 64 lanes: tail lanes recompute the last
+        // set, workgroups are RR_BLOCK threads -- no AND with exec)
+        if ((wet_m | ~soil_m) != 0) {
 #else
         if ((wet_m | ~soil_m) & rr_exec()) {
 #endif
@@ -632,6 +719,25 @@ hbvedu_kernel(
                 soil_lw = soil + liquid_water;
                 asm("" : "+v"(soil_lw));
             }
+#if RR_HBV_POW_SOIL
+            // fastmath.h fastpow_soil: the power from the soil alone -- the
+            // quotient by FC lives in a per-lane constant of the exponent --,
+            // table-driven in plain double, 28 instructions.  Inside the box
+            // its arguments are in its domain by construction (soil a
+            // positive normal number within 2^9 of FC, |zz| <= 64 * 9.1): the
+            // box mask is the vote.  If any lane is outside the box the wave
+            // also evaluates the general pow of the reference's own quotient
+            // and every lane fastpow_soil cannot serve takes it.
+            double sN;
+            double pw = fastpow_soil<FORCING >= 2>(soil, beta_y2N, beta_cF,
+                                                   soillog, soilexp, &sN);
+            if (RR_ANY_OUTSIDE(soil_m)) {
+                double soil_again = soil;
+                asm volatile("" : "+v"(soil_again));
+                const double general = pow_general(soil_again / FC, Beta);
+                pw = fastpow_soil_ok(soil_again, sN) ? pw : general;
+            }
+#else
 #if RR_FAITHFUL_QUOTIENTS
             // (a tame wave has checked its divisors once, before the loop)
             double wetness;
@@ -680,6 +786,7 @@ hbvedu_kernel(
                 const double general = pow_general(w, Beta);
                 pw = fastpow_tab_ok(w, z) ? pw : general;
             }
+#endif
             // lanes of this wave that did not need the power sit inside the
             // box with liquid_water == 0: their pw is finite (|z| <= 64 * 9.1)
             // and 0 * pw is the 0 they already hold, so no select is needed
@@ -862,7 +969,11 @@ hbvedu_kernel(
                 asm volatile("" : "+s"(pn));
                 dst.temp = pn->temp; dst.prec = pn->prec;     // one load burst
                 dst.dtemp = pn->dtemp; dst.pe_m = pn->pe_m; dst.qobs = pn->qobs;
+#ifdef HBV_EXP_CONST_RECORD
+                // timing experiment only (wrong results): no new record
+#else
                 pn += 1;
+#endif
             };
             auto use = [](const HbvDay &r) {
                 asm volatile("" : : "s"(r.temp), "s"(r.prec), "s"(r.dtemp),

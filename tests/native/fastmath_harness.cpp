@@ -160,6 +160,69 @@ int main(int argc, char **argv) {
                lw[0], lw[1], lbound * 100, lex);
     }
 
+    // fastpow_soil (HBV-Edu's default since round 5): (soil / FC) ** Beta
+    // from the soil alone, against powl of the EXACT quotient, relative
+    // error in units of 2^-53 -- (a) a sane run's box: FC 50..1000 mm, soil
+    // = FC U(0.05, 1.5), Beta 0.5..8; (b) the whole guard box: FC =
+    // 10^U(-3, 6), soil = FC 2^U(-9, 9), Beta U(-64, 64) -- and the stated
+    // bound (6 + 3 |zz| + |y| (1 + 3 |log2 FC| + 3 |log2 soil|)) 2^-53
+    {
+        static const FpSoilEntry tabl[FP_SOIL_LOG_N] = FP_SOIL_LOG_TABLE_INIT;
+        static const double tabe[FP_SOIL_EXP_N] = FP_SOIL_EXP_TABLE_INIT;
+        double sw[2] = {0, 0}, sbound = 0;
+        long srej = 0;
+        s = 88172645463325252ULL;
+        for (int set = 0; set < 2; ++set)
+            for (long i = 0; i < n; ++i) {
+                double fc, x, y;
+                if (set == 0) {
+                    fc = 50 + 950 * u01(); x = fc * (0.05 + 1.45 * u01());
+                    y = 0.5 + 7.5 * u01();
+                } else {
+                    fc = pow(10.0, -3 + 9 * u01());
+                    x = fc * exp2(-9 + 18 * u01()); y = -64 + 128 * u01();
+                }
+                double y2N, cF, sN;
+                fastpow_soil_exponent(y, fc, tabl, &y2N, &cF);
+                const double got = fastpow_soil(x, y2N, cF, tabl, tabe, &sN);
+                if (!fastpow_soil_ok(x, sN)) { srej++; continue; }
+                const long double want =
+                    powl((long double)x / (long double)fc, (long double)y);
+                const double rel = (double)(fabsl((long double)got - want) /
+                                            want) * 0x1p53;
+                if (rel > sw[set]) sw[set] = rel;
+                const double zz = sN / FP_SOIL_EXP_N;
+                const double over = rel / (6 + 3 * fabs(zz) + fabs(y) *
+                    (1 + 3 * fabs(log2(fc)) + 3 * fabs(log2(x))));
+                if (over > sbound) sbound = over;
+            }
+        // special arguments: the guard refuses what the split cannot serve,
+        // and an FC that is no positive normal number poisons cF
+        double y2N, cF, sN;
+        fastpow_soil_exponent(2.0, 100.0, tabl, &y2N, &cF);
+        int sok = fabs(fastpow_soil(100.0, y2N, cF, tabl, tabe, &sN) - 1.0)
+                      < 1e-14 &&
+                  fabs(fastpow_soil(50.0, y2N, cF, tabl, tabe, &sN) - 0.25)
+                      < 1e-14 &&
+                  !fastpow_soil_ok(0.0, 0.0) && !fastpow_soil_ok(-1.0, 0.0) &&
+                  !fastpow_soil_ok(4e-320, 0.0) && !fastpow_soil_ok(NAN, 0.0) &&
+                  !fastpow_soil_ok(INFINITY, 0.0) && !fastpow_soil_ok(1.0, NAN) &&
+                  !fastpow_soil_ok(1.0, 3e5) && fastpow_soil_ok(0x1p-1022, 3.0);
+        fastpow_soil_exponent(2.0, 0.0, tabl, &y2N, &cF);
+        sok = sok && std::isnan(cF);
+        fastpow_soil_exponent(2.0, -5.0, tabl, &y2N, &cF);
+        sok = sok && std::isnan(cF);
+        fastpow_soil_exponent(2.0, INFINITY, tabl, &y2N, &cF);
+        sok = sok && std::isnan(cF);
+        fastpow_soil_exponent(2.0, NAN, tabl, &y2N, &cF);
+        sok = sok && std::isnan(cF);
+        (void)fastpow_soil(1.0, 1.0, NAN, tabl, tabe, &sN);
+        sok = sok && !fastpow_soil_ok(1.0, sN);
+        printf("soil_worst_rel53_sane %.2f\nsoil_worst_rel53_box %.2f\n"
+               "soil_worst_over_bound_x100 %.0f\nsoil_guard_rejected %ld\n"
+               "soil_special_ok %d\n", sw[0], sw[1], sbound * 100, srej, sok);
+    }
+
     // tanh: arguments as GR4J produces them (net / x1 in [0, ~1]) and wide
     double wt = 0, wtx = 0, wtw = 0, wtwx = 0;
     for (long i = 0; i < n; ++i) {

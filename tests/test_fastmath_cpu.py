@@ -51,6 +51,16 @@ def test_fastpow_accuracy(tmp_path):
     assert int(vals["lite_tab_worst_over_bound_x100"]) <= 100, out
     assert int(vals["lite_tab_exact_ok"]) == 1, out
     assert float(vals["lite_tab_vs_poly_rel53"]) < 4, out
+    # HBV-Edu's default since round 5: the power from the soil alone
+    # (fastpow_soil) against powl of the exact quotient -- a sane run's box,
+    # the whole guard box (FC 1e-3..1e6, soil within 2^9 of it, |Beta| <= 64)
+    # and the stated bound
+    # (6 + 3 |zz| + |y| (1 + 3 |log2 FC| + 3 |log2 soil|)) 2^-53
+    assert float(vals["soil_worst_rel53_sane"]) < 250, out       # 2.8e-14
+    assert float(vals["soil_worst_rel53_box"]) < 6000, out       # 6.7e-13
+    assert int(vals["soil_worst_over_bound_x100"]) <= 100, out
+    assert int(vals["soil_guard_rejected"]) == 0, out
+    assert int(vals["soil_special_ok"]) == 1, out
     assert float(vals["worst_ulp_tanh_gr4j"]) < 3.0, out
     assert float(vals["worst_ulp_tanh_wide"]) < 3.0, out
     assert int(vals["tanh_special_ok"]) == 1, out
@@ -115,3 +125,39 @@ def test_pow_tables_header_matches_its_generator(tmp_path):
         assert (invc * 2 ** 9) % 1 == 0 or (invc * 2 ** 8) % 1 == 0
         assert lnc == logc + tail          # the pair's sum, rounded once
         assert (logc * 2 ** 43) % 1 == 0 and abs(tail) < 2 ** -43
+
+
+def test_pow2_tables_header_matches_its_generator(tmp_path):
+    """rrmpg_amd/csrc/pow2_tables.h (fastpow_soil's tables) is what
+    csrc/tools/gen_pow2_tables.py writes; 512 logarithm entries over [1/2, 1)
+    whose products with their subinterval stay within 2^-9.99 of 1, 256
+    entries 2^(j/256)."""
+    import importlib.util
+    import pytest
+    pytest.importorskip("mpmath")
+    gen = os.path.join(REPO, "rrmpg_amd", "csrc", "tools",
+                       "gen_pow2_tables.py")
+    committed = os.path.join(REPO, "rrmpg_amd", "csrc", "pow2_tables.h")
+    with open(committed) as fp:
+        want = fp.read()
+    spec = importlib.util.spec_from_file_location("gen_pow2_tables", gen)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fresh = str(tmp_path / "pow2_tables.h")
+    mod.main(fresh)
+    with open(fresh) as fp:
+        assert fp.read() == want
+    rows = re.findall(r"^    \{(\S+), (\S+)\}, ", want, flags=re.M)
+    assert len(rows) == 512
+    import math
+    for i, (invc, lnc) in enumerate(rows):
+        invc, lnc = float.fromhex(invc), float.fromhex(lnc)
+        lo, hi = 0.5 + i / 1024, 0.5 + (i + 1) / 1024
+        assert abs(lo * invc - 1) <= 2 ** -9.99
+        assert abs(hi * invc - 1) <= 2 ** -9.99
+        assert abs(lnc + math.log(invc)) < 2e-16
+    exps = re.findall(r"0x1\.[0-9a-f]+p\+0", want.split(
+        "FP_SOIL_EXP_TABLE_INIT")[1])
+    assert len(exps) == 256
+    assert float.fromhex(exps[128]) == 2 ** 0.5
+    assert "#define FP_SOIL_LOG_A0 -0x1.0000000000000p-1" in want
