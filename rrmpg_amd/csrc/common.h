@@ -275,6 +275,31 @@ __device__ __forceinline__ void rr_store_row(double *row_base, unsigned bytes,
     else
         __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_byte_off, 0, 0);
 }
+// The same with a wave-uniform byte offset in the instruction's SOFFSET field:
+// a time loop unrolled k-fold keeps ONE row base per trip and addresses its
+// k rows through loop-invariant offsets ld * 8, 2 ld * 8 ... -- no scalar
+// address arithmetic per day.  On gfx950 the range check of a raw buffer
+// covers soffset + the lane's offset (measured: with num_records = `bytes`
+// every store of a row behind the first was dropped), so the descriptor's
+// size is soffset + bytes: lanes at or beyond `bytes` are still dropped.
+// soffset + bytes < 2^32: the caller's business.
+__device__ __forceinline__ void rr_store_row_at(double *row_base, unsigned bytes,
+                                                int lane_byte_off,
+                                                unsigned soffset, double v,
+                                                bool nontemporal = RR_OUT_NT != 0)
+{
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)row_base, (short)0, (int)(soffset + bytes), 0x00020000);
+    rr_v2i d;
+    d.x = __double2loint(v);
+    d.y = __double2hiint(v);
+    if (nontemporal)
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_byte_off,
+                                              (int)soffset, RR_OUT_AUX);
+    else
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_byte_off,
+                                              (int)soffset, 0);
+}
 __device__ __forceinline__ unsigned rr_row_bytes(int64_t first, int64_t N)
 {
     const int64_t rem = N - first;

@@ -233,6 +233,22 @@ __device__ __forceinline__ HbvRefDay hbv_reference_day(
     return r;
 }
 
+// A day record through the CONSTANT address space: the records are read-only
+// for the time-loop kernels, and a wave-uniform load from address space 4 is
+// a scalar load whatever else the kernel does (from the global address space
+// hipcc scalarises a uniform load only while it can prove that nothing in the
+// kernel has written memory before it -- the prologue's inline-asm prefetch
+// already counts, and the records then arrive by vector loads in VGPRs).
+__device__ __forceinline__ HbvDay hbv_load_day(const HbvDay *days, int64_t t)
+{
+    typedef const HbvDay __attribute__((address_space(4))) *cp_t;
+    const cp_t p = (cp_t)(days + t);
+    HbvDay d;
+    d.temp = p->temp; d.prec = p->prec; d.dtemp = p->dtemp;
+    d.pe_m = p->pe_m; d.qobs = p->qobs;
+    return d;
+}
+
 // blockIdx.y = catchment.  A single-catchment launch has gridDim.y == 1; a
 // multi-catchment launch (rr_hbvedu_simulate_catchments_dev) lays every array
 // out catchment-major: days [C][T], params [C][N][11], outputs [C][T][ld],
@@ -290,12 +306,15 @@ __device__ __forceinline__ HbvRefDay hbv_reference_day(
 // it starts, so that the scalar loads of the time loop find their lines in
 // this XCD's L2 (see the kernel's prologue).  0: off (an A/B switch).
 #ifndef HBV_WARM_L2
-#define HBV_WARM_L2 0
+#define HBV_WARM_L2 1
 #endif
 // timing experiments only (wrong results): 1 every day takes the power's
 // branch, 2 no day does
+#ifndef HBV_WARM_L2_MAX_PER_SIMD
+#define HBV_WARM_L2_MAX_PER_SIMD 1
+#endif
 #ifndef HBV_WARM_L2_LOADS
-#define HBV_WARM_L2_LOADS 8
+#define HBV_WARM_L2_LOADS 4
 #endif
 #ifndef HBV_FULL_EXEC
 #define HBV_FULL_EXEC 1
@@ -315,7 +334,7 @@ hbvedu_kernel(
     double *__restrict__ s2_out, int64_t ld, const double *__restrict__ qobs,
     double *__restrict__ sse, const int *__restrict__ day_flags,
     const double *__restrict__ dtemp_raw, int *__restrict__ queue,
-    double *__restrict__ tile_state, int pieces, int ncatch)
+    double *__restrict__ tile_state, int pieces, int ncatch, int warm)
 {
 #if RR_HBV_POW_SOIL
     __shared__ FpSoilEntry soillog[FP_SOIL_LOG_N];
@@ -343,21 +362,26 @@ hbvedu_kernel(
     const double *const params0 = params, *const qobs0 = qobs;
     double *const qsim0 = qsim, *const snow0 = snow_out, *const soil0 = soil_out,
                  *const s10 = s1_out, *const s20 = s2_out, *const sse0 = sse;
-    if constexpr (HBV_WARM_L2 != 0 && !REFERENCE) {
+    if (HBV_WARM_L2 != 0 && !REFERENCE && warm != 0) {
         // The day records are read through the scalar cache, whose misses go
         // to the L2 of the wave's XCD -- and the records have just been
         // written by the pre-pass, on whatever XCD its blocks ran: the first
-        // touch of a 64-byte line (1.6 days) in an XCD goes out to the
+        // touch of a 64-byte line (1.3 days) in an XCD goes out to the
         // Infinity Cache / HBM, which takes longer than the day or two the
-        // prefetching loops ask ahead.  A sweep of many waves per SIMD never
-        // notices (another wave issues); with one or two, every wave of the
-        // XCD sits behind the one that leads.  So the waves of an XCD
-        // (workgroups are dealt round-robin: XCD = linear id % 8) share out
-        // the lines among themselves, one ordinary load per lane, at most
-        // eight per wave, interleaved so that a partial cover is an even
+        // prefetching loops ask ahead.  A sweep of several waves per SIMD
+        // never notices (another wave issues); with ONE wave on a SIMD every
+        // wave of the XCD sits behind the one that leads (65,536 sets: 2.32
+        // -> 1.98 ms, profiles/r05_hbv_soilpow_ab.txt).  So the waves of an
+        // XCD (workgroups are dealt round-robin: XCD = linear id % 8) share
+        // out the lines among themselves, one ordinary load per lane, at
+        // most four per wave, interleaved so that a partial cover is an even
         // one: a few microseconds once, and the time loop's scalar loads are
         // L2 hits from then on.  A prefetch only: nothing depends on which
-        // XCD a wave really runs on.
+        // XCD a wave really runs on.  (Written as asm, load and wait in one
+        // statement, no memory clobber: as C++ -- or with the clobber -- hipcc
+        // no longer takes the records for read-only, fetches them with vector
+        // loads and keeps them in VGPRs: four more vector instructions a
+        // day.)  `warm`: the launch's choice (hbv_launch).
         const int64_t ctotal = TILED == 2 ? ncatch : (int64_t)gridDim.y;
         const int64_t nlines =
             (T * ctotal * (int64_t)sizeof(HbvDay) + 63) / 64;
@@ -365,13 +389,16 @@ hbvedu_kernel(
         const int64_t R = ((int64_t)gridDim.x * gridDim.y + 7) / 8;
         const int64_t r = wg >> 3;
         const char *base = (const char *)days;
-        double w = 0.0;
-#pragma unroll
         for (int m = 0; m < HBV_WARM_L2_LOADS; ++m) {
             const int64_t line = ((int64_t)m * RR_BLOCK + threadIdx.x) * R + r;
-            if (line < nlines) w += *(const double *)(base + line * 64);
+            if (line < nlines) {
+                const char *ptr = base + line * 64;
+                double dummy;
+                asm volatile("global_load_dwordx2 %0, %1, off\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(dummy) : "v"(ptr));
+            }
         }
-        asm volatile("" : : "v"(w));
     }
   for (;;) {           // TILED: one work item per trip; otherwise one trip
     int job = blockIdx.x, piece = 0, slot = 0, catchment = blockIdx.y;
@@ -556,8 +583,12 @@ hbvedu_kernel(
     // sum with a precipitation that is not -0 -- the same +0, or prec,
     // either way.  Bit-identical by construction; any other wave runs the
     // general copy.
-    auto day_step = [&](const HbvDay f, int t, auto &&mid, auto tame) {
-        row += ld;
+    // `soff`: the day's row as a byte offset from `row` (the stores' SOFFSET
+    // field, common.h rr_store_row_at): the unrolled loops advance `row`
+    // once per trip and pass loop-invariant multiples of ld * 8 -- three
+    // scalar instructions of address arithmetic per trip instead of per day
+    auto day_step = [&](const HbvDay f, int t, auto &&mid, auto tame,
+                        unsigned soff) {
 
         // snow routine (hbvedu_model.py:87-96)
         const double melt = DD * (f.temp - T_t);
@@ -585,13 +616,16 @@ hbvedu_kernel(
             double m;
             asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(snow), "v"(melt));
             const lanemask_t cold_m = RR_LANES(cold);
-            const double neg_prec = -f.prec;          // wave-uniform (SGPRs)
+            // (-prec as v_max_f64 of the negated record field with itself:
+            // the negation is an operand modifier, where a v_mov_b64 needs
+            // the negative in an SGPR pair of its own -- s_xor + s_mov a day;
+            // prec is a number here, so the maximum is the value)
             lanemask_t saved;
             asm("s_and_saveexec_b64 %1, %2\n\t"
-                "v_mov_b64 %0, %3\n\t"
+                "v_max_f64 %0, -%3, -%3\n\t"
                 "s_mov_b64 exec, %1"
                 : "+v"(m), "=&s"(saved)
-                : "s"(cold_m), "s"(neg_prec)
+                : "s"(cold_m), "s"(f.prec)
                 : "scc");
             snow_n = snow - m;
             liquid_water = f.prec + m;
@@ -884,12 +918,12 @@ hbvedu_kernel(
             snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
         }
 
-        if (WRITE_Q) rr_store_row(qsim + row, row_bytes, lane_off, q_c, HBV_Q_NT != 0);
+        if (WRITE_Q) rr_store_row_at(qsim + row, row_bytes, lane_off, soff, q_c, HBV_Q_NT != 0);
         if (WRITE_S) {
-            rr_store_row(snow_out + row, row_bytes, lane_off, snow);
-            rr_store_row(soil_out + row, row_bytes, lane_off, soil);
-            rr_store_row(s1_out + row, row_bytes, lane_off, s1);
-            rr_store_row(s2_out + row, row_bytes, lane_off, s2);
+            rr_store_row_at(snow_out + row, row_bytes, lane_off, soff, snow);
+            rr_store_row_at(soil_out + row, row_bytes, lane_off, soff, soil);
+            rr_store_row_at(s1_out + row, row_bytes, lane_off, soff, s1);
+            rr_store_row_at(s2_out + row, row_bytes, lane_off, soff, s2);
         }
         if (WITH_SSE) {
             const double d = f.qobs - q_c;
@@ -898,6 +932,9 @@ hbvedu_kernel(
         (void)t;
     };
 
+    // (hbv_launch rejects 3 * ld * 8 >= 2^32)
+    const unsigned ld8 = (unsigned)ld * 8u, ld16 = 2u * ld8, ld24 = 3u * ld8;
+    (void)ld16; (void)ld24;
     __shared__ HbvDay tile[FORCING == 1 ? RR_BLOCK : 1];
     (void)tile;
     auto time_loop = [&](auto tame) {
@@ -909,7 +946,8 @@ hbvedu_kernel(
                 const int n = (Ti - t0 < RR_BLOCK) ? (Ti - t0) : RR_BLOCK;
                 for (int k = 0; k < n; ++k) {
                     const HbvDay f = tile[k];  // uniform address: LDS broadcast
-                    day_step(f, t0 + k, [] {}, tame);
+                    row += ld;
+                    day_step(f, t0 + k, [] {}, tame, 0u);
                 }
                 __syncthreads();
             }
@@ -933,7 +971,7 @@ hbvedu_kernel(
                 dst.dtemp = pn->dtemp; dst.pe_m = pn->pe_m; dst.qobs = pn->qobs;
                 pn += 1;
             };
-            HbvDay a = days[1], b;
+            HbvDay a = hbv_load_day(days, 1), b;
             // (a "use" of the first record ahead of the loop: otherwise hipcc
             // leaves half of its load in flight across the loop entry and then
             // waits for ALL scalar loads -- the prefetch included -- at that
@@ -942,10 +980,11 @@ hbvedu_kernel(
                          "s"(a.pe_m), "s"(a.qobs));
             int t = 1;
             for (; t + 1 < Ti; t += 2) {
-                day_step(a, t, [&] { fetch(b); }, tame);
-                day_step(b, t + 1, [&] { fetch(a); }, tame);
+                day_step(a, t, [&] { fetch(b); }, tame, ld8);
+                day_step(b, t + 1, [&] { fetch(a); }, tame, ld16);
+                row += 2 * ld;
             }
-            if (t < Ti) day_step(a, t, [] {}, tame);
+            if (t < Ti) day_step(a, t, [] {}, tame, ld8);
         } else if constexpr (FORCING == 3) {
             // sweeps of at most two waves per SIMD, round 4: a lone wave's
             // day is a latency chain (a day takes as long with one wave on
@@ -979,17 +1018,19 @@ hbvedu_kernel(
                 asm volatile("" : : "s"(r.temp), "s"(r.prec), "s"(r.dtemp),
                              "s"(r.pe_m), "s"(r.qobs));
             };
-            HbvDay a = days[t_begin], b = days[t_begin + 1], c;
+            HbvDay a = hbv_load_day(days, t_begin),
+                   b = hbv_load_day(days, t_begin + 1), c;
             use(a);
             int t = t_begin;
             for (; t + 2 < t_end; t += 3) {
-                day_step(a, t, [&] { use(b); fetch(c); }, tame);
-                day_step(b, t + 1, [&] { use(c); fetch(a); }, tame);
-                day_step(c, t + 2, [&] { use(a); fetch(b); }, tame);
+                day_step(a, t, [&] { use(b); fetch(c); }, tame, ld8);
+                day_step(b, t + 1, [&] { use(c); fetch(a); }, tame, ld16);
+                day_step(c, t + 2, [&] { use(a); fetch(b); }, tame, ld24);
+                row += 3 * ld;
             }
             if (t < t_end) {
-                day_step(a, t, [&] { use(b); }, tame);
-                if (t + 1 < t_end) day_step(b, t + 1, [] {}, tame);
+                day_step(a, t, [&] { use(b); }, tame, ld8);
+                if (t + 1 < t_end) day_step(b, t + 1, [] {}, tame, ld16);
             }
         } else {
             // (two days per trip, written out -- the votes are convergent
@@ -1002,21 +1043,22 @@ hbvedu_kernel(
                 // the same two records -- no scalar-cache misses
                 int tt = 1;
                 asm volatile("" : "+s"(tt));
-                const HbvDay f0 = days[tt];
-                day_step(f0, t, [] {}, tame);
+                const HbvDay f0 = hbv_load_day(days, tt);
+                day_step(f0, t, [] {}, tame, ld8);
                 asm volatile("" : "+s"(tt));
-                const HbvDay f1 = days[tt + 1];
-                day_step(f1, t + 1, [] {}, tame);
+                const HbvDay f1 = hbv_load_day(days, tt + 1);
+                day_step(f1, t + 1, [] {}, tame, ld16);
 #else
-                const HbvDay f0 = days[t];     // wave-uniform -> s_load_dwordx8
-                day_step(f0, t, [] {}, tame);
-                const HbvDay f1 = days[t + 1];
-                day_step(f1, t + 1, [] {}, tame);
+                const HbvDay f0 = hbv_load_day(days, t);   // s_load_dwordx8 + x2
+                day_step(f0, t, [] {}, tame, ld8);
+                const HbvDay f1 = hbv_load_day(days, t + 1);
+                day_step(f1, t + 1, [] {}, tame, ld16);
 #endif
+                row += 2 * ld;
             }
             if (t < t_end) {
-                const HbvDay f = days[t];
-                day_step(f, t, [] {}, tame);
+                const HbvDay f = hbv_load_day(days, t);
+                day_step(f, t, [] {}, tame, ld8);
             }
         }
     };
@@ -1138,6 +1180,13 @@ static int hbv_launch(const double *temp, const double *prec,
                      (long long)T);
         return RR_E_SIZE;
     }
+    if (ld > 0x7ffffff) {
+        // (the unrolled loops address a trip's rows through 32-bit offsets
+        // of up to 3 * ld * 8 bytes; 134 million columns x 8 B x T > any HBM)
+        rr_set_error("HBV-Edu: ld=%lld columns; supported up to 2^27 - 1",
+                     (long long)ld);
+        return RR_E_SIZE;
+    }
     HbvDay *days = (HbvDay *)workspace;
     int *day_flags = (int *)(days + (size_t)T * (size_t)C + 2);
     double *dtemp_raw = (double *)((char *)workspace +
@@ -1174,6 +1223,19 @@ static int hbv_launch(const double *temp, const double *prec,
     // 14.85: profiles/r04_mid_sizes.txt; the launch of
     // equal-length waves moves in rounds of four waves per SIMD, which tiles
     // smooth).  rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one.
+    // the records' lines fetched into every XCD's L2 by the waves themselves
+    // when they start (the kernel's prologue): where a SIMD holds one wave,
+    // and in the score-only mode at any size.  Measured, kernel ms without /
+    // with (profiles/r05_hbv_warm_ab.txt): 32k sets 2.11 / 1.60, 65,536 2.20 /
+    // 1.51; scores only 125k 2.16 / 1.98, 1M 11.59 / 11.43 -- but with qsim
+    // written 100k 2.19 / 2.27, 125k 2.38 / 2.39, 250k 4.85 / 5.12: at two
+    // to four waves per SIMD the store stream (4 to 4.6 TB/s) is what the
+    // sweep waits for, and waves that queue behind their XCD's leading wave
+    // write the same rows at the same time, which the memory system likes
+    // better than 2,000 waves each at a row of its own.
+    const bool score_only = qsim == nullptr && snow == nullptr;
+    const int warm = (HBV_WARM_L2 == 2 || score_only ||
+                      waves <= HBV_WARM_L2_MAX_PER_SIMD * simds) ? 1 : 0;
     const int64_t many_waves = 6 * simds;
     int variant = waves <= 2 * simds ? 3 : (waves > many_waves ? 0 : 2);
     const int64_t pinned = rr_option(RR_OPT_HBV_VARIANT);
@@ -1242,7 +1304,7 @@ static int hbv_launch(const double *temp, const double *prec,
                         days, T, snow_init, soil_init, s1_init, s2_init, inits,
                         params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
                         day_flags, dtemp_raw, queue, tile_state, pieces,
-                        (int)C);
+                        (int)C, warm);
                     return;
                 }
             }
@@ -1250,7 +1312,7 @@ static int hbv_launch(const double *temp, const double *prec,
                 <<<grid, dim3(RR_BLOCK), 0, st>>>(
                     days, T, snow_init, soil_init, s1_init, s2_init, inits,
                     params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
-                    day_flags, dtemp_raw, nullptr, nullptr, 0, (int)C);
+                    day_flags, dtemp_raw, nullptr, nullptr, 0, (int)C, warm);
         };
         if (variant == 1) go(std::integral_constant<int, 1>{}, std::false_type{});
         else if (variant == 2) go(std::integral_constant<int, 2>{}, std::true_type{});
@@ -1268,7 +1330,7 @@ static int hbv_launch(const double *temp, const double *prec,
             <<<grid, dim3(RR_BLOCK), 0, st>>>(
                 days, T, snow_init, soil_init, s1_init, s2_init, inits,
                 params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
-                day_flags, dtemp_raw, nullptr, nullptr, 0, (int)C);
+                day_flags, dtemp_raw, nullptr, nullptr, 0, (int)C, 0);
     });
     RR_HIP(hipGetLastError());
     return RR_OK;
