@@ -202,7 +202,7 @@ def build_workload(args, device, rank, n, first, total_sets):
             syn.STATION_HEIGHT, 0, 0, list(syn.ALTITUDES), etp=f["etp"])
         ens = rrdev.SnowGR4JEnsemble(
             hyst, ice, layers[0], layers[1], layers[2], layers[3],
-            frac_ice=[0.02, 0.04, 0.25, 0.51, 0.71] if ice else None,
+            frac_ice=SNOW_NEXT_FRAC_ICE if ice else None,
             s_init=0.6, r_init=0.7, device=device)
         name = cls.__name__ + "(L=5)"
     else:
@@ -319,7 +319,35 @@ def _oracle_sweep(args, f):
             lambda flat, nt: pyoracle.simulate_cemaneigegr4j(
                 layers[0], layers[1], layers[3], layers[2],
                 (0., 0., 0.6, 0.7), flat, nthreads=nt)
+    if args.model in SNOW_NEXT:
+        hyst, ice = SNOW_NEXT[args.model]
+        layers, fi = _snow_next_inputs(f, ice)
+        return SNOW_NEXT_NAMES[args.model] + "(L=5)", \
+            6 + (2 if hyst else 0) + (1 if ice else 0), \
+            lambda flat, nt: pyoracle.simulate_snow_gr4j(
+                hyst, ice, layers[0], layers[1], layers[3], layers[2],
+                (0., 0., 0., 0.6, 0.7), flat, frac_ice=fi, nthreads=nt)
     return None
+
+
+# the hysteresis / ice-melt couplings: model -> (hyst, ice)
+SNOW_NEXT = {"cemaneigehystgr4j": (True, False),
+             "cemaneigegr4jice": (False, True),
+             "cemaneigehystgr4jice": (True, True)}
+SNOW_NEXT_NAMES = {"cemaneigehystgr4j": "CemaneigeHystGR4J",
+                   "cemaneigegr4jice": "CemaneigeGR4JIce",
+                   "cemaneigehystgr4jice": "CemaneigeHystGR4JIce"}
+SNOW_NEXT_FRAC_ICE = [0.02, 0.04, 0.25, 0.51, 0.71]
+
+
+def _snow_next_inputs(f, ice):
+    """The layer forcing build_workload gives the next-tier ensembles."""
+    from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+    from rrmpg_amd.utils import synthetic as syn
+    layers, _ = prepare_snow_inputs(
+        f["prec"], f["temp"] - 3, f["tmin"] - 3, f["tmax"] - 3,
+        syn.STATION_HEIGHT, 0, 0, list(syn.ALTITUDES), etp=f["etp"])
+    return layers, (SNOW_NEXT_FRAC_ICE if ice else None)
 
 
 # the reference's own published single-thread numba rates (BASELINE.md /
@@ -379,7 +407,8 @@ def parity_spot(args, f, params_host, qsim, sse, qobs, n_cols=16):
     import torch
     from oracle import pyoracle
     from rrmpg_amd.utils import synthetic as syn
-    if args.model not in ("hbvedu", "gr4j", "abc", "cemaneigegr4j"):
+    if args.model not in ("hbvedu", "gr4j", "abc", "cemaneigegr4j") \
+            and args.model not in SNOW_NEXT:
         return None
     if args.catchments > 0:
         # catchment 0 of the launch: its forcing is `f`, its parameter sets
@@ -410,6 +439,8 @@ def parity_spot(args, f, params_host, qsim, sse, qobs, n_cols=16):
         ref = pyoracle.simulate_cemaneigegr4j(
             layers[0], layers[1], layers[3], layers[2], (0., 0., 0.6, 0.7),
             flat, nthreads=4)
+    elif args.model in SNOW_NEXT:
+        ref = _oracle_sweep(args, f)[2](flat, 4)
     else:
         ref = pyoracle.simulate_abc(f["prec"], 2.5, flat)
     if isinstance(ref, tuple):
@@ -532,11 +563,27 @@ def traffic_record(args, n, t):
         key = "%s:%s:%dx%d:%d" % (args.model, args.mode, args.catchments,
                                   args.sets, t)
     try:
+        from rrmpg_amd.utils.buildid import kernel_source_id
         with open(tpath) as fh:
             pmc = json.load(fh)
+        if pmc.get("_build", {}).get(args.model) != kernel_source_id(args.model):
+            # the kernels have changed since the counters were collected
+            return None, None
         return pmc.get(key), pmc.get(key + ":valu_instr_per_unit")
     except Exception:
         return None, None
+
+
+def traffic_is_stale(model):
+    """True if profiles/traffic.json was collected on other kernel sources
+    than this tree's (rrmpg_amd.utils.buildid)."""
+    try:
+        from rrmpg_amd.utils.buildid import kernel_source_id
+        with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
+            pmc = json.load(fh)
+        return pmc.get("_build", {}).get(model) != kernel_source_id(model)
+    except Exception:
+        return True
 
 
 class SocketSampler:
@@ -642,7 +689,7 @@ def power_soak(sweep, per_step_s, device, world, seconds=2.5):
 
 
 def run_workload(args, device, rank, world, on_host, steps, warmup,
-                 score="mse"):
+                 score="mse", settle_s=0.0, min_timed_s=0.0):
     """Build this rank's share of the workload `args` names, time `steps`
     sweeps (barrier + synchronize on both sides) and return the measurements.
     The sweep itself -- kernel launch, score, the one all-gather -- is
@@ -676,6 +723,21 @@ def run_workload(args, device, rank, world, on_host, steps, warmup,
     for _ in range(warmup):
         scores = sweep.step()
     fence()
+    if settle_s > 0:
+        # the extra configurations: each follows seconds of CPU work (the
+        # previous one's oracle sample), during which the GPU has clocked
+        # down, and a sweep of a few milliseconds is over before the clock is
+        # back -- round 4's driver run timed HBV-Edu 100k at 2.83 ms where
+        # sweeps in steady state take 2.4-2.6.  Untimed sweeps until `settle_s`
+        # seconds have passed, then enough timed ones to fill `min_timed_s`.
+        t_s = time.perf_counter()
+        k_s = 0
+        while time.perf_counter() - t_s < settle_s:
+            scores = sweep.step()
+            torch.cuda.synchronize(device)
+            k_s += 1
+        per = (time.perf_counter() - t_s) / max(k_s, 1)
+        steps = int(min(200, max(steps, np.ceil(min_timed_s / max(per, 1e-6)))))
     # kernel time: HIP events on the stream the kernel is launched on (torch's
     # current stream), bracketing only the library call of each step; a third
     # event closes the score exchange
@@ -706,9 +768,15 @@ def run_workload(args, device, rank, world, on_host, steps, warmup,
                                             -float(red[2]), float(red[3]))
     assert scores.numel() == total_units
     finite = bool(torch.isfinite(scores).all().item())
+    # the whole sweep's scores as every rank holds them after the all-gather
+    # (same population for any number of ranks with the device sampler: a
+    # sharded run must reproduce the single-rank digest)
+    import hashlib
+    digest = hashlib.sha1(scores.detach().cpu().numpy().tobytes()).hexdigest()
     bytes_per_step = {"qsim": 8, "metric": 0,
                       "storages": ALL_OUT_BYTES[args.model]}[args.mode]
-    return dict(ens=ens, sweep=sweep, params_host=params_host, qsim=qsim,
+    return dict(steps=steps, digest=digest, first=first, ens=ens, sweep=sweep,
+                params_host=params_host, qsim=qsim,
                 qobs=qobs, f=f, name=name, scaling=scaling, n=n, t=t,
                 total_units=total_units, elapsed=elapsed, kernel_ms=kernel_ms,
                 k_min=k_min, k_max=k_max, gather_ms=gather_ms, finite=finite,
@@ -734,6 +802,13 @@ EXTRA_CONFIGS = [
      dict(model="hbvedu", mode="storages", sets=400_000)),
     ("ABC 1M sets, qsim + MSE (8 B per model-timestep)",
      dict(model="abc", mode="qsim", sets=1_000_000)),
+    # the hysteresis / ice-melt couplings, L = 5, default bounds
+    ("CemaneigeHystGR4J 1M sets, per-set MSE (next tier)",
+     dict(model="cemaneigehystgr4j", mode="metric", sets=1_000_000)),
+    ("CemaneigeGR4JIce 1M sets, per-set MSE (next tier)",
+     dict(model="cemaneigegr4jice", mode="metric", sets=1_000_000)),
+    ("CemaneigeHystGR4JIce 1M sets, per-set MSE (next tier)",
+     dict(model="cemaneigehystgr4jice", mode="metric", sets=1_000_000)),
 ]
 
 
@@ -754,8 +829,9 @@ def extra_configs(args, device):
                 setattr(a, k, v)
         try:
             r = run_workload(a, device, 0, 1, False, args.extra_steps, 1,
-                             score=score)
+                             score=score, settle_s=0.3, min_timed_s=0.06)
             rec = {"workload": label, "kernel_ms": r["kernel_ms"],
+                   "steps": r["steps"],
                    "model_timesteps_per_s": r["n"] * r["t"]
                    / (r["kernel_ms"] * 1e-3),
                    "bytes_per_unit": r["bytes_per_step"],
@@ -874,6 +950,12 @@ def main():
             # state (rank 0's GPU): at the cap, the kernel is power-bound
             "power": r["power"],
         }
+        if traffic_is_stale(args.model):
+            roof["source"]["stale"] = (
+                "profiles/traffic.json was collected on other kernel sources "
+                "than this tree's (rrmpg_amd/utils/buildid.py): traffic and "
+                "instruction count withheld until profiles/collect.sh + "
+                "make_traffic.py have run again")
         if valu:
             # the roof that actually binds the 8 B/unit mode: fp64 VALU issue.
             # floor = instructions x 4 cycles on 1024 SIMDs at the nominal
@@ -886,6 +968,21 @@ def main():
                             "clock_ghz_nominal": CLOCK_GHZ_NOMINAL,
                             "floor_ms": floor_ms,
                             "frac": floor_ms / kernel_ms}
+            pw = r["power"] or {}
+            if pw.get("sclk_mhz"):
+                # ... and at the clock the chip actually sustains under this
+                # sweep (the soak's mean shader clock): what is left in the
+                # kernel once the socket's power cap has been paid
+                f_ms = floor_ms * CLOCK_GHZ_NOMINAL * 1e3 / pw["sclk_mhz"]
+                roof["valu"]["floor_ms_at_measured_clock"] = f_ms
+                roof["valu"]["frac_at_measured_clock"] = f_ms / kernel_ms
+        pw = r["power"] or {}
+        if pw.get("socket_w") and pw.get("cap_w"):
+            # `bound` stays what the contract asks for (the HBM roof the
+            # fraction is taken against); this names the roof that BINDS
+            roof["binding_roof"] = (
+                "socket power" if pw["socket_w"] >= 0.97 * pw["cap_w"]
+                else ("hbm" if roof["frac"] >= 0.7 else "fp64 issue"))
         out = {
             "metric": "model-timesteps/s",
             "value": value,
@@ -919,7 +1016,14 @@ def main():
             "kernel_ms_per_rank": {"min": r["k_min"], "max": r["k_max"]},
             "allgather_ms": r["gather_ms"],
             "scores_finite": r["finite"],
+            "scores_digest": r["digest"],
         }
+        if r["scaling"] == "strong":
+            from rrmpg_amd.sharding import shard_bounds
+            out["config"]["shards"] = [list(shard_bounds(r["total_units"],
+                                                         world, k))
+                                       for k in range(world)]
+            assert out["config"]["shards"][0] == [r["first"], r["first"] + n]
         if not args.no_parity_spot:
             # columns of the resident result vs the CPU oracle, after timing
             out["parity_spot"] = parity_spot(args, r["f"], r["params_host"],

@@ -182,7 +182,13 @@ int rr_release_cached_memory(void);
                                   * an item only ever waits for one a running
                                   * wave already holds.  -1 by sweep size
                                   * (default), 0 never, k > 1 pieces          */
-#define RR_OPT_COUNT_          9
+#define RR_OPT_WARM_RECORDS    9 /* every time-loop kernel: the waves read a
+                                  * share of the day records with ordinary
+                                  * loads when they start, so that the loop's
+                                  * scalar loads hit the L2 of their XCD
+                                  * (DESIGN.md 3.2).  -1 by sweep size and
+                                  * mode (default), 0 never, 1 always         */
+#define RR_OPT_COUNT_          10
 int rr_debug_set_option(int option, int64_t value);
 int64_t rr_debug_get_option(int option);
 

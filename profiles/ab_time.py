@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--fused-variant", type=int, default=0)
     ap.add_argument("--gr4j-variant", type=int, default=0)
     ap.add_argument("--catchments", type=int, default=0)
+    ap.add_argument("--warm-records", type=int, default=-1)
     a = ap.parse_args()
     from rrmpg_amd import _lib
     if a.lib:
@@ -57,6 +58,7 @@ def main():
         if a.fused_variant:
             lib.rr_debug_set_option(_lib.OPTIONS["fused_variant"],
                                     a.fused_variant)
+        lib.rr_debug_set_option(_lib.OPTIONS["warm_records"], a.warm_records)
         if a.gr4j_variant:
             lib.rr_debug_set_option(_lib.OPTIONS["gr4j_variant"],
                                     a.gr4j_variant)
@@ -77,9 +79,11 @@ def main():
             q = r["qsim"]
             cols = q[:, :: max(1, q.shape[1] // 64)].contiguous().cpu().numpy()
             hq = hashlib.sha1(cols.tobytes()).hexdigest()[:10]
+        tag_ = tag + ("" if a.warm_records < 0 else "/warm%d" % a.warm_records) \
+            + ("" if a.hbv_variant < 0 else "/v%d" % a.hbv_variant)
         print("AB tag=%s model=%s mode=%s sets=%d mean_ms=%.4f min_ms=%.4f "
               "first_run_mean=%.4f scores=%s qsim=%s"
-              % (tag, a.model, a.mode, n, ms.mean(), ms.min(),
+              % (tag_, a.model, a.mode, n, ms.mean(), ms.min(),
                  r["kernel_ms"], h, hq), flush=True)
         del r, sweep
         torch.cuda.empty_cache()

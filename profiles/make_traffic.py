@@ -11,6 +11,8 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from rrmpg_amd.utils.buildid import kernel_source_id  # noqa: E402
 T = 10957
 # tag suffix -> (traffic.json key, waves' worth of sets in one launch)
 WORKLOADS = {
@@ -24,6 +26,9 @@ WORKLOADS = {
     "_fused125k": ("cemaneigegr4j:metric:125000:%d" % T, 1954),
     "_cema": ("cemaneige:qsim:1000000:%d" % T, 15625),
     "_abc": ("abc:qsim:1000000:%d" % T, 15625),
+    "_hyst": ("cemaneigehystgr4j:metric:1000000:%d" % T, 15625),
+    "_ice": ("cemaneigegr4jice:metric:1000000:%d" % T, 15625),
+    "_hystice": ("cemaneigehystgr4jice:metric:1000000:%d" % T, 15625),
 }
 
 
@@ -37,6 +42,10 @@ def main():
            "_source_valu": "the same summaries: SQ_INSTS_VALU of the sweep "
                            "kernel (x SQ_WAVES) / the waves' worth of sets / "
                            "%d days (rocprofv3 --pmc, own pass)" % T}
+    # the kernel sources the counters were collected on (bench.py quotes a
+    # model's numbers only while its sources are these)
+    out["_build"] = {m: kernel_source_id(m) for m in sorted(
+        {key.split(":")[0] for key, _ in WORKLOADS.values()})}
     for suffix, (key, jobs) in WORKLOADS.items():
         path = os.path.join(HERE, "%s%s_summary.json" % (tag, suffix))
         if not os.path.exists(path):

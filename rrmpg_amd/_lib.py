@@ -224,7 +224,7 @@ def set_device(index):
 # include/rrhip.h RR_OPT_*
 OPTIONS = {"hbv_variant": 1, "gr4j_force_lds": 2, "max_block_cols": 3,
            "gather_threads": 4, "fused_variant": 5, "gr4j_variant": 6,
-           "host_shards": 7, "time_tiles": 8}
+           "host_shards": 7, "time_tiles": 8, "warm_records": 9}
 
 
 _tls = threading.local()

@@ -46,7 +46,7 @@ extern "C" int rr_version(void) { return 100; }
 // choices.
 static std::atomic<int64_t> g_options[RR_OPT_COUNT_] = {
     {0}, {-1} /* HBV variant: heuristic */, {0}, {0}, {0}, {0}, {0}, {0},
-    {-1} /* HBV tiles: by sweep size */};
+    {-1} /* HBV tiles: by sweep size */, {-1} /* records: by sweep size */};
 static thread_local const rr_call_options *tl_call = nullptr;
 static thread_local rr_call_options tl_standing;
 static thread_local bool tl_standing_on = false;
@@ -71,6 +71,7 @@ static bool option_value_ok(int option, int64_t value)
     case RR_OPT_GATHER_THREADS: return value >= 0 && value <= 256;
     case RR_OPT_HOST_SHARDS: return value >= -1 && value <= 1024;
     case RR_OPT_TIME_TILES: return value >= -1 && value <= 64 && value != 1;
+    case RR_OPT_WARM_RECORDS: return value >= -1 && value <= 1;
     default: return false;
     }
 }

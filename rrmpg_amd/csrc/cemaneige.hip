@@ -314,6 +314,8 @@ cemaneigegr4j_kernel(
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
     if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
+    if (tiles.warm)
+        rr_warm_l2(days, (T + 1) * (int64_t)cema_record_len(L, true) * 8);
     int job = blockIdx.x, piece = 0;
     const int njobs = TILED ? (int)((N + RR_BLOCK - 1) / RR_BLOCK) : 0;
     if constexpr (TILED) {
@@ -521,10 +523,12 @@ cemaneigegr4j_opt_kernel(
     int64_t T, double snow_pack_init, double thermal_state_init,
     double s_init, double r_init, const double *__restrict__ params,
     int64_t N, const int *__restrict__ plan, int force_lds, int wq, int ws,
-    const double *__restrict__ qobs, double *__restrict__ sse)
+    const double *__restrict__ qobs, double *__restrict__ sse, int warm)
 {
     int n1cap, n2cap;
     if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
+    if (warm)
+        rr_warm_l2(days, (T + 1) * (int64_t)cema_record_len(L, true) * 8);
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 6;
@@ -968,7 +972,7 @@ extern "C" int rr_cemaneige_simulate_dev(
         return RR_OK;
     }
     // time tiles (common.h RrTiles) for sweeps of many rounds of waves
-    RrTiles tiles = {nullptr, nullptr, 0};
+    RrTiles tiles = {nullptr, nullptr, 0, 0};
     {
         const int64_t opt = rr_option(RR_OPT_TIME_TILES);
         int pieces = 0;
@@ -1145,7 +1149,12 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                        rr_option(RR_OPT_FUSED_VARIANT) != 1;
     const int fv = (int)rr_option(RR_OPT_FUSED_VARIANT);
     // time tiles (common.h RrTiles) for the many-waves kernel
-    RrTiles tiles = {nullptr, nullptr, 0};
+    // (the day records -- 17 doubles a day -- prefetched into the XCDs' L2,
+    // common.h rr_warm_l2: 65,536 sets, scores, 8.91 -> 7.71 ms; 125k 10.91
+    // -> 10.82; a million unchanged, profiles/r05_warm_family_ab.txt)
+    RrTiles tiles = {nullptr, nullptr, 0,
+                     rr_warm_choice((int64_t)grid.x, rr_simd_count(),
+                                    qsim == nullptr && G == nullptr)};
     {
         const int64_t opt = rr_option(RR_OPT_TIME_TILES);
         int pieces = 0;
@@ -1183,7 +1192,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                                 out, days, gt, T, snow_pack_init,
                                 thermal_state_init, s_init, r_init, params, N,
                                 d_plan, force_lds, qsim != nullptr,
-                                G != nullptr, qo, sse);
+                                G != nullptr, qo, sse, tiles.warm);
 #endif
 #ifndef COUPLED_OPT_NO_BIG
                     if (!sm)
@@ -1192,7 +1201,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                                 out, days, gt, T, snow_pack_init,
                                 thermal_state_init, s_init, r_init, params, N,
                                 d_plan, force_lds, qsim != nullptr,
-                                G != nullptr, qo, sse);
+                                G != nullptr, qo, sse, tiles.warm);
 #endif
                     return;
                 }
@@ -1204,7 +1213,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                             out, days, gt, T, snow_pack_init,
                             thermal_state_init, s_init, r_init, params, N,
                             d_plan, force_lds, qsim != nullptr, G != nullptr,
-                            qo, sse, uh_mem, RrTiles{nullptr, nullptr, 0});
+                            qo, sse, uh_mem, RrTiles{nullptr, nullptr, 0, tiles.warm});
                     return;
                 }
             }
@@ -1226,7 +1235,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                     out, days, gt, T, snow_pack_init, thermal_state_init,
                     s_init, r_init, params, N, d_plan, force_lds,
                     qsim != nullptr, G != nullptr, qo, sse, uh_mem,
-                    RrTiles{nullptr, nullptr, 0});
+                    RrTiles{nullptr, nullptr, 0, tiles.warm});
         });
         // ... and behind them the sets that are not civil
         // (gr4j_reference.h)

@@ -306,6 +306,43 @@ __device__ __forceinline__ unsigned rr_row_bytes(int64_t first, int64_t N)
     return rem >= RR_BLOCK ? 8u * RR_BLOCK : (rem > 0 ? (unsigned)rem * 8u : 0u);
 }
 
+// ---- the day records prefetched into the XCD's L2 -----------------------------
+// The time loops read their day records through the scalar cache, whose
+// misses go to the L2 of the wave's XCD -- and the records have just been
+// written by a pre-pass, on whatever XCD its blocks ran: the first touch of a
+// 64-byte line in an XCD goes out to the Infinity Cache / HBM, which takes
+// longer than the day or two the prefetching loops ask ahead.  A sweep of
+// several waves per SIMD never notices (another wave issues); with ONE wave on
+// a SIMD every wave of the XCD sits behind the one that leads (HBV-Edu,
+// 65,536 sets: 2.24 -> 1.51 ms, profiles/r05_hbv_warm_ab.txt).  So the waves
+// of an XCD (workgroups are dealt round-robin: XCD = linear id % 8) share out
+// the lines among themselves when they start, one ordinary load per lane, at
+// most `max_loads` per wave, interleaved so that a partial cover is an even
+// one: a few microseconds once, and the time loop's scalar loads are L2 hits
+// from then on.  A prefetch only: nothing depends on which XCD a wave really
+// runs on.  Written as asm, load and wait in one statement, no memory
+// clobber: as C++ -- or with the clobber -- hipcc no longer takes global
+// memory for unwritten, and a kernel that reads its records through the
+// global address space gets them by vector loads, in VGPRs.
+__device__ __forceinline__ void rr_warm_l2(const void *base, int64_t nbytes,
+                                           int max_loads = 4)
+{
+    const int64_t nlines = (nbytes + 63) / 64;
+    const int64_t wg = blockIdx.x + (int64_t)blockIdx.y * gridDim.x;
+    const int64_t R = ((int64_t)gridDim.x * gridDim.y + 7) / 8;
+    const int64_t r = wg >> 3;
+    for (int m = 0; m < max_loads; ++m) {
+        const int64_t line = ((int64_t)m * RR_BLOCK + threadIdx.x) * R + r;
+        if (line < nlines) {
+            const char *ptr = (const char *)base + line * 64;
+            double dummy;
+            asm volatile("global_load_dwordx2 %0, %1, off\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(dummy) : "v"(ptr));
+        }
+    }
+}
+
 // ---- the time axis in pieces ------------------------------------------------
 // A million-set sweep is 15,625 waves of equal duration on 1,024 SIMDs: 15.26
 // per SIMD, so 265 SIMDs run a sixteenth wave while the others idle -- the
@@ -338,7 +375,21 @@ struct RrTiles {
     int *queue;        // [0]: ticket counter; [1 + job]: pieces of the job done
     double *state;     // hand-over scratch
     int pieces;        // 0 / 1: untiled
+    int warm;          // != 0: the waves prefetch the day records into their
+                       // XCD's L2 when they start (rr_warm_l2; rides along
+                       // here because these kernels take the struct anyway)
 };
+// sweeps whose waves prefetch their day records (rr_warm_l2): one wave per
+// SIMD at most, or nothing but scores written (measured for HBV-Edu,
+// hbvedu.hip hbv_launch; the GR4J family: profiles/r05_warm_family_ab.txt)
+int64_t rr_option(int option);
+int rr_simd_count();
+static inline int rr_warm_choice(int64_t waves, int64_t simds, bool score_only)
+{
+    const int64_t opt = rr_option(RR_OPT_WARM_RECORDS);
+    if (opt >= 0) return opt != 0;
+    return (waves <= simds || score_only) ? 1 : 0;
+}
 // days [b, e) of piece `piece` of the days [t0, t1); piece lengths are
 // multiples of `even` (2 for the loops that run two days per trip)
 __device__ __forceinline__ void rr_tile_range(int t0, int t1, int pieces,

@@ -225,6 +225,7 @@ void gr4j_opt_kernel(
     const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
     typedef const GrDay __attribute__((address_space(4))) *day_ptr_t;
     const day_ptr_t dp = (day_ptr_t)days;
+    if (tiles.warm) rr_warm_l2(days, T * (int64_t)sizeof(GrDay));
     // (TILED == 1: one single-wave workgroup per item, the item a ticket
     // drawn when the wave starts -- common.h "the time axis in pieces";
     // TILED == 2, the persistent loop around this kernel's two-generation
@@ -672,7 +673,13 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     const int variant = (int)rr_option(RR_OPT_GR4J_VARIANT);
     const int64_t waves = rr_ceil_div(N, RR_BLOCK);
     // time-tiled persistent form of the optimistic kernel (common.h RrTiles)
-    RrTiles tiles = {nullptr, nullptr, 0};
+    // (the day records prefetched into the XCDs' L2, common.h rr_warm_l2:
+    // only on request -- GR4J's day is issue-bound and its record asked for a
+    // day and a half ahead: 65,536 sets 3.66 / 3.64 ms without / with,
+    // scores only 3.37 / 3.34, 125k with qsim 5.71 / 6.00,
+    // profiles/r05_warm_family_ab.txt)
+    RrTiles tiles = {nullptr, nullptr, 0,
+                     rr_option(RR_OPT_WARM_RECORDS) == 1 ? 1 : 0};
     {
         const int64_t opt = rr_option(RR_OPT_TIME_TILES);
         int pieces = 0;

@@ -310,9 +310,6 @@ __device__ __forceinline__ HbvDay hbv_load_day(const HbvDay *days, int64_t t)
 #endif
 // timing experiments only (wrong results): 1 every day takes the power's
 // branch, 2 no day does
-#ifndef HBV_WARM_L2_MAX_PER_SIMD
-#define HBV_WARM_L2_MAX_PER_SIMD 1
-#endif
 #ifndef HBV_WARM_L2_LOADS
 #define HBV_WARM_L2_LOADS 4
 #endif
@@ -363,42 +360,11 @@ hbvedu_kernel(
     double *const qsim0 = qsim, *const snow0 = snow_out, *const soil0 = soil_out,
                  *const s10 = s1_out, *const s20 = s2_out, *const sse0 = sse;
     if (HBV_WARM_L2 != 0 && !REFERENCE && warm != 0) {
-        // The day records are read through the scalar cache, whose misses go
-        // to the L2 of the wave's XCD -- and the records have just been
-        // written by the pre-pass, on whatever XCD its blocks ran: the first
-        // touch of a 64-byte line (1.3 days) in an XCD goes out to the
-        // Infinity Cache / HBM, which takes longer than the day or two the
-        // prefetching loops ask ahead.  A sweep of several waves per SIMD
-        // never notices (another wave issues); with ONE wave on a SIMD every
-        // wave of the XCD sits behind the one that leads (65,536 sets: 2.32
-        // -> 1.98 ms, profiles/r05_hbv_soilpow_ab.txt).  So the waves of an
-        // XCD (workgroups are dealt round-robin: XCD = linear id % 8) share
-        // out the lines among themselves, one ordinary load per lane, at
-        // most four per wave, interleaved so that a partial cover is an even
-        // one: a few microseconds once, and the time loop's scalar loads are
-        // L2 hits from then on.  A prefetch only: nothing depends on which
-        // XCD a wave really runs on.  (Written as asm, load and wait in one
-        // statement, no memory clobber: as C++ -- or with the clobber -- hipcc
-        // no longer takes the records for read-only, fetches them with vector
-        // loads and keeps them in VGPRs: four more vector instructions a
-        // day.)  `warm`: the launch's choice (hbv_launch).
+        // the day records into this XCD's L2 (common.h rr_warm_l2); `warm`:
+        // the launch's choice (hbv_launch)
         const int64_t ctotal = TILED == 2 ? ncatch : (int64_t)gridDim.y;
-        const int64_t nlines =
-            (T * ctotal * (int64_t)sizeof(HbvDay) + 63) / 64;
-        const int64_t wg = blockIdx.x + (int64_t)blockIdx.y * gridDim.x;
-        const int64_t R = ((int64_t)gridDim.x * gridDim.y + 7) / 8;
-        const int64_t r = wg >> 3;
-        const char *base = (const char *)days;
-        for (int m = 0; m < HBV_WARM_L2_LOADS; ++m) {
-            const int64_t line = ((int64_t)m * RR_BLOCK + threadIdx.x) * R + r;
-            if (line < nlines) {
-                const char *ptr = base + line * 64;
-                double dummy;
-                asm volatile("global_load_dwordx2 %0, %1, off\n\t"
-                             "s_waitcnt vmcnt(0)"
-                             : "=&v"(dummy) : "v"(ptr));
-            }
-        }
+        rr_warm_l2(days, T * ctotal * (int64_t)sizeof(HbvDay),
+                   HBV_WARM_L2_LOADS);
     }
   for (;;) {           // TILED: one work item per trip; otherwise one trip
     int job = blockIdx.x, piece = 0, slot = 0, catchment = blockIdx.y;
@@ -1234,10 +1200,16 @@ static int hbv_launch(const double *temp, const double *prec,
     // write the same rows at the same time, which the memory system likes
     // better than 2,000 waves each at a row of its own.
     const bool score_only = qsim == nullptr && snow == nullptr;
-    const int warm = (HBV_WARM_L2 == 2 || score_only ||
-                      waves <= HBV_WARM_L2_MAX_PER_SIMD * simds) ? 1 : 0;
+    const int warm = rr_warm_choice(waves, simds, score_only);
     const int64_t many_waves = 6 * simds;
-    int variant = waves <= 2 * simds ? 3 : (waves > many_waves ? 0 : 2);
+    // (round 5, with the shorter power and the trip-wise row addressing:
+    // the three-record loop wins up to six waves per SIMD -- kernel ms 0 / 2 /
+    // 3 with qsim: 250k sets 4.96 / 4.98 / 4.76, 375k 7.83 / 7.02 / 6.97;
+    // scores only 250k 3.78 / 3.80 / 3.55, 375k 5.26 / 5.22 / 4.94 -- and
+    // the tiled plain loop beyond: 400k 7.02 / 8.02 / 8.01, 500k 8.80 / 9.48 /
+    // 9.14, 750k 12.84 / 14.00 / 13.61; profiles/r05_mid_sizes.txt.  Variant
+    // 2 is no longer chosen.)
+    int variant = waves > many_waves ? 0 : 3;
     const int64_t pinned = rr_option(RR_OPT_HBV_VARIANT);
     if (pinned >= 0) variant = (int)pinned;
     // time-tiled persistent form (hbvedu_kernel's TILED), variants 0 and 3:

@@ -77,29 +77,74 @@ def test_default_line_carries_every_config_and_the_valu_roof():
     assert d["config"]["timesteps"] == 10957 and d["config"]["mode"] == "qsim"
     assert 0 <= d["parity_spot"] < 1e-10
     r = d["roofline"]
-    assert r["traffic"] and r["valu_instr_per_unit"]
     assert "profiles/traffic.json" in r["source"]["traffic"]
-    v = r["valu"]
-    assert v["cycles_per_instr"] == 4 and v["simds"] == 1024
-    assert abs(v["frac"] - v["floor_ms"] / r["kernel_ms"]) < 1e-12
-    assert 0.4 < v["frac"] < 1.0 and 0.3 < r["frac"] < 1.0
+    if "stale" in r["source"]:
+        # the kernels have changed since the committed counter passes
+        # (rrmpg_amd/utils/buildid.py): their numbers are withheld
+        assert r["traffic"] is None and r["valu_instr_per_unit"] is None
+        assert "valu" not in r
+    else:
+        assert r["traffic"] and r["valu_instr_per_unit"]
+        v = r["valu"]
+        assert v["cycles_per_instr"] == 4 and v["simds"] == 1024
+        assert abs(v["frac"] - v["floor_ms"] / r["kernel_ms"]) < 1e-12
+        assert 0.4 < v["frac"] < 1.0
+        if r["power"] and r["power"]["sclk_mhz"]:
+            # the same floor at the clock the chip sustains under the sweep
+            assert v["frac"] <= v["frac_at_measured_clock"] < 1.05
+            assert r["binding_roof"] in ("socket power", "hbm", "fp64 issue")
+    assert 0.3 < r["frac"] < 1.0
     # socket power / shader clock of the same sweep in steady state, read
     # after the timed region (None where the GPU has no hwmon files)
     pw = r["power"]
     assert pw is None or (pw["samples"] >= 1 and 50 < pw["socket_w"] < 3000
                           and pw["soak_steps"] >= 4)
     ex = d["extra_configs"]
-    assert len(ex) == 6
+    assert len(ex) == 9
     for e in ex:
         assert "error" not in e, e
         assert e["kernel_ms"] > 0 and e["scores_finite"] is True
-        assert e["parity_spot"] is None or 0 <= e["parity_spot"] < 1e-10, e
+        # every configuration -- the hysteresis / ice couplings included --
+        # carries its parity spot against the oracle
+        assert 0 <= e["parity_spot"] < 1e-10, e
+        assert e["steps"] >= 2
         if e["bytes_per_unit"]:
             assert 0 < e["frac"] < 1
     by = {e["workload"].split(",")[0]: e for e in ex}
     assert by["ABC 1M sets"]["frac"] > 0.6          # the HBM-bound kernels
     assert by["HBV-Edu 400k sets"]["frac"] > 0.6
     assert any(e["score"] == "nse" for e in ex)     # configs[3]
+    for name in ("CemaneigeHystGR4J", "CemaneigeGR4JIce",
+                 "CemaneigeHystGR4JIce"):
+        assert by[name + " 1M sets"]["kernel_ms"] > 0
+
+
+def test_eight_ranks_rehearsal_on_one_gpu():
+    """As far as one GPU allows towards the 8-GPU job: the driver's launch
+    line with eight ranks sharing the device over gloo, a ragged total of
+    1,000,003 sets, strong scaling.  The partition is shard_bounds', and the
+    all-gathered scores are those of the single-rank sweep, bit for bit (the
+    ranks draw their rows of ONE Philox population)."""
+    from rrmpg_amd.sharding import shard_bounds
+    common = ["--steps", "2", "--warmup", "1", "--sets", "1000003", "--mode",
+              "metric", "--no-extra-configs", "--no-cpu-baseline",
+              "--no-parity-spot", "--no-power-soak"]
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common)
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+              "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+              "--master-port", "29583", "bench.py", "--gpus", "8",
+              "--backend", "gloo", "--share-gpu"] + common,
+             env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["sets_total"] == 1000003
+    assert d["config"]["shards"] == [list(shard_bounds(1000003, 8, r))
+                                     for r in range(8)]
+    assert d["config"]["sets_per_gpu"] == 125001       # rank 0: a longer block
+    assert d["scores_finite"] is True
+    assert d["scores_digest"] == one["scores_digest"]
+    units = 1000003 * 10957 * 2
+    assert abs(d["value"] - units / (d["ms_per_step"] * 2e-3)) \
+        <= 1e-6 * d["value"]
 
 
 def test_two_ranks_share_the_gpu_over_gloo():

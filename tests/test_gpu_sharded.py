@@ -113,6 +113,29 @@ def test_monte_carlo_gpus_and_sharding_sweep(env):
             monte_carlo(m.HBVEdu(), 10, qobs=qobs, gpus=bad, **kw)
 
 
+def test_monte_carlo_over_eight_shards_with_qsim(env):
+    """monte_carlo(gpus=8) as an eight-GPU node would run it -- eight shards
+    of a ragged total inside the one host-pointer call, all on this box's one
+    device --: discharge columns and scores of the single launch."""
+    from rrmpg_amd.tools import monte_carlo
+    m, f = env["models"], env["f"]
+    kw = dict(temp=f["temp"], prec=f["prec"], month=f["month"],
+              PE_m=f["PE_m"], T_m=f["T_m"], **env["syn"].HBV_INITS)
+    n = 20011
+    np.random.seed(11)
+    base = monte_carlo(m.HBVEdu(), 8, qobs=None, **kw)
+    qobs = base["qsim"][:, 5] * 0.97 + 0.01
+    np.random.seed(12)
+    one = monte_carlo(m.HBVEdu(), n, qobs=qobs, score="nse", **kw)
+    np.random.seed(12)
+    eight = monte_carlo(m.HBVEdu(), n, qobs=qobs, gpus=8, score="nse",
+                        return_qsim=True, **kw)
+    assert eight["qsim"].shape == (len(qobs), n)
+    for key in ("qsim", "mse", "nse"):
+        assert np.array_equal(one[key], eight[key]), key
+    assert np.array_equal(one["params"], eight["params"])
+
+
 def test_concurrent_sweeps_keep_their_own_options(env):
     """The shard count travels with the CALL (rr_<model>_simulate_opt's
     rr_call_options), not through a process-wide switch: two threads running

@@ -417,6 +417,8 @@ def test_debug_options_and_cache_release_need_no_gpu():
     assert lib.rr_debug_get_option(opt["gr4j_variant"]) == 0
     assert lib.rr_debug_set_option(opt["gr4j_variant"], 5) == -4
     assert b"does not take" in lib.rr_last_error()
+    assert lib.rr_debug_get_option(opt["warm_records"]) == -1
+    assert lib.rr_debug_set_option(opt["warm_records"], 2) == -4
     assert lib.rr_debug_set_option(99, 0) == -4
     assert lib.rr_debug_get_option(99) == -2 ** 63
     assert lib.rr_release_cached_memory() == 0
