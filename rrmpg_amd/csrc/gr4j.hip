@@ -595,6 +595,142 @@ int rr_gr4j_plan_async(const double *params, int64_t N, int stride,
     return RR_OK;
 }
 
+// ---- side streams for a launch's tier kernels (snow_core.h) ------------------
+// Per thread and device, created on first use, never destroyed (a handful of
+// streams and events per calling thread).
+namespace {
+struct TierStreams {
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, done[3] = {nullptr, nullptr, nullptr};
+    bool ok = false;
+};
+constexpr int RR_TIER_MAX_DEVICES = 64;
+thread_local TierStreams tl_tier[RR_TIER_MAX_DEVICES];
+TierStreams *tier_streams()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 ||
+        dev >= RR_TIER_MAX_DEVICES)
+        return nullptr;
+    TierStreams &t = tl_tier[dev];
+    if (!t.ok) {
+        for (int k = 0; k < 3; ++k) {
+            if (hipStreamCreateWithFlags(&t.side[k], hipStreamNonBlocking) !=
+                    hipSuccess ||
+                hipEventCreateWithFlags(&t.done[k], hipEventDisableTiming) !=
+                    hipSuccess)
+                return nullptr;
+        }
+        if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) !=
+            hipSuccess)
+            return nullptr;
+        t.ok = true;
+    }
+    return &t;
+}
+thread_local TierStreams *tl_tier_now = nullptr;
+}  // namespace
+int rr_tier_fork(hipStream_t st)
+{
+    tl_tier_now = tier_streams();
+    if (!tl_tier_now) {
+        (void)hipGetLastError();
+        return RR_OK;                  // no side streams: everything on `st`
+    }
+    RR_HIP(hipEventRecord(tl_tier_now->fork, st));
+    for (int k = 0; k < 3; ++k)
+        RR_HIP(hipStreamWaitEvent(tl_tier_now->side[k], tl_tier_now->fork, 0));
+    return RR_OK;
+}
+hipStream_t rr_tier_stream(int k)
+{
+    return tl_tier_now ? tl_tier_now->side[k] : nullptr;
+}
+int rr_tier_join(hipStream_t st)
+{
+    if (!tl_tier_now) return RR_OK;
+    for (int k = 0; k < 3; ++k) {
+        RR_HIP(hipEventRecord(tl_tier_now->done[k], tl_tier_now->side[k]));
+        RR_HIP(hipStreamWaitEvent(st, tl_tier_now->done[k], 0));
+    }
+    tl_tier_now = nullptr;
+    return RR_OK;
+}
+
+// ---- the sets of a launch ordered by ceil(x4) -------------------------------
+// For the per-wave tiers (gr4j_core.h gr4j_wave_selects) of a sweep that
+// writes nothing but scores: a counting sort by n1 = ceil(x4) (64 bins; a
+// set without ordinates goes to bin 0, n1 >= 63 to bin 63) into `perm` -- wave
+// w then simulates the sets perm[64 w .. 64 w + 63] and writes their scores
+// to their own places.  Three tiny kernels, about 30 us for a million sets;
+// the order inside a bin is whatever the atomics give (a set's result does
+// not depend on its wave-mates).
+#define GR4J_SORT_BINS 64
+__device__ __forceinline__ int gr4j_sort_key(double x4)
+{
+    const int n1 = gr4j_num_uh1(x4);
+    return n1 < 1 ? 0 : (n1 >= GR4J_SORT_BINS ? GR4J_SORT_BINS - 1 : n1);
+}
+__global__ void gr4j_sort_count(const double *__restrict__ params, int64_t N,
+                                int stride, int x4_index,
+                                int *__restrict__ bins)
+{
+    __shared__ int local[GR4J_SORT_BINS];
+    if (threadIdx.x < GR4J_SORT_BINS) local[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&local[gr4j_sort_key(params[i * stride + x4_index])], 1);
+    __syncthreads();
+    if (threadIdx.x < GR4J_SORT_BINS && local[threadIdx.x])
+        atomicAdd(&bins[threadIdx.x], local[threadIdx.x]);
+}
+__global__ void gr4j_sort_offsets(int *__restrict__ bins)
+{
+    // bins[0..63]: counts -> bins[64..127]: where each bin starts
+    if (threadIdx.x == 0) {
+        int at = 0;
+        for (int b = 0; b < GR4J_SORT_BINS; ++b) {
+            bins[GR4J_SORT_BINS + b] = at;
+            at += bins[b];
+        }
+    }
+}
+__global__ void gr4j_sort_place(const double *__restrict__ params, int64_t N,
+                                int stride, int x4_index,
+                                int *__restrict__ bins, int *__restrict__ perm)
+{
+    __shared__ int local[GR4J_SORT_BINS], base[GR4J_SORT_BINS];
+    int *cursor = bins + GR4J_SORT_BINS;
+    const int64_t chunk = (int64_t)blockIdx.x * blockDim.x;
+    if (threadIdx.x < GR4J_SORT_BINS) local[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = chunk + threadIdx.x;
+    int key = 0, rank = 0;
+    if (i < N) {
+        key = gr4j_sort_key(params[i * stride + x4_index]);
+        rank = atomicAdd(&local[key], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < GR4J_SORT_BINS && local[threadIdx.x])
+        base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], local[threadIdx.x]);
+    __syncthreads();
+    if (i < N) perm[base[key] + rank] = (int)i;
+}
+int rr_gr4j_tier_sort_async(const double *params, int64_t N, int stride,
+                            int x4_index, int *bins, int *perm,
+                            hipStream_t st)
+{
+    RR_HIP(hipMemsetAsync(bins, 0, 2 * GR4J_SORT_BINS * sizeof(int), st));
+    int blocks = (int)rr_ceil_div(N, 256);
+    hipLaunchKernelGGL(gr4j_sort_count, dim3(blocks > 1024 ? 1024 : blocks),
+                       dim3(256), 0, st, params, N, stride, x4_index, bins);
+    hipLaunchKernelGGL(gr4j_sort_offsets, dim3(1), dim3(64), 0, st, bins);
+    hipLaunchKernelGGL(gr4j_sort_place, dim3(blocks), dim3(256), 0, st, params,
+                       N, stride, x4_index, bins, perm);
+    return RR_OK;
+}
+
 extern "C" int rr_gr4j_plan_status(const void *workspace, void *stream)
 {
     if (!workspace) {

@@ -493,6 +493,40 @@ __device__ __forceinline__ bool gr4j_plan_selects(const int *__restrict__ plan,
     return gr4j_plan_tier(mx, bad, force_lds, mem_cap) == UH::TIER;
 }
 
+// ... refined per WAVE (round 5): every tier's kernel runs over the whole grid
+// anyway, so a wave need not take the tier of the launch's largest x4 -- it
+// takes the smallest register tier that holds ITS 64 sets' hydrographs, and
+// returns from every other tier's kernel.  A set's bits do not depend on the
+// tier that ran it (tests/test_gpu_parity.py
+// test_a_sets_bits_do_not_depend_on_its_launch), so nothing changes but the
+// time: under bounds that reach x4 = 10 (the hysteresis couplings' defaults)
+// the sets of a wave are as random as the population and most waves still
+// need the widest tier -- but a score-only sweep can take its sets in any
+// order, and with the sets sorted by ceil(x4) (gr4j_tier_sort_async below)
+// a fifth of the waves run in the 3-register tier and another quarter in the
+// 5-register one.  Launches whose plan selects the HBM-scratch tier, no tier
+// at all, or that are pinned to LDS stay whole (their slabs are sized by the
+// launch's largest x4).  `x4`: the lane's own (tail lanes: the last set's).
+template <class UH>
+__device__ __forceinline__ bool gr4j_wave_selects(const int *__restrict__ plan,
+                                                  int force_lds, double x4,
+                                                  int &n1cap, int &n2cap)
+{
+    const int mx = plan[0], bad = plan[1];        // wave-uniform scalar loads
+    const int mem_cap = plan[2];
+    n1cap = mx;
+    n2cap = 2 * mx + 1;
+    const int launch = gr4j_plan_tier(mx, bad, force_lds, mem_cap);
+    if (launch < 0 || launch == GR4J_TIER_MEM || force_lds || launch == 3)
+        return launch == UH::TIER;
+    const int n1 = gr4j_num_uh1(x4);
+    int wave = 3;
+    if (RR_LANES(n1 > 3) != 0) wave = 5;
+    if (RR_LANES(n1 > 5) != 0) wave = 10;
+    if (RR_LANES(n1 > 10) != 0) wave = GR4J_TIER_LDS;
+    return wave == UH::TIER;
+}
+
 // Hydrograph state of the lane, whichever tier: `lds` the workgroup's dynamic
 // LDS, `uh_mem` the launch's unit-hydrograph scratch (single-wave workgroups:
 // wave = blockIdx.x).

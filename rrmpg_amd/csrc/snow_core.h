@@ -12,6 +12,22 @@ int rr_gr4j_plan_async(const double *params, int64_t N, int stride,
 // defined in gr4j.hip: bytes of unit-hydrograph scratch (UhMem, gr4j_core.h)
 // behind a workspace whose launch may hold x4 up to max_x4 (0 up to 20)
 size_t rr_gr4j_uh_scratch_bytes(int64_t N, double max_x4);
+// Side streams for the tier kernels of one launch (gr4j.hip): with the waves
+// choosing their own tier (gr4j_core.h gr4j_wave_selects) every tier's kernel
+// has work, and enqueued on ONE stream they would run one after the other,
+// each with a fraction of the GPU.  rr_tier_fork makes the calling thread's
+// side streams of the current device wait for what `st` holds so far,
+// rr_tier_stream(k) hands out side stream k (0..2), rr_tier_join makes `st`
+// wait for all of them.  Events only: nothing blocks the host, and a stream
+// capture of `st` follows the fork into the side streams.
+int rr_tier_fork(hipStream_t st);
+hipStream_t rr_tier_stream(int k);
+int rr_tier_join(hipStream_t st);
+// the sets of a launch ordered by ceil(x4) (gr4j.hip): `perm` [N] ints,
+// `bins` 128 ints of scratch
+int rr_gr4j_tier_sort_async(const double *params, int64_t N, int stride,
+                            int x4_index, int *bins, int *perm,
+                            hipStream_t st);
 
 // Day record of the snow kernels, D = cema_record_len(L, with_etp) doubles:
 //   [0, L) snow   [L, 2L) rain   [2L, 3L) mean temperature   [3L] etp (if any)

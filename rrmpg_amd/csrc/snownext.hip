@@ -177,14 +177,20 @@ snow_gr4j_kernel(
     const double *__restrict__ params, SnowParLayout lay, int64_t N,
     const int *__restrict__ plan, int force_lds, int wq, int ws,
     const double *__restrict__ qobs, double *__restrict__ sse,
-    double *__restrict__ uh_mem)
+    double *__restrict__ uh_mem, const int *__restrict__ perm)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    // `perm` (score-only sweeps, or NULL): the sets ordered by ceil(x4), so
+    // that most waves need a narrower hydrograph tier than the launch's
+    // widest (gr4j_core.h gr4j_wave_selects); lane g simulates set perm[g]
+    const int64_t g_lane = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
+    const bool active = g_lane < N;
+    const int64_t g_set = active ? g_lane : N - 1;
+    const int64_t i = perm ? (int64_t)perm[g_set] : g_lane;
+    const double *p = params + (perm ? i : g_set) * lay.npar;
     int n1cap, n2cap;
-    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
-    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
-    const bool active = i < N;
-    const double *p = params + (active ? i : N - 1) * lay.npar;
+    if (!gr4j_wave_selects<UH>(plan, force_lds, p[lay.i_x1 + 3], n1cap, n2cap))
+        return;
     const double CTG = p[0], Kf = p[1];
     const double Rsp = HYST ? p[3] : 0.0;
     const InvDivisor inv_Thacc = make_inv_divisor(HYST ? p[2] : 1.0);
@@ -618,16 +624,50 @@ static int snow_gr4j_dev(const char *who, const double *prec,
         RR_HIP(hipGetLastError());
         return RR_OK;
     }
+    // A sweep that writes nothing but scores takes its sets in the order of
+    // their ceil(x4): the waves then pick their own hydrograph tier
+    // (gr4j_core.h gr4j_wave_selects).  The order lives where the tiled
+    // kernels of cemaneige.hip keep their hand-over scratch (unused here).
+    // From four waves per SIMD on: there every tier's share of the waves still
+    // fills the GPU (1M sets under the hysteresis couplings' default bounds:
+    // 146.8 -> 140.0 ms, hysteresis + ice 165.4 -> 156.5,
+    // profiles/r05_n1_tiers_ab.txt); a smaller sweep keeps its order, and its
+    // waves -- 64 sets drawn from the whole range of x4 -- the launch's tier.
+    const int *perm = nullptr;
+    const bool by_tier = !qsim && !G && qo && N < 0x7fffffff &&
+                         rr_ceil_div(N, RR_BLOCK) >= 4 * (int64_t)rr_simd_count();
+    if (by_tier) {
+        int *bins = (int *)((char *)workspace + cema_tile_offset(T, L, true));
+        int *pm = bins + 128;
+        rc = rr_gr4j_tier_sort_async(params, N, lay.npar, lay.i_x1 + 3, bins,
+                                     pm, st);
+        if (rc != RR_OK) return rc;
+        perm = pm;
+    }
+    // every tier's kernel on a stream of its own (the narrowest register tier
+    // stays on the caller's: a launch inside the default bounds of the plain
+    // GR4J family runs as it always has): with the waves choosing their tiers
+    // all of them have work, and they are to share the GPU, not to take turns
+    if (by_tier) {
+        rc = rr_tier_fork(st);
+        if (rc != RR_OK) return rc;
+    }
     dispatch_layers((int)L, [&](auto LL) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
+            hipStream_t ts = st;
+            if (std::is_same<UH, UhRegs<5>>::value) ts = rr_tier_stream(0);
+            else if (std::is_same<UH, UhRegs<10>>::value) ts = rr_tier_stream(1);
+            else if (std::is_same<UH, UhLds>::value) ts = rr_tier_stream(2);
+            if (!ts || !by_tier) ts = st;
             snow_gr4j_kernel<LL.value, UH, HYST, ICE>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
-                   st>>>(out, days, gt, frac_ice, T, snow_pack_init,
+                   ts>>>(out, days, gt, frac_ice, T, snow_pack_init,
                          thermal_state_init, sca_init, s_init, r_init, params,
                          lay, N, d_plan, force_lds, qsim != nullptr,
-                         G != nullptr, qo, sse, uh_mem);
+                         G != nullptr, qo, sse, uh_mem, perm);
         });
+        if (by_tier) (void)rr_tier_join(st);
         // ... and behind them the sets that are not civil
         // (gr4j_reference.h)
         snow_gr4j_reference_kernel<LL.value, HYST, ICE>

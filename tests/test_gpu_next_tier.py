@@ -345,6 +345,45 @@ def test_next_tier_resident_ensembles_match_host_path(models):
         assert np.array_equal(sse.cpu().numpy(), sse_h)
 
 
+def test_score_only_sweeps_sorted_by_tier_keep_every_sets_bits(models):
+    """A score-only sweep of four or more waves per SIMD takes its sets in
+    the order of their ceil(x4) (csrc/gr4j.hip rr_gr4j_tier_sort_async) and
+    lets every wave run in the narrowest hydrograph tier that holds its own
+    sets (gr4j_core.h gr4j_wave_selects), the tiers' kernels side by side on
+    streams of their own: the scores are those of the sweep that writes qsim
+    (its order untouched, every wave in the launch's widest tier), set by
+    set, bit for bit -- sets beyond the register tiers (x4 up to 18) and a
+    ragged tail included."""
+    import torch
+    from rrmpg_amd import device as rrdev
+    h = golden("syn_cemaneigehystgr4j")
+    t = 120
+    layers = tuple(h[k][:t] for k in ("layer_prec", "layer_mean",
+                                      "frac_solid", "etp"))
+    fice = np.array([0.0, 0.1, 0.3, 0.6, 0.9])
+    n = 4 * 1024 * 64 + 777
+    for (hyst, ice), cls, hi in [((True, False), models.CemaneigeHystGR4J, 10),
+                                 ((True, True), models.CemaneigeHystGR4JIce,
+                                  18)]:
+        np.random.seed(5)
+        p = cls().get_random_params(n)
+        p["x4"] = np.random.uniform(1.1, hi, size=n)
+        ens = rrdev.SnowGR4JEnsemble(
+            hyst, ice, layers[0], layers[1], layers[2], layers[3],
+            frac_ice=fice if ice else None, s_init=0.5, r_init=0.6)
+        ens.max_x4 = float(hi)
+        params = ens.upload_params(p)
+        q = ens.new_output(n)
+        ens.run(params, q)
+        qobs = (q[:, 7] * 0.9 + 0.05).contiguous()
+        sse_q = ens.run(params, q, qobs=qobs).clone()      # with qsim: plain
+        sse_s = ens.run(params, None, qobs=qobs).clone()   # scores: by tier
+        torch.cuda.synchronize()
+        ens.check()
+        assert torch.isfinite(sse_q).all()
+        assert torch.equal(sse_q, sse_s)
+
+
 def test_monte_carlo_every_model_class(models):
     """rrmpg_amd.tools.monte_carlo works for EVERY model class, as the
     reference's does (monte_carlo.py:64 goes through model.simulate): the
