@@ -516,10 +516,28 @@ def end_to_end(args, n=100_000):
     finite = bool(np.isfinite(q[-1]).all())
     nbytes = q.nbytes
     del q
-    np.random.seed(1)
-    t0 = time.perf_counter()
-    mc = monte_carlo(m, n, qobs=qobs, return_qsim=False, **kw)
-    t_mc = time.perf_counter() - t0
+    t_mc = None
+    for _ in range(3):                  # (best of three: one call is 6 ms)
+        np.random.seed(1)
+        t0 = time.perf_counter()
+        mc = monte_carlo(m, n, qobs=qobs, return_qsim=False, **kw)
+        dt = time.perf_counter() - t0
+        t_mc = dt if t_mc is None else min(t_mc, dt)
+    # the same call with the sets drawn in HBM (sampler='device'), at the
+    # configuration's 100k sets and at the headline's million: what the
+    # reference's monte_carlo(model, num, qobs) costs a user end to end
+    monte_carlo(m, 1000, qobs=qobs, return_qsim=False, sampler="device",
+                seed=1, **kw)                              # ensemble upload
+    dev_times = {}
+    for nn in (n, 1_000_000):
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r_dev = monte_carlo(m, nn, qobs=qobs, return_qsim=False,
+                                sampler="device", seed=7, **kw)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        dev_times[nn] = (best, bool(np.isfinite(r_dev["mse"]).all()))
     _lib.load().rr_release_cached_memory()
     steps = n * args.days
     return {
@@ -532,10 +550,23 @@ def end_to_end(args, n=100_000):
         "finite": finite,
         "monte_carlo_scores_only": {
             "workload": "monte_carlo(HBVEdu, %d, qobs, return_qsim=False): "
-                        "sampling, upload, sweep, per-set MSE back" % n,
+                        "sets drawn on the host (numpy's global generator, "
+                        "the reference's contract: ~3.8 ms of the call), "
+                        "upload, sweep, per-set MSE back; best of three "
+                        "calls" % n,
             "seconds": t_mc,
             "model_timesteps_per_s": steps / t_mc,
             "finite": bool(np.isfinite(mc["mse"]).all())},
+        "monte_carlo_device_sampler": {
+            "workload": "monte_carlo(HBVEdu, num, qobs, return_qsim=False, "
+                        "sampler='device'): forcing validated and uploaded, "
+                        "sets drawn in HBM, sweep, per-set MSE back (best of "
+                        "three calls)",
+            "seconds_100k": dev_times[n][0],
+            "seconds_1m": dev_times[1_000_000][0],
+            "model_timesteps_per_s_1m":
+                1_000_000 * args.days / dev_times[1_000_000][0],
+            "finite": dev_times[n][1] and dev_times[1_000_000][1]},
         "note": "PCIe-inclusive, single GPU; never the line's `value`",
     }
 

@@ -260,7 +260,8 @@ class call_options:
     def __enter__(self):
         self.prev = getattr(_tls, "stack", None)
         merged = dict(self.prev[0]) if self.prev else {}
-        merged.update(self.values)
+        # (None: "not set here" -- the enclosing block's value stays)
+        merged.update({k: v for k, v in self.values.items() if v is not None})
         _tls.stack = (merged, _new_options(merged))
         return self
 
@@ -272,7 +273,9 @@ class call_options:
 def host_shards_of(gpus):
     """The RR_OPT_HOST_SHARDS value of a ``gpus=`` argument: None -> unset
     (the current device), 'all' -> -1 (one shard per visible device), a
-    positive int -> that many shards."""
+    positive int -> that many shards.  (0 is rejected since round 4: it
+    used to mean "the current device", which None says; an integral float
+    such as 2.0 counts as its int.)"""
     if gpus is None:
         return None
     if isinstance(gpus, str):
@@ -294,19 +297,35 @@ def opts_ptr():
 class thread_options:
     """``with thread_options(hbv_variant=0): ens.run(...)`` -- standing
     options of the calling thread (rr_thread_options) for the *_simulate_dev
-    family, which has no per-call argument; cleared on exit."""
+    family, which has no per-call argument.  Nested blocks merge, the inner
+    one winning (None: the enclosing block's value stays); on exit the
+    enclosing block's options stand again (cleared behind the outermost)."""
 
     def __init__(self, **values):
+        for name in values:
+            if name not in OPTIONS:
+                raise KeyError("unknown option %r (one of %s)"
+                               % (name, sorted(OPTIONS)))
         self.values = values
 
     def __enter__(self):
-        opt = _new_options(self.values)
+        self.prev = getattr(_tls, "standing", None)
+        merged = dict(self.prev) if self.prev else {}
+        merged.update({k: v for k, v in self.values.items() if v is not None})
+        opt = _new_options(merged)
         check(load().rr_thread_options(ctypes.byref(opt)),
               "rr_thread_options")
+        _tls.standing = merged
         return self
 
     def __exit__(self, *exc):
-        check(load().rr_thread_options(None), "rr_thread_options")
+        _tls.standing = self.prev
+        if self.prev:
+            opt = _new_options(self.prev)
+            check(load().rr_thread_options(ctypes.byref(opt)),
+                  "rr_thread_options")
+        else:
+            check(load().rr_thread_options(None), "rr_thread_options")
         return False
 
 

@@ -728,7 +728,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
     constexpr bool coupled = !std::is_same<UH, void>::value;
     int n1cap = 0, n2cap = 0;
     if constexpr (coupled) {
-        if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
+        if (!gr4j_plan_selects<UH, false>(plan, force_lds, n1cap, n2cap)) return;
     }
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;

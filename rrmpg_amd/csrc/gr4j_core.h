@@ -481,7 +481,9 @@ static __host__ __device__ __forceinline__ int gr4j_plan_tier(int max_n1,
 
 // true if this kernel instantiation (UH) is the one the plan selects; the
 // indexed tiers also get their capacities (the launch's longest hydrographs)
-template <class UH>
+// REF_BEHIND: the launch enqueues a one-lane reference kernel behind this one
+// (false: the kernels for more than RR_CEMANEIGE_MAX_LAYERS layers)
+template <class UH, bool REF_BEHIND = true>
 __device__ __forceinline__ bool gr4j_plan_selects(const int *__restrict__ plan,
                                                   int force_lds, int &n1cap,
                                                   int &n2cap)
@@ -490,7 +492,15 @@ __device__ __forceinline__ bool gr4j_plan_selects(const int *__restrict__ plan,
     const int mem_cap = plan[2];
     n1cap = mx;
     n2cap = 2 * mx + 1;
-    return gr4j_plan_tier(mx, bad, force_lds, mem_cap) == UH::TIER;
+    const int tier = gr4j_plan_tier(mx, bad, force_lds, mem_cap);
+    // plan[3] != 0: a forcing value that is not civil (gr4j_reference.h) --
+    // the one-lane reference kernel behind the fast ones then computes EVERY
+    // set with x4 <= RR_GR4J_MAX_X4 anyway, so the fast kernels of those
+    // tiers do not run at all (they used to, and their output was then
+    // overwritten).  Only a launch of the HBM-scratch tier keeps its fast
+    // kernel: the reference kernel's private hydrographs end at x4 = 20.
+    if (REF_BEHIND && plan[3] != 0 && tier != GR4J_TIER_MEM) return false;
+    return tier == UH::TIER;
 }
 
 // ... refined per WAVE (round 5): every tier's kernel runs over the whole grid
@@ -517,6 +527,7 @@ __device__ __forceinline__ bool gr4j_wave_selects(const int *__restrict__ plan,
     n1cap = mx;
     n2cap = 2 * mx + 1;
     const int launch = gr4j_plan_tier(mx, bad, force_lds, mem_cap);
+    if (plan[3] != 0 && launch != GR4J_TIER_MEM) return false;  // (see above)
     if (launch < 0 || launch == GR4J_TIER_MEM || force_lds || launch == 3)
         return launch == UH::TIER;
     const int n1 = gr4j_num_uh1(x4);

@@ -682,7 +682,14 @@ hbvedu_kernel(
             // K_0 as max(0, s1 K_0 - L K_0), the product L K_0 a loop
             // invariant; a lane's form does not depend on the loop copy its
             // wave runs: in the general copy a lane with such K_0 and L takes
-            // the same value, any other lane the reference's sequence)
+            // the same value, any other lane the reference's sequence.
+            // The folded form's error is ABSOLUTE: L K_0 is rounded once, so
+            // the spill is within ulp(L K_0) of the reference's -- close to
+            // the threshold, s1 ~ L, that is not a relative bound, and a
+            // spill of that size can come out as 0 or the other way round
+            // (the reference's (s1 - L) K_0 is exact there).  1e-16 L K_0 mm
+            // a day against a discharge compared at 1e-10; pinned by
+            // tests/test_gpu_parity.py test_hbvedu_overflow_term_alone.)
             if constexpr (decltype(tame)::value) {
                 over = rr_hw_max(__builtin_fma(s1, K_0, neg_LK0), 0.0);
             } else {

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
-    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
+    if (!gr4j_plan_selects<UH, false>(plan, force_lds, n1cap, n2cap)) return;
     const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     // tail lanes of the last wave share (and rewrite identically) set N-1's

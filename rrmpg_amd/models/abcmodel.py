@@ -120,6 +120,16 @@ class ABCModel(BaseModel):
         return qsim, sse
 
 
+    def _resident(self, prec, initial_state=0, device=None):
+        """simulate()'s forcing as an HBM-resident ensemble
+        (rrmpg_amd.device.ABCEnsemble) after simulate()'s own checks."""
+        from .. import device as rrdev
+        prec, initial_state = _validate(prec, initial_state)
+        return rrdev.ABCEnsemble(
+            prec, initial_state,
+            **({} if device is None else {"device": device}))
+
+
 def _validate(prec, initial_state):
     prec = validate_array_input(prec, np.float64, 'precipitation')
     if check_for_negatives(prec):

@@ -119,6 +119,21 @@ class Cemaneige(BaseModel):
         return out[0], sse
 
 
+    def _resident(self, prec, mean_temp, min_temp, max_temp,
+                  met_station_height, snow_pack_init=0, thermal_state_init=0,
+                  altitudes=[], device=None):
+        """simulate()'s forcing as an HBM-resident ensemble
+        (rrmpg_amd.device.CemaneigeEnsemble) after simulate()'s own checks
+        and layer preprocessing."""
+        from .. import device as rrdev
+        layers, inits = prepare_snow_inputs(
+            prec, mean_temp, min_temp, max_temp, met_station_height,
+            snow_pack_init, thermal_state_init, altitudes)
+        return rrdev.CemaneigeEnsemble(
+            layers[0], layers[1], layers[2], *inits,
+            **({} if device is None else {"device": device}))
+
+
 def prepare_snow_inputs(prec, mean_temp, min_temp, max_temp,
                         met_station_height, snow_pack_init,
                         thermal_state_init, altitudes, etp=None):

@@ -118,6 +118,21 @@ class CemaneigeGR4J(BaseModel):
         return out[0], sse
 
 
+    def _resident(self, prec, mean_temp, min_temp, max_temp, etp,
+                  met_station_height, snow_pack_init=0, thermal_state_init=0,
+                  s_init=0, r_init=0, altitudes=[], device=None):
+        """simulate()'s forcing as an HBM-resident ensemble
+        (rrmpg_amd.device.CemaneigeGR4JEnsemble) after simulate()'s own
+        checks and layer preprocessing."""
+        from .. import device as rrdev
+        layers, inits = _prepare(prec, mean_temp, min_temp, max_temp, etp,
+                                 met_station_height, snow_pack_init,
+                                 thermal_state_init, s_init, r_init, altitudes)
+        return rrdev.CemaneigeGR4JEnsemble(
+            layers[0], layers[1], layers[2], layers[3], *inits,
+            **({} if device is None else {"device": device}))
+
+
 def _prepare(prec, mean_temp, min_temp, max_temp, etp, met_station_height,
              snow_pack_init, thermal_state_init, s_init, r_init, altitudes):
     layers, snow_inits = prepare_snow_inputs(

@@ -116,6 +116,17 @@ class GR4J(BaseModel):
         return out[0], sse
 
 
+    def _resident(self, prec, etp, s_init=0., r_init=0., device=None):
+        """simulate()'s forcing as an HBM-resident ensemble
+        (rrmpg_amd.device.GR4JEnsemble) after simulate()'s own checks."""
+        from .. import device as rrdev
+        prec, etp = _validate_forcing(prec, etp)
+        s_init, r_init = _validate_inits(s_init, r_init)
+        return rrdev.GR4JEnsemble(
+            prec, etp, s_init, r_init,
+            **({} if device is None else {"device": device}))
+
+
 def _validate_forcing(prec, etp):
     prec = validate_array_input(prec, np.float64, 'precipitation')
     etp = validate_array_input(etp, np.float64, 'pot. evapotranspiration')

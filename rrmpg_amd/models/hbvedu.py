@@ -115,6 +115,20 @@ class HBVEdu(BaseModel):
         return out[0], sse
 
 
+    def _resident(self, temp, prec, month, PE_m, T_m, snow_init=0,
+                  soil_init=0, s1_init=0, s2_init=0, device=None):
+        """The forcing of a simulate() call as an HBM-resident ensemble
+        (rrmpg_amd.device.HBVEduEnsemble), after simulate()'s own input
+        checks: what ``monte_carlo(..., sampler='device')`` sweeps."""
+        from .. import device as rrdev
+        temp, prec, month0, PE_m, T_m = _validate(temp, prec, month, PE_m,
+                                                   T_m)
+        return rrdev.HBVEduEnsemble(
+            temp, prec, month0 + 1, PE_m, T_m, float(snow_init),
+            float(soil_init), float(s1_init), float(s2_init),
+            **({} if device is None else {"device": device}))
+
+
 def _validate(temp, prec, month, PE_m, T_m):
     """Input checks of simulate()/fit() (reference: hbvedu.py:133-164)."""
     temp = validate_array_input(temp, np.float64, 'temperature')

@@ -18,8 +18,76 @@ from .. import _lib
 from ..utils.metrics import mse_from_sse, nse_from_sse
 
 
+class DeviceParams:
+    """The parameter sets of a ``monte_carlo(..., sampler='device')`` sweep:
+    they were drawn in HBM and stay there until somebody looks --
+    ``np.asarray(p)``, ``p[i]``, ``p['x1']``, ``len(p)`` and ``p.dtype`` work
+    as on the structured array ``get_random_params`` returns, the first
+    access downloading the block once; ``p.tensor`` is the [num, k] device
+    tensor itself."""
+
+    def __init__(self, model, tensor):
+        self._model, self.tensor, self._host = model, tensor, None
+
+    def numpy(self):
+        if self._host is None:
+            flat = self.tensor.cpu().numpy()
+            rec = np.zeros(flat.shape[0], dtype=self._model._dtype)
+            for j, name in enumerate(self._model._param_list):
+                rec[name] = flat[:, j]
+            self._host = rec
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, key):
+        return self.numpy()[key]
+
+    def __len__(self):
+        return int(self.tensor.shape[0])
+
+    @property
+    def dtype(self):
+        return self._model._dtype
+
+    @property
+    def shape(self):
+        return (len(self),)
+
+
+def _monte_carlo_resident(model, num, qobs, score, seed, kwargs):
+    """sampler='device': sets drawn in HBM (numpy's Philox stream under
+    `seed`, rrmpg_amd.device.sample_params), swept against the resident
+    forcing, only the scores come back."""
+    import torch
+    from .. import device as rrdev
+    if not hasattr(model, "_resident"):
+        raise ValueError("sampler='device' is not available for %s"
+                         % type(model).__name__)
+    ens = model._resident(**kwargs)
+    if seed is None:
+        # no key given: one draw from numpy's global generator, so that
+        # np.random.seed(s) in front of the call still fixes the sweep
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    params = rrdev.sample_params(model, num, int(seed), device=ens.device)
+    q = torch.as_tensor(qobs, dtype=torch.float64, device=ens.device)
+    if q.numel() != ens.num_timesteps:
+        raise ValueError("Arrays must have the same size.")
+    sse = ens.run(params, None, qobs=q)
+    if hasattr(ens, "check"):
+        ens.check()
+    sse = sse.cpu().numpy()
+    result = {'params': DeviceParams(model, params),
+              'mse': mse_from_sse(sse, len(qobs))}
+    if score == "nse":
+        result['nse'] = nse_from_sse(sse, qobs)
+    return result
+
+
 def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
-                score="mse", **kwargs):
+                score="mse", sampler="numpy", seed=None, **kwargs):
     """Perform Monte-Carlo-Simulation.
 
     Args:
@@ -39,6 +107,17 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
         score: (optional, extension) 'mse' (default) or 'nse': with 'nse'
             the result also carries the Nash-Sutcliffe efficiency of every
             set (calc_nse's definition).
+        sampler: (optional, extension) 'numpy' (default): the sets come from
+            ``model.get_random_params`` -- numpy's global generator, the
+            reference's contract: ``np.random.seed(s)`` in front of the call
+            gives the reference's sets.  'device': the sets are drawn in the
+            GPU's memory (numpy's Philox stream under `seed`; without one a
+            key is taken from numpy's global generator) and never leave it
+            unless looked at -- 'params' is then a DeviceParams; needs qobs
+            and return_qsim=False.  The mode for million-set sweeps: at
+            100,000 HBV-Edu sets drawing and uploading the sets on the host
+            is three quarters of the call.
+        seed: (optional) the key of sampler='device'.
         **kwargs: Keyword arguments matching the inputs the model needs to
             perform a simulation; see help(model.simulate).
 
@@ -62,6 +141,16 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
     elif not return_qsim:
         raise ValueError("return_qsim=False needs qobs to score the sets.")
 
+    if score not in ("mse", "nse"):
+        raise ValueError("score must be 'mse' or 'nse'")
+    shards = _lib.host_shards_of(gpus)   # (checked before anything is drawn)
+    if sampler not in ("numpy", "device"):
+        raise ValueError("sampler must be 'numpy' or 'device'")
+    if sampler == "device":
+        if qobs is None or return_qsim or gpus is not None:
+            raise ValueError("sampler='device' scores resident sets: it "
+                             "needs qobs, return_qsim=False and gpus=None")
+        return _monte_carlo_resident(model, num, qobs, score, seed, kwargs)
     params = model.get_random_params(num=num)
     sweep = model._sweep
     accepted = inspect.signature(sweep).parameters
@@ -70,12 +159,10 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
         # a simulate() keyword the fused sweep does not take (return_storage
         # ...): go through simulate itself, as the reference does
         sweep = lambda *a, **kw: BaseModel._sweep(model, *a, **kw)  # noqa
-    if score not in ("mse", "nse"):
-        raise ValueError("score must be 'mse' or 'nse'")
     # per-call option of the host-pointer entry point (rr_<model>_simulate_opt,
     # include/rrhip.h): nothing process-wide is touched, so concurrent sweeps
     # from several threads keep their own shard counts
-    with _lib.call_options(host_shards=_lib.host_shards_of(gpus)):
+    with _lib.call_options(host_shards=shards):
         qsim, sse = sweep(params, qobs, bool(return_qsim), **kwargs)
 
     result = {'params': params}

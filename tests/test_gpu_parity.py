@@ -128,6 +128,35 @@ def test_hbvedu_golden_and_oracle(models, oracle, hbv_variant):
     assert np.array_equal(out[1], ref[1])
 
 
+def test_hbvedu_overflow_term_alone(models, oracle, hbv_variant):
+    """K_1 = K_2 = 0: the discharge is the near-surface store's overflow
+    term alone, max(0, s1 - L) K_0 (hbvedu_model.py:114-115, 125-127), which
+    the kernels form as max(0, fma(s1, K_0, -(L K_0))) for a civil set.
+    Close to the threshold that is an ABSOLUTE bound -- a rounding of L K_0 --
+    not a relative one: the spill is compared at 4 ulp(L K_0) + 1e-10 of
+    itself, on sets whose store hovers around L (K_p small, L inside the
+    store's range), every loop variant."""
+    g = golden("syn_hbvedu")
+    rng = np.random.default_rng(29)
+    lo = np.array([-1, 3, 100, 1, .01, 90, .05, 0, 0, .002, 0.5])
+    hi = np.array([1, 7, 200, 7, .07, 180, .9, 0, 0, .02, 30.])
+    t, n = 1200, 257
+    flat = lo + (hi - lo) * rng.random((n, 11))
+    ref = oracle.simulate_hbvedu(g["temp"][:t], g["prec"][:t],
+                                 g["month"][:t] - 1, g["PE_m"], g["T_m"],
+                                 (1., 90., 2., 8.), flat, return_storage=True)
+    out = models.HBVEdu().simulate(
+        g["temp"][:t], g["prec"][:t], g["month"][:t], g["PE_m"], g["T_m"],
+        1., 90., 2., 8., return_storage=True,
+        params=_records(models.HBVEdu, flat))
+    q, q_ref = out[0], ref[0]
+    assert (q_ref > 0).mean() > 0.05 and (q_ref == 0).mean() > 0.05
+    ulp_lk0 = np.spacing(flat[:, 10] * flat[:, 6])[None, :]
+    assert np.all(np.abs(q - q_ref) <= 4 * ulp_lk0 + 1e-10 * np.abs(q_ref))
+    for a, b in zip(out[1:], ref[1:]):
+        assert rel_err(a, b) < RTOL
+
+
 def test_hbvedu_ragged_sizes_vs_oracle(models, oracle, hbv_variant):
     g = golden("syn_hbvedu")
     rng = np.random.default_rng(11)

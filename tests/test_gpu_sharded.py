@@ -136,6 +136,61 @@ def test_monte_carlo_over_eight_shards_with_qsim(env):
     assert np.array_equal(one["params"], eight["params"])
 
 
+def test_monte_carlo_device_sampler(env):
+    """monte_carlo(sampler='device'): the sets are drawn in HBM (numpy's
+    Philox stream under `seed`) and scored against the resident forcing; the
+    scores are those of the same population run through the default path,
+    'params' downloads on first access, and without a seed the key comes
+    from numpy's global generator (np.random.seed still fixes the sweep)."""
+    from rrmpg_amd.tools import monte_carlo
+    from rrmpg_amd.tools.monte_carlo import DeviceParams
+    m, f, dev = env["models"], env["f"], env["device"]
+    n = 3001
+    for cls, kw in (
+            (m.HBVEdu, dict(temp=f["temp"], prec=f["prec"], month=f["month"],
+                            PE_m=f["PE_m"], T_m=f["T_m"],
+                            **env["syn"].HBV_INITS)),
+            (m.GR4J, dict(prec=f["prec"], etp=f["etp"], s_init=0.6,
+                          r_init=0.7)),
+            (m.ABCModel, dict(prec=f["prec"], initial_state=2.0)),
+            (m.CemaneigeGR4J, dict(
+                prec=f["prec"], mean_temp=f["temp"], min_temp=f["tmin"],
+                max_temp=f["tmax"], etp=f["etp"],
+                met_station_height=env["syn"].STATION_HEIGHT,
+                altitudes=list(env["syn"].ALTITUDES), s_init=0.6,
+                r_init=0.7))):
+        model = cls()
+        pop = dev.host_population(model, n, 77)
+        rec = np.zeros(n, dtype=model._dtype)
+        for j, name in enumerate(model._param_list):
+            rec[name] = pop[:, j]
+        base = model.simulate(params=rec[:8], **kw)
+        qobs = np.asarray(base)[:, 3] * 0.95 + 0.02
+        qs, sse = model._sweep(rec, qobs, False, **kw)
+        want = sse / len(qobs)
+        got = monte_carlo(model, n, qobs=qobs, return_qsim=False,
+                          sampler="device", seed=77, score="nse", **kw)
+        assert isinstance(got["params"], DeviceParams)
+        assert np.array_equal(got["mse"], want)
+        assert len(got["params"]) == n and got["params"].dtype == model._dtype
+        assert np.array_equal(np.asarray(got["params"]), rec)
+        assert np.array_equal(got["params"]["%s" % model._param_list[0]],
+                              rec[model._param_list[0]])
+        assert got["nse"].shape == (n,)
+    np.random.seed(3)
+    a = monte_carlo(model, 500, qobs=qobs, return_qsim=False,
+                    sampler="device", **kw)
+    np.random.seed(3)
+    b = monte_carlo(model, 500, qobs=qobs, return_qsim=False,
+                    sampler="device", **kw)
+    assert np.array_equal(a["mse"], b["mse"])
+    for bad in (dict(return_qsim=True), dict(gpus=2, return_qsim=False)):
+        with pytest.raises(ValueError):
+            monte_carlo(model, 10, qobs=qobs, sampler="device", **bad, **kw)
+    with pytest.raises(ValueError):
+        monte_carlo(model, 10, qobs=qobs, sampler="gpu", **kw)
+
+
 def test_concurrent_sweeps_keep_their_own_options(env):
     """The shard count travels with the CALL (rr_<model>_simulate_opt's
     rr_call_options), not through a process-wide switch: two threads running

@@ -453,6 +453,22 @@ def test_debug_options_and_cache_release_need_no_gpu():
         assert _lib.opts_ptr()._obj.value[opt["max_block_cols"]] \
             == _lib.RR_OPT_UNSET
     assert _lib.opts_ptr() is None
+    # None in a nested block means "not set here": the outer value stays
+    with _lib.call_options(host_shards=3):
+        with _lib.call_options(host_shards=None, max_block_cols=8):
+            cur = _lib.opts_ptr()._obj
+            assert cur.value[opt["host_shards"]] == 3
+            assert cur.value[opt["max_block_cols"]] == 8
+    # standing options of the thread nest the same way, and the enclosing
+    # block's options stand again behind an inner one
+    with _lib.thread_options(hbv_variant=0):
+        assert _lib._tls.standing == {"hbv_variant": 0}
+        with _lib.thread_options(time_tiles=4, hbv_variant=None):
+            assert _lib._tls.standing == {"hbv_variant": 0, "time_tiles": 4}
+        assert _lib._tls.standing == {"hbv_variant": 0}
+    assert _lib._tls.standing is None
+    with pytest.raises(KeyError):
+        _lib.thread_options(no_such_option=1)
     assert lib.rr_debug_get_option(opt["host_shards"]) == 0
     with pytest.raises(KeyError):
         _lib.call_options(no_such_option=1)
