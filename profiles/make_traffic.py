@@ -55,8 +55,16 @@ def main():
         if hbm:
             out[key] = hbm["traffic_bytes_per_launch"]
         if "SQ_INSTS_VALU" in sq:
-            out[key + ":valu_instr_per_unit"] = round(
-                sq["SQ_INSTS_VALU"] / (jobs * T), 2)
+            valu = sq["SQ_INSTS_VALU"]
+            # a sweep whose waves run in several tier kernels side by side
+            # (the hysteresis couplings): the other tiers' summaries
+            for extra in ("_t3", "_t5"):
+                pe = os.path.join(HERE, "%s%s%s_summary.json"
+                                  % (tag, suffix, extra))
+                if suffix and os.path.exists(pe):
+                    valu += json.load(open(pe)).get("sq", {}).get(
+                        "SQ_INSTS_VALU", 0)
+            out[key + ":valu_instr_per_unit"] = round(valu / (jobs * T), 2)
     with open(os.path.join(HERE, "traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))

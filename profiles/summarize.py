@@ -55,7 +55,10 @@ def main():
     tag, match = sys.argv[1], sys.argv[2]
     algo_bytes = float(sys.argv[3]) if len(sys.argv) > 3 else None
     MIN_GRID = float(sys.argv[4]) if len(sys.argv) > 4 else 0
-    root = os.path.join("gpurun_out", "prof_" + tag)
+    # argv[5]: the collection to read if it is not the tag's own (several
+    # kernels of one run, each with a summary of its own)
+    root = os.path.join("gpurun_out", "prof_" + (sys.argv[5] if len(sys.argv)
+                                                  > 5 else tag))
     out = {"tag": tag, "kernel_match": match}
     stats = glob.glob(os.path.join(root, "trace", "*", "*_kernel_stats.csv"))
     rows = []
