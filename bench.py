@@ -459,7 +459,10 @@ def parity_spot(args, f, params_host, qsim, sse, qobs, n_cols=16):
 
 
 MODEL_CLASSES = {"hbvedu": "HBVEdu", "abc": "ABCModel", "gr4j": "GR4J",
-                 "cemaneigegr4j": "CemaneigeGR4J"}
+                 "cemaneigegr4j": "CemaneigeGR4J",
+                 "cemaneigehystgr4j": "CemaneigeHystGR4J",
+                 "cemaneigegr4jice": "CemaneigeGR4JIce",
+                 "cemaneigehystgr4jice": "CemaneigeHystGR4JIce"}
 
 
 def parity_spot_host_population(args, ens, f, n=4096, n_cols=16):
