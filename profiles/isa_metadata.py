@@ -62,7 +62,10 @@ def loop_lane_moves(body):
         latch = None
         for k in members:
             for l in blocks[k]["lines"]:
-                if re.search(r"s_c?branch\w*\s+\.%s\b" % re.escape(hdr), l):
+                # (labels are ".LBBx_y", `hdr` is "BBx_y"; until round 5 the
+                # pattern lacked the L, no latch was ever found and every block
+                # of a loop counted as its straight path)
+                if re.search(r"s_c?branch\w*\s+\.L%s\b" % re.escape(hdr), l):
                     latch = k if latch is None else max(latch, k)
         for k in members:
             n = sum(1 for l in blocks[k]["lines"]
