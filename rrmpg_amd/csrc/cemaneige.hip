@@ -259,11 +259,27 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
 // Small configurations (<= 5 layers, unit hydrographs in 3+7 registers or in
 // LDS) are held at 128 registers = 4 waves per SIMD: a handful of spills cost
 // less than the lost wave (137 -> 130 ms at L = 5).
+// (measurement switches: the many-waves kernel held to COUPLED_BIG_MINWAVES
+// waves per SIMD, and with its polynomial constants in VGPR pairs instead of
+// fetched at the point of use.  The kernel executes 38 lane moves a day --
+// scalar values parked in VGPR lanes -- at four waves per SIMD; round 5
+// measured what giving it registers instead costs: 1M sets, scores, 72.6 ms
+// as shipped, 78.1 at three waves per SIMD, 74.7 with the constants in VGPRs
+// as well, 73.1 for the optimistic many-waves form, 77.9 / 82.7 for the
+// small-sweep forms; profiles/r05_fused_forms_ab.txt)
+#ifndef COUPLED_BIG_MINWAVES
+#define COUPLED_BIG_MINWAVES 4
+#endif
+#ifndef COUPLED_BIG_VCONST
+#define COUPLED_BIG_VCONST 0
+#endif
 template <int L, class UH, bool SMALL = false>
 constexpr int coupled_min_waves()
 {
     return (!SMALL && L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
-                                 uh_is_indexed<UH>)) ? 4 : 2;
+                                 uh_is_indexed<UH>))
+               ? (std::is_same<UH, UhRegs<3>>::value ? COUPLED_BIG_MINWAVES : 4)
+               : 2;
 }
 
 // SMALL variant of the fused kernel, for sweeps of at most two waves per SIMD
@@ -353,7 +369,9 @@ cemaneigegr4j_kernel(
     // shorter of SGPRs still, lose with it and keep the load at the top).
     CemaGtRegs<L> gt_regs;
     if constexpr (SMALL) cema_gt_to_regs<L>(gt_tab, gt_regs);
-    constexpr int CONSTS = SMALL ? GR4J_CONSTS_VGPR : GR4J_CONSTS_JIT;
+    constexpr int CONSTS = (SMALL || (COUPLED_BIG_VCONST && !TILED &&
+                                      std::is_same<UH, UhRegs<3>>::value))
+                               ? GR4J_CONSTS_VGPR : GR4J_CONSTS_JIT;
     const cema_rec_ptr_t drec = (cema_rec_ptr_t)days;
     int64_t t_begin = 0, t_end = T;
     double *const hand = TILED ? tiles.state + ((int64_t)job * RR_BLOCK +
