@@ -345,3 +345,53 @@ def test_host_family_context_and_staged_gather(env, oracle):
     assert np.array_equal(q3, q4)
     q5 = m.simulate(temp, prec.copy(), params=p, **kw)        # ring again
     assert np.array_equal(q5[:, :64], q3)
+
+
+@pytest.mark.parametrize("which", ["hbvedu", "gr4j", "hystgr4j"])
+def test_dev_sweeps_capture_into_a_hip_graph(env, which):
+    """Nothing in a *_simulate_dev call allocates, copies back or waits: a
+    whole sweep -- pre-pass, plan, the tier kernels (for a sorted score-only
+    sweep of the hysteresis coupling: on side streams forked from and joined
+    to the caller's with events), the reference kernel -- captures into ONE
+    HIP graph, and its replays give the bits of the plain call."""
+    torch, dev, models, syn, f = env
+    t = 400
+    if which == "hbvedu":
+        ens = dev.HBVEduEnsemble(f["temp"][:t], f["prec"][:t], f["month"][:t],
+                                 f["PE_m"], f["T_m"], **syn.HBV_INITS)
+        cls, n, with_q = models.HBVEdu, 70_001, True
+    elif which == "gr4j":
+        ens = dev.GR4JEnsemble(f["prec"][:t], f["etp"][:t], **syn.GR4J_INITS)
+        cls, n, with_q = models.GR4J, 30_011, True
+    else:
+        from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+        layers, _ = prepare_snow_inputs(f["prec"][:t], f["temp"][:t],
+                                        f["tmin"][:t], f["tmax"][:t],
+                                        syn.STATION_HEIGHT, 0, 0,
+                                        list(syn.ALTITUDES), etp=f["etp"][:t])
+        ens = dev.SnowGR4JEnsemble(True, False, layers[0], layers[1],
+                                   layers[2], layers[3], s_init=.6, r_init=.7)
+        cls, n, with_q = models.CemaneigeHystGR4J, 4 * 1024 * 64 + 5, False
+    side = torch.cuda.Stream()
+    params = dev.sample_params(cls(), n, 5)
+    qobs = torch.rand(t, dtype=torch.float64, device="cuda")
+    q_plain = ens.new_output(n) if with_q else None
+    q_graph = ens.new_output(n) if with_q else None
+    sse_graph = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        # plain call first: workspace, side streams, the comparison
+        sse_plain = ens.run(params, q_plain, qobs=qobs).clone()
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            ens.run(params, q_graph, qobs=qobs, sse=sse_graph)
+        side.synchronize()
+        assert not bool(sse_graph.any())       # captured, not run
+        for _ in range(3):
+            sse_graph.zero_()
+            g.replay()
+            side.synchronize()
+            assert torch.equal(sse_graph, sse_plain)
+            if with_q:
+                assert torch.equal(q_graph, q_plain)
