@@ -79,7 +79,9 @@ extern "C" {
 #define RR_OK          0
 #define RR_E_NULL     -1  /* a required pointer is NULL                     */
 #define RR_E_SIZE     -2  /* negative or inconsistent size / ld < N / more
-                           * than 2e9 timesteps (days are counted in 32 bits) */
+                           * than 2e9 timesteps (days are counted in 32 bits)
+                           * / HBV-Edu: ld beyond 2^27 - 1 columns (a trip's
+                           * rows are addressed through 32-bit offsets)       */
 #define RR_E_HIP      -3  /* a HIP runtime call failed                      */
 #define RR_E_PARAM    -4  /* parameter value the kernels cannot represent   */
 #define RR_E_NODEVICE -5  /* no usable gfx950 device                        */
