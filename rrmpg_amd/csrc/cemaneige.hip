@@ -593,14 +593,10 @@ cemaneigegr4j_opt_kernel(
             for (int k = 0; k < D; ++k) day[k] = nx[k];
         };
         const bool wet = liquid >= etp_t;                   // gr4j_model.py:89
-#if COUPLED_UNIFORM_WET
         // liquid - etp on a wet day, etp - liquid = -(liquid - etp) on a dry
-        // one (:90, :102): the magnitude of one difference (x - x = +0; the
-        // sets of this kernel are civil, no NaN)
+        // one (:90, :102): the magnitude of one difference (gr4j_core.h
+        // gr4j_step)
         const double net = fabs(liquid - etp_t);
-#else
-        const double net = wet ? liquid - etp_t : etp_t - liquid;
-#endif
         const lanemask_t net_m = gr4j_num_lanes(net);
         OptimisticVotes votes;
         double s = in.s, r = in.r;

@@ -861,12 +861,15 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
         keep_excess = __hiloint2double(0x3ff00000 & keep, 0);
         sn = __builtin_fma(frac, sgn, s);
         excess = net - frac;
-    } else if (wet) {
-        sn = s + frac;
-        excess = net - frac;
     } else {
-        sn = s - frac;
-        excess = 0.0;
+        // (per lane: the same two factors, their high words ONE v_cndmask_b32
+        // each -- where s + frac / s - frac and net - frac / 0 were formed
+        // both and selected, two 64-bit selects of two instructions each)
+        const double sgn = __hiloint2double(
+            wet ? 0x3ff00000 : (int)0xbff00000, 0);
+        keep_excess = __hiloint2double(wet ? 0x3ff00000 : 0, 0);
+        sn = __builtin_fma(frac, sgn, s);
+        excess = net - frac;
     }
     // percolation (:117); **4 is two squarings
     const double v = gr4j_div(4.0 / 9.0 * sn, P.inv_x1, P.x1_m, votes);
@@ -910,10 +913,7 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     mid();
     s = sn - perc;                                              // :120
 #endif
-    if constexpr (uniform_wet)
-        return __builtin_fma(excess, keep_excess, perc);        // p_r, :123
-    else
-        return perc + excess;                                   // p_r, :123
+    return __builtin_fma(excess, keep_excess, perc);            // p_r, :123
 }
 
 // `in` -> `out`: the hydrograph slots' two generations (UhRegs::Slots), or
@@ -999,7 +999,11 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
                                             double etp, MID &&mid = MID())
 {
     const bool wet = prec >= etp;                               // :89
-    const double net = wet ? prec - etp : etp - prec;           // :90, :102
+    // prec - etp on a wet day, etp - prec on a dry one (:90, :102): the two
+    // differences are each other's negatives exactly, so both are the
+    // magnitude of one (a NaN stays a NaN) -- one subtraction where the
+    // per-lane selection of two cost four instructions more
+    const double net = __builtin_fabs(prec - etp);
     const lanemask_t net_m = gr4j_num_lanes(net);
 #if GR4J_STEP_UNIFORM_WET
     // (the coupled kernels: on most days every lane of a wave is on the same
