@@ -395,3 +395,43 @@ def test_dev_sweeps_capture_into_a_hip_graph(env, which):
             assert torch.equal(sse_graph, sse_plain)
             if with_q:
                 assert torch.equal(q_graph, q_plain)
+
+
+def test_record_prefetch_changes_nothing_but_the_time(env):
+    """RR_OPT_WARM_RECORDS (the waves read a share of the day records into
+    their XCD's L2 when they start, common.h rr_warm_l2): a prefetch only --
+    the same bits with it pinned on, pinned off and chosen by sweep size, for
+    HBV-Edu (every loop variant's launch path), the fused CemaneigeGR4J
+    kernels and GR4J (where it only runs on request)."""
+    torch, dev, models, syn, f = env
+    from rrmpg_amd import _lib
+    t = 500
+    hbv = dev.HBVEduEnsemble(f["temp"][:t], f["prec"][:t], f["month"][:t],
+                             f["PE_m"], f["T_m"], **syn.HBV_INITS)
+    gr = dev.GR4JEnsemble(f["prec"][:t], f["etp"][:t], **syn.GR4J_INITS)
+    from rrmpg_amd.models.cemaneige import prepare_snow_inputs
+    layers, _ = prepare_snow_inputs(f["prec"][:t], f["temp"][:t],
+                                    f["tmin"][:t], f["tmax"][:t],
+                                    syn.STATION_HEIGHT, 0, 0,
+                                    list(syn.ALTITUDES), etp=f["etp"][:t])
+    fused = dev.CemaneigeGR4JEnsemble(layers[0], layers[1], layers[2],
+                                      layers[3], 0., 0., .6, .7)
+    for ens, cls, n in ((hbv, models.HBVEdu, 1000), (hbv, models.HBVEdu, 70_001),
+                        (gr, models.GR4J, 9_000),
+                        (fused, models.CemaneigeGR4J, 5_003),
+                        (fused, models.CemaneigeGR4J, 140_000)):
+        params = dev.sample_params(cls(), n, 17)
+        qobs = torch.rand(t, dtype=torch.float64, device="cuda")
+        got = []
+        for pin in (-1, 0, 1):
+            q = ens.new_output(n)
+            with _lib.debug_option("warm_records", pin):
+                sse = ens.run(params, q, qobs=qobs).clone()
+                sse_only = ens.run(params, None, qobs=qobs).clone()
+            torch.cuda.synchronize()
+            got.append((q, sse, sse_only))
+        for q, sse, sse_only in got[1:]:
+            assert torch.equal(q, got[0][0]), (cls.__name__, n)
+            assert torch.equal(sse, got[0][1])
+            assert torch.equal(sse_only, got[0][2])
+        assert torch.equal(got[0][1], got[0][2])
