@@ -12,7 +12,7 @@ $S r05           'true, 1, false>('                                87656000000 2
 $S r05_hbv125k   'true, 0, false>('                                10957000000 125056 > /dev/null
 $S r05_hbv100k   'true, 0, false>('                                 8765600000 100032 > /dev/null
 $S r05_hbv65k    'true, 0, false>('                                 5744623616 65536 > /dev/null
-$S r05_hbv400ks  'true, 1, false>('                               175312000000 262144 > /dev/null
+$S r05_hbv400ks  'true, 1, false>('                               175312000000 190000 > /dev/null
 $S r05_hbvcat    'true, 2, false>('                                          0 262144 > /dev/null
 $S r05_gr4j      'gr4j_opt_kernel<UhRegs<3>, true, false, true'    87656000000 4000000 > /dev/null
 $S r05_gr4j125k  'gr4j_opt_kernel<UhRegs<3>, false, false, true'             0 125056 > /dev/null
