@@ -153,7 +153,10 @@ int rr_release_cached_memory(void);
                                   * the small-sweep kernel with an optimistic
                                   * GR4J half (votes noted, the half redone if
                                   * one failed); 4 the many-waves kernel with
-                                  * an optimistic GR4J half                   */
+                                  * an optimistic GR4J half; 5 (score-only
+                                  * sweeps) the two-wave pipeline: snow routine
+                                  * and GR4J day in two waves of a workgroup,
+                                  * an LDS ring between them                  */
 #define RR_OPT_GR4J_VARIANT    6 /* GR4J kernel: 0 the library's choice
                                   * (default: the optimistic kernel where it
                                   * exists); 1 gr4j_kernel, one wave per 64

@@ -680,6 +680,155 @@ cemaneigegr4j_opt_kernel(
     if (we && active) sse[i] = acc;
 }
 
+// ---- the fused sweep as a pipeline of two waves (round 5) ---------------------
+// What makes the fused kernels hard on hipcc is that ONE wave carries both
+// halves of the day: the snow routine's record (3 L + 2 doubles in SGPRs, its
+// successor prefetched in the middle of the GR4J half) AND the GR4J half's
+// polynomial constants -- more scalar values than the 102 SGPRs hold, so the
+// constants are fetched from constant memory at their point of use (a scalar
+// load and a wait each, GR4J_CONSTS_JIT) and what still overflows is parked
+// in VGPR lanes (38 v_readlane / v_writelane a day in the many-waves kernel:
+// vector issue slots).  The day is feed-forward at one point -- the snow
+// routine's layer-mean outflow is the GR4J half's precipitation, nothing
+// flows back -- so a score-only sweep (no per-day output to keep the halves
+// together for) is cut there:
+//   * workgroups of TWO waves over the same 64 sets: wave 0 runs the snow
+//     routine (record in SGPRs, 2 L states), wave 1 the optimistic GR4J day
+//     (its constants at home in SGPRs, two generations of stores and
+//     hydrograph slots, the day's etp / qobs as one 16-byte scalar load);
+//   * the outflow travels through an LDS ring [2][K][64] (K = 8 days per
+//     half, 8 KiB a workgroup): the snow wave fills half b & 1 with block b's
+//     days and meets the GR4J wave at ONE barrier per K days; the GR4J wave
+//     works on block b while the snow wave is a block ahead.  (Half h is
+//     written again in block b + 2, behind the barrier that ended the GR4J
+//     wave's reading of block b.)
+// Twice the waves for the same arithmetic: at 125k sets a SIMD holds four
+// lighter waves instead of two heavy ones, and neither wave waits for the
+// other's scalar loads.  The same functions on the same values in the same
+// order as every other fused kernel: the same bits
+// (tests/test_gpu_parity.py test_kernel_variants_agree_bit_for_bit).
+#ifndef COUPLED_PIPE_DAYS
+#define COUPLED_PIPE_DAYS 8
+#endif
+#ifndef COUPLED_PIPE_MINWAVES
+#define COUPLED_PIPE_MINWAVES 4
+#endif
+template <int L, class UH>
+__global__ __launch_bounds__(2 * RR_BLOCK, COUPLED_PIPE_MINWAVES) void
+cemaneigegr4j_pipe_kernel(
+    const double *__restrict__ days, const double *__restrict__ gtresh,
+    int64_t T, double snow_pack_init, double thermal_state_init,
+    double s_init, double r_init, const double *__restrict__ params,
+    int64_t N, const int *__restrict__ plan, int force_lds,
+    double *__restrict__ sse, int warm)
+{
+    constexpr int K = COUPLED_PIPE_DAYS;
+    static_assert(K % 2 == 0, "the GR4J wave's two generations");
+    __shared__ double ring[2][K][RR_BLOCK];
+    int n1cap, n2cap;
+    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
+    constexpr int D = cema_record_len(L, true);
+    if (warm) rr_warm_l2(days, (T + 1) * (int64_t)D * 8);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & (RR_BLOCK - 1);
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + lane;
+    const bool active = i < N;
+    const double *p = params + (active ? i : N - 1) * 6;
+    const cema_rec_ptr_t drec = (cema_rec_ptr_t)days;
+    const int Ti = (int)T;
+    const int nblk = (Ti + K - 1) / K;
+    if (wave == 0) {
+        // ---- the snow routine, one block of K days ahead ----------------------
+        const double CTG = p[0], Kf = p[1];
+        const double omc = 1 - CTG;
+        double G[L], eTG[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
+        const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
+        const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
+        auto snow_day = [&](auto first, auto sane, int t)
+            __attribute__((always_inline)) {
+            double day[3 * L];   // by value: one wide scalar load per day
+            const cema_rec_ptr_t rec = drec + (int64_t)t * D;
+#pragma unroll
+            for (int k = 0; k < 3 * L; ++k) day[k] = rec[k];
+            return cema_day<L, decltype(first)::value, false,
+                            decltype(sane)::value>(
+                day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
+                omc, Kf, G, eTG, (const CemaGtRegs<L> *)nullptr);
+        };
+        auto run = [&](auto sane) __attribute__((always_inline)) {
+            // day 0 (peeled: the reference's t = 0 branch)
+            ring[0][0][lane] = snow_day(std::true_type{}, sane, 0);
+            for (int b = 0; b < nblk; ++b) {
+                double (*half)[RR_BLOCK] = ring[b & 1];
+                for (int k = (b == 0 ? 1 : 0); k < K; ++k) {
+                    const int t = b * K + k;
+                    if (t < Ti)
+                        half[k][lane] = snow_day(std::false_type{}, sane, t);
+                }
+                __syncthreads();        // block b is in the ring
+            }
+        };
+        // (two copies of the time loop, see cemaneige_kernel)
+        if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
+                              thermal_state_init))
+            run(std::true_type{});
+        else
+            run(std::false_type{});
+    } else {
+        // ---- the GR4J day, optimistic, two generations ------------------------
+        Gr4jPar P;
+        P.set(p[2], p[3], p[4], p[5]);
+        typedef Gr4jGen<UH> Gen;
+        Gen A, B;
+        UH uh;
+        uh.init(P.x4, A.u);
+        A.s = s_init * P.x1;
+        A.r = r_init * P.x3;
+        double acc = 0.0;
+        constexpr int CONSTS = GR4J_CONSTS_SGPR;
+        auto gr4j_day = [&](const Gen &in, Gen &out, int t, double liquid)
+            __attribute__((always_inline)) {
+            // the day's evapotranspiration and observation: the record's two
+            // trailing slots, one 16-byte scalar load
+            const cema_rec_ptr_t tail = drec + (int64_t)t * D + 3 * L;
+            const double etp_t = tail[0], qobs_t = tail[1];
+            const bool wet = liquid >= etp_t;               // gr4j_model.py:89
+            const double net = fabs(liquid - etp_t);        // :90, :102
+            const lanemask_t net_m = gr4j_num_lanes(net);
+            OptimisticVotes votes;
+            double s = in.s, r = in.r;
+            double p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
+                                                     Gr4jNoHook(), votes);
+            double q = gr4j_routing<UH>(P, r, uh, in.u, out.u, p_r, votes);
+            if (RR_VOTES_FAILED(votes)) {
+                // some lane left a fast form's domain: the day again from its
+                // untouched start state, every vote decided on the spot
+                asm volatile("");
+                s = in.s;
+                r = in.r;
+                p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m);
+                q = gr4j_routing<UH>(P, r, uh, in.u, out.u, p_r);
+            }
+            out.s = s;
+            out.r = r;
+            const double d = qobs_t - q;
+            acc = __builtin_fma(d, d, acc);
+        };
+        for (int b = 0; b < nblk; ++b) {
+            __syncthreads();            // block b has arrived
+            double (*half)[RR_BLOCK] = ring[b & 1];
+            for (int k = 0; k < K; k += 2) {
+                const int t = b * K + k;
+                if (t < Ti) gr4j_day(A, B, t, half[k][lane]);
+                if (t + 1 < Ti) gr4j_day(B, A, t + 1, half[k + 1][lane]);
+            }
+        }
+        if (active) sse[i] = acc;
+    }
+}
+
 // ---- more than RR_CEMANEIGE_MAX_LAYERS elevation layers ----------------------
 // Same day step with a run-time layer count; the per-layer snow states live
 // in an HBM scratch [2][L][N] (lane-contiguous, so every access is a coalesced
@@ -1192,6 +1341,16 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
             using UH = decltype(uh);
             const size_t lds = std::is_same<UH, UhLds>::value ? lds_bytes : 0;
             if constexpr (coupled_has_optimistic<LL.value, UH>()) {
+                // 5: the two-wave pipeline (score-only sweeps: nothing but
+                // the squared-error sums is written)
+                if (fv == 5 && !qsim && !G && qo) {
+                    cemaneigegr4j_pipe_kernel<LL.value, UH>
+                        <<<grid, dim3(2 * RR_BLOCK), 0, st>>>(
+                            days, gt, T, snow_pack_init, thermal_state_init,
+                            s_init, r_init, params, N, d_plan, force_lds, sse,
+                            tiles.warm);
+                    return;
+                }
                 // 3: small-sweep form with an optimistic GR4J half -- the
                 // default for at most two waves per SIMD (125k sets: 14.35 ->
                 // 13.96 ms) --, 4: many-waves form with one (measured slower

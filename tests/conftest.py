@@ -86,9 +86,11 @@ def hbv_variant(request):
 # Likewise the fused CemaneigeGR4J kernel: 1 = the many-waves kernel (million-
 # set sweeps), 2 = the small-sweep kernel (<= 131,072 sets: constants and melt
 # thresholds in VGPRs), 0 = the library's own choice by sweep size.
-@pytest.fixture(params=[0, 1, 2, 3, 4],
+# 5 = the two-wave pipeline (score-only sweeps; with outputs requested the
+# library's own choice runs)
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5],
                 ids=["auto", "many-waves", "small-sweep", "optimistic-small",
-                     "optimistic-many-waves"])
+                     "optimistic-many-waves", "pipeline"])
 def fused_variant(request):
     from rrmpg_amd import _lib
     with _lib.debug_option("fused_variant", request.param):

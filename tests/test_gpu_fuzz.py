@@ -801,6 +801,14 @@ def test_kernel_variants_agree_bit_for_bit(models):
     with _lib.debug_option("fused_variant", 1):
         _, fsse = fmod._run(layers, (3.0, -0.2, 0.4, 0.5), rec, False, False,
                             fq)
+    # the score-only forms of every variant, the two-wave pipeline (5) among
+    # them: the sums of the sweep that writes its series
+    for v in (0, 2, 3, 4, 5):
+        with _lib.debug_option("fused_variant", v):
+            _, sse_v = fmod._run(layers, (3.0, -0.2, 0.4, 0.5), rec, False,
+                                 False, fq)
+        assert np.array_equal(sse_v, fsse), "fused variant %d, scores" % v
+    with _lib.debug_option("fused_variant", 1):
         for tiles in (2, 3, 5):
             with _lib.debug_option("time_tiles", tiles):
                 out, sse_t = fmod._run(layers, (3.0, -0.2, 0.4, 0.5), rec,

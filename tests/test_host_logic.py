@@ -411,7 +411,7 @@ def test_debug_options_and_cache_release_need_no_gpu():
     assert lib.rr_debug_get_option(opt["hbv_variant"]) == -1
     assert lib.rr_debug_set_option(opt["hbv_variant"], 7) == -4    # RR_E_PARAM
     assert lib.rr_debug_get_option(opt["fused_variant"]) == 0
-    assert lib.rr_debug_set_option(opt["fused_variant"], 5) == -4
+    assert lib.rr_debug_set_option(opt["fused_variant"], 6) == -4
     assert lib.rr_debug_get_option(opt["time_tiles"]) == -1
     assert lib.rr_debug_set_option(opt["time_tiles"], 1) == -4
     assert lib.rr_debug_get_option(opt["gr4j_variant"]) == 0
