@@ -560,3 +560,35 @@ def test_resident_outputs_start_rows_on_128_byte_boundaries():
     with pytest.raises(ValueError, match="row stride"):
         dev._Ensemble._check_outputs(
             ens, 99, (q, torch.empty((7, 99), dtype=torch.float64)))
+
+
+def test_counter_results_are_tied_to_the_kernel_sources(monkeypatch):
+    """profiles/traffic.json carries the ids of the kernel sources its
+    counters were collected on (rrmpg_amd/utils/buildid.py); bench.py quotes a
+    model's HBM traffic / instruction count only while the tree's sources are
+    those, and says "stale" otherwise."""
+    import argparse
+    import json
+    import bench
+    from rrmpg_amd.utils import buildid
+    ids = {m: buildid.kernel_source_id(m) for m in buildid._KERNEL_FILE}
+    assert all(len(v) == 16 and int(v, 16) >= 0 for v in ids.values())
+    assert ids["hbvedu"] != ids["gr4j"] != ids["abc"]
+    assert ids["cemaneige"] == ids["cemaneigegr4j"]      # one kernel file
+    with open(os.path.join(REPO, "profiles", "traffic.json")) as fh:
+        pmc = json.load(fh)
+    assert set(pmc["_build"]) == set(ids)
+    args = argparse.Namespace(model="hbvedu", mode="qsim", sets=1_000_000,
+                              catchments=0)
+    key = "hbvedu:qsim:1000000:10957"
+    assert key in pmc and key + ":valu_instr_per_unit" in pmc
+    # sources as stamped: the numbers are quoted ...
+    monkeypatch.setattr(buildid, "kernel_source_id",
+                        lambda m: pmc["_build"][m])
+    traffic, valu = bench.traffic_record(args, 1_000_000, 10957)
+    assert traffic == pmc[key] and valu == pmc[key + ":valu_instr_per_unit"]
+    assert bench.traffic_is_stale("hbvedu") is False
+    # ... sources changed since: withheld
+    monkeypatch.setattr(buildid, "kernel_source_id", lambda m: "0" * 16)
+    assert bench.traffic_record(args, 1_000_000, 10957) == (None, None)
+    assert bench.traffic_is_stale("hbvedu") is True
