@@ -706,7 +706,7 @@ cemaneigegr4j_opt_kernel(
 // lighter waves instead of two heavy ones, and neither wave waits for the
 // other's scalar loads.  The same functions on the same values in the same
 // order as every other fused kernel: the same bits
-// (tests/test_gpu_parity.py test_kernel_variants_agree_bit_for_bit).
+// (tests/test_gpu_fuzz.py test_kernel_variants_agree_bit_for_bit).
 #ifndef COUPLED_PIPE_DAYS
 #define COUPLED_PIPE_DAYS 8
 #endif

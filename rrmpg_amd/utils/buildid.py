@@ -6,6 +6,7 @@ collection shows as "stale" instead of silently keeping the old numbers."""
 import glob
 import hashlib
 import os
+import re
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                      "csrc")
@@ -16,14 +17,24 @@ _KERNEL_FILE = {"hbvedu": "hbvedu.hip", "abc": "abc.hip", "gr4j": "gr4j.hip",
                 "cemaneigehystgr4jice": "snownext.hip"}
 
 
+_COMMENTS = re.compile(r"//[^\n]*|/\*.*?\*/", re.S)
+
+
+def _code_of(text):
+    """The source without its comments and with runs of white space
+    collapsed: an edit of a comment is not a change of the kernel."""
+    return " ".join(_COMMENTS.sub(" ", text).split())
+
+
 def kernel_source_id(model):
-    """sha256 (16 hex digits) over the model's kernel file and every header of
+    """sha256 (16 hex digits) over the CODE (comments and white space
+    dropped) of the model's kernel file and of every header of
     rrmpg_amd/csrc, in name order."""
     files = sorted(glob.glob(os.path.join(_CSRC, "*.h")))
     files.append(os.path.join(_CSRC, _KERNEL_FILE[model]))
     h = hashlib.sha256()
     for path in files:
         h.update(os.path.basename(path).encode())
-        with open(path, "rb") as fh:
-            h.update(fh.read())
+        with open(path, "r", encoding="utf-8", errors="replace") as fh:
+            h.update(_code_of(fh.read()).encode())
     return h.hexdigest()[:16]
