@@ -116,6 +116,41 @@ int rr_get_device(void);
  * next call allocates again). */
 int rr_release_cached_memory(void);
 
+/* ---- the job's one collective ----------------------
+ * A sweep sharded over several processes / GPUs (contiguous blocks of sets,
+ * forcing replicated, no exchange on the data path: the loop the reference
+ * runs over its sets, rrmpg/tools/monte_carlo.py:61-71, cut into blocks)
+ * exchanges ONE thing: the per-set scores, 8 bytes a set, all-gathered so
+ * that every rank holds the whole sweep's.  In Python that is
+ * rrmpg_amd.sharding.allgather_scores over torch.distributed; these entry
+ * points are the same exchange over RCCL / xGMI for a binder without Python
+ * or torch.  librccl is opened at first use: librrhip.so itself does not
+ * link against it.
+ *   rr_shard_bounds     rank's block [first, stop) of n_total sets: sizes
+ *                       differ by at most one, the first n_total % world
+ *                       ranks hold the longer ones (sharding.shard_bounds)
+ *   rr_comm_unique_id   rank 0: RR_COMM_ID_BYTES bytes to hand to every rank
+ *                       out of band (ncclGetUniqueId)
+ *   rr_comm_init        every rank, its GPU selected (rr_set_device /
+ *                       hipSetDevice) beforehand; collective, blocks until
+ *                       all ranks have called (ncclCommInitRank)
+ *   rr_allgather_metric local: this rank's n_local device doubles; all:
+ *                       n_total device doubles, block r of rank r in set
+ *                       order (local may be all + first: in place).  One
+ *                       group of broadcasts, rank r the root of block r:
+ *                       ragged blocks need no padding and nothing is
+ *                       allocated.  Enqueued on `stream` (hipStream_t),
+ *                       returns at once like the *_simulate_dev family.
+ *   rr_comm_destroy                                                          */
+#define RR_COMM_ID_BYTES 128
+int rr_shard_bounds(int64_t n_total, int world, int rank, int64_t *first,
+                    int64_t *stop);
+int rr_comm_unique_id(void *id_out);
+int rr_comm_init(void **comm_out, int world, int rank, const void *id);
+int rr_allgather_metric(void *comm, const double *local, int64_t n_local,
+                        double *all, int64_t n_total, void *stream);
+int rr_comm_destroy(void *comm);
+
 /* Options: which GPUs a host-pointer call spreads over, and which kernel
  * variant / blocking a call uses where the library's own choice (by sweep
  * size) is to be overridden.  Every option is an integer indexed by RR_OPT_*.

@@ -46,6 +46,17 @@ _SIGNATURES = {
     "rr_set_device": (ctypes.c_int, [ctypes.c_int]),
     "rr_get_device": (ctypes.c_int, []),
     "rr_release_cached_memory": (ctypes.c_int, []),
+    "rr_shard_bounds": (ctypes.c_int, [_i64, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(_i64),
+                                       ctypes.POINTER(_i64)]),
+    "rr_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "rr_comm_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p),
+                                    ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_void_p]),
+    "rr_allgather_metric": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
+                                           _i64, ctypes.c_void_p, _i64,
+                                           ctypes.c_void_p]),
+    "rr_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "rr_debug_set_option": (ctypes.c_int, [ctypes.c_int, _i64]),
     "rr_debug_get_option": (_i64, [ctypes.c_int]),
     "rr_call_options_init": (None, [_optp]),

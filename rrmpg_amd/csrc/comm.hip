@@ -1,0 +1,212 @@
+// comm.hip -- the job's one collective inside the C-ABI.
+//
+// The reference has no distributed code; its scalable axis, the loop over
+// parameter sets (rrmpg/models/hbvedu.py:199-209, tools/monte_carlo.py:61-71),
+// shards into contiguous blocks, one per process / GPU, with no exchange on
+// the data path.  What a sharded Monte-Carlo job exchanges is ONE all-gather
+// of the per-set scores (8 bytes per set) -- in Python that is
+// rrmpg_amd.sharding.allgather_scores over torch.distributed (backend "nccl"
+// = RCCL).  A binder that has neither Python nor torch gets the same exchange
+// here, over RCCL / xGMI directly:
+//
+//   rr_comm_unique_id  (rank 0; the 128 bytes travel out of band)
+//   rr_comm_init       (every rank, one per GPU: ncclCommInitRank)
+//   rr_allgather_metric(comm, local block, n_total scores out, stream)
+//   rr_comm_destroy
+//
+// The blocks are rrmpg_amd.sharding.shard_bounds' (contiguous, sizes differ
+// by at most one, the first n_total % world ranks hold the longer ones).
+// Ragged blocks rule out ncclAllGather's equal counts, so the exchange is one
+// group of `world` broadcasts, rank r the root of block r, each landing in
+// its place of `all` -- no padding, no staging buffer, nothing allocated.
+// Asynchronous on `stream` like the *_simulate_dev family.
+//
+// librccl is opened at first use (dlopen "librccl.so.1": the copy a host
+// program -- PyTorch, say -- has already loaded is the one that answers),
+// so librrhip.so itself carries no link-time dependency on it and every other
+// entry point works on a box without RCCL.
+#include <dlfcn.h>
+#include <string.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t,
+                              int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+const Rccl *rccl()
+{
+    std::call_once(g_rccl_once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.handle) break;
+        }
+        if (!g_rccl.handle) return;
+        auto sym = [](const char *n) { return dlsym(g_rccl.handle, n); };
+        g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+        g_rccl.CommInitRank =
+            (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+        g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+        g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
+        g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+        g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+        g_rccl.GetErrorString =
+            (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+        g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank &&
+                    g_rccl.CommDestroy && g_rccl.Broadcast &&
+                    g_rccl.GroupStart && g_rccl.GroupEnd;
+    });
+    return g_rccl.ok ? &g_rccl : nullptr;
+}
+
+struct RrComm {
+    ncclComm_t comm;
+    int world, rank;
+};
+
+int fail(const Rccl *r, const char *what, ncclResult_t rc)
+{
+    rr_set_error("%s: %s", what,
+                 r->GetErrorString ? r->GetErrorString(rc) : "RCCL error");
+    return RR_E_HIP;
+}
+const Rccl *need_rccl(const char *who)
+{
+    const Rccl *r = rccl();
+    if (!r)
+        rr_set_error("%s: librccl.so.1 could not be opened (or lacks an entry "
+                     "point): %s", who, dlerror() ? dlerror() : "-");
+    return r;
+}
+}  // namespace
+
+static_assert(RR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "rrhip.h");
+
+extern "C" int rr_comm_unique_id(void *id_out)
+{
+    if (!id_out) {
+        rr_set_error("rr_comm_unique_id: id_out is NULL");
+        return RR_E_NULL;
+    }
+    const Rccl *r = need_rccl("rr_comm_unique_id");
+    if (!r) return RR_E_NODEVICE;
+    ncclUniqueId id;
+    const ncclResult_t rc = r->GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail(r, "ncclGetUniqueId", rc);
+    memcpy(id_out, id.internal, RR_COMM_ID_BYTES);
+    return RR_OK;
+}
+
+extern "C" int rr_comm_init(void **comm_out, int world, int rank,
+                            const void *id)
+{
+    if (!comm_out || !id) {
+        rr_set_error("rr_comm_init: NULL argument");
+        return RR_E_NULL;
+    }
+    *comm_out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) {
+        rr_set_error("rr_comm_init: rank %d of %d", rank, world);
+        return RR_E_SIZE;
+    }
+    const Rccl *r = need_rccl("rr_comm_init");
+    if (!r) return RR_E_NODEVICE;
+    ncclUniqueId uid;
+    memcpy(uid.internal, id, RR_COMM_ID_BYTES);
+    RrComm *c = new RrComm{nullptr, world, rank};
+    const ncclResult_t rc = r->CommInitRank(&c->comm, world, uid, rank);
+    if (rc != ncclSuccess) {
+        delete c;
+        return fail(r, "ncclCommInitRank", rc);
+    }
+    *comm_out = c;
+    return RR_OK;
+}
+
+extern "C" int rr_comm_destroy(void *comm)
+{
+    if (!comm) return RR_OK;
+    RrComm *c = (RrComm *)comm;
+    const Rccl *r = need_rccl("rr_comm_destroy");
+    ncclResult_t rc = ncclSuccess;
+    if (r) rc = r->CommDestroy(c->comm);
+    delete c;
+    if (r && rc != ncclSuccess) return fail(r, "ncclCommDestroy", rc);
+    return RR_OK;
+}
+
+// [first, stop) of rank r's block (rrmpg_amd/sharding.py shard_bounds)
+extern "C" int rr_shard_bounds(int64_t n_total, int world, int rank,
+                               int64_t *first, int64_t *stop)
+{
+    if (!first || !stop) {
+        rr_set_error("rr_shard_bounds: NULL output");
+        return RR_E_NULL;
+    }
+    if (n_total < 0 || world < 1 || rank < 0 || rank >= world) {
+        rr_set_error("rr_shard_bounds: %lld sets, rank %d of %d",
+                     (long long)n_total, rank, world);
+        return RR_E_SIZE;
+    }
+    const int64_t base = n_total / world, extra = n_total % world;
+    *first = rank * base + (rank < extra ? rank : extra);
+    *stop = *first + base + (rank < extra ? 1 : 0);
+    return RR_OK;
+}
+
+extern "C" int rr_allgather_metric(void *comm, const double *local,
+                                   int64_t n_local, double *all,
+                                   int64_t n_total, void *stream)
+{
+    const char *who = "rr_allgather_metric";
+    if (!comm || !all || (!local && n_local > 0)) {
+        rr_set_error("%s: NULL argument", who);
+        return RR_E_NULL;
+    }
+    RrComm *c = (RrComm *)comm;
+    int64_t first = 0, stop = 0;
+    int rc = rr_shard_bounds(n_total, c->world, c->rank, &first, &stop);
+    if (rc != RR_OK) return rc;
+    if (n_local != stop - first) {
+        rr_set_error("%s: rank %d of %d holds %lld scores, its block of %lld "
+                     "has %lld", who, c->rank, c->world, (long long)n_local,
+                     (long long)n_total, (long long)(stop - first));
+        return RR_E_SIZE;
+    }
+    const Rccl *r = need_rccl(who);
+    if (!r) return RR_E_NODEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    ncclResult_t nrc = r->GroupStart();
+    if (nrc != ncclSuccess) return fail(r, "ncclGroupStart", nrc);
+    for (int root = 0; root < c->world; ++root) {
+        int64_t a = 0, b = 0;
+        (void)rr_shard_bounds(n_total, c->world, root, &a, &b);
+        if (b == a) continue;
+        nrc = r->Broadcast(root == c->rank ? (const void *)local
+                                           : (const void *)(all + a),
+                           all + a, (size_t)(b - a), ncclFloat64, root,
+                           c->comm, st);
+        if (nrc != ncclSuccess) {
+            (void)r->GroupEnd();
+            return fail(r, "ncclBroadcast", nrc);
+        }
+    }
+    nrc = r->GroupEnd();
+    if (nrc != ncclSuccess) return fail(r, "ncclGroupEnd", nrc);
+    return RR_OK;
+}

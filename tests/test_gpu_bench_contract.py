@@ -222,3 +222,96 @@ def test_rccl_collectives_on_one_rank(tmp_path):
                          text=True, timeout=300,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_c_abi_allgather_over_rccl_on_one_rank(tmp_path):
+    """The collective of the C-ABI itself (include/rrhip.h rr_comm_* /
+    rr_allgather_metric: RCCL opened at first use, one group of broadcasts,
+    rank r the root of block r) -- with the one rank a single-GPU box can
+    host: communicator from a unique id, out of place and in place, the
+    block-size check, destroy.  In a process of its own (RCCL and a second
+    communicator next to torch's are not what the other tests need)."""
+    script = tmp_path / "abi_one_rank.py"
+    script.write_text(
+        "import ctypes, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from rrmpg_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "torch.cuda.set_device(0)\n"
+        "ident = (ctypes.c_char * 128)()\n"
+        "assert lib.rr_comm_unique_id(ident) == 0, lib.rr_last_error()\n"
+        "comm = ctypes.c_void_p()\n"
+        "assert lib.rr_comm_init(ctypes.byref(comm), 1, 0, ident) == 0, "
+        "lib.rr_last_error()\n"
+        "n = 1001\n"
+        "x = torch.arange(n, dtype=torch.float64, device='cuda') * 0.25\n"
+        "y = torch.zeros(n, dtype=torch.float64, device='cuda')\n"
+        "st = torch.cuda.current_stream().cuda_stream\n"
+        "assert lib.rr_allgather_metric(comm, x.data_ptr(), n, y.data_ptr(),"
+        " n, st) == 0, lib.rr_last_error()\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(x, y)\n"
+        "z = x.clone()\n"
+        "assert lib.rr_allgather_metric(comm, z.data_ptr(), n, z.data_ptr(),"
+        " n, st) == 0\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(x, z)\n"
+        "assert lib.rr_allgather_metric(comm, x.data_ptr(), n - 1, "
+        "y.data_ptr(), n, st) == -2\n"
+        "assert b'holds 1000 scores' in lib.rr_last_error()\n"
+        "assert lib.rr_comm_destroy(comm) == 0\n"
+        "print('abi rccl ok')\n" % REPO)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True,
+                         text=True, timeout=300,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "abi rccl ok" in out.stdout, \
+        (out.stdout + out.stderr)[-2000:]
+
+
+def test_c_abi_allgather_over_rccl_two_ranks(tmp_path):
+    """Two processes, one GPU each, ragged blocks (1001 scores: 501 + 500):
+    the id travels through a file, every rank ends with the whole vector."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    script = tmp_path / "abi_two_ranks.py"
+    script.write_text(
+        "import ctypes, os, sys, time, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from rrmpg_amd import _lib\n"
+        "rank, idfile = int(sys.argv[1]), sys.argv[2]\n"
+        "lib = _lib.load()\n"
+        "torch.cuda.set_device(rank)\n"
+        "ident = (ctypes.c_char * 128)()\n"
+        "if rank == 0:\n"
+        "    assert lib.rr_comm_unique_id(ident) == 0, lib.rr_last_error()\n"
+        "    open(idfile + '.tmp', 'wb').write(bytes(ident))\n"
+        "    os.rename(idfile + '.tmp', idfile)\n"
+        "else:\n"
+        "    while not os.path.exists(idfile): time.sleep(0.05)\n"
+        "    ident = (ctypes.c_char * 128).from_buffer_copy("
+        "open(idfile, 'rb').read())\n"
+        "comm = ctypes.c_void_p()\n"
+        "assert lib.rr_comm_init(ctypes.byref(comm), 2, rank, ident) == 0, "
+        "lib.rr_last_error()\n"
+        "n = 1001\n"
+        "a, b = ctypes.c_int64(), ctypes.c_int64()\n"
+        "lib.rr_shard_bounds(n, 2, rank, ctypes.byref(a), ctypes.byref(b))\n"
+        "whole = torch.arange(n, dtype=torch.float64, device='cuda') * 0.5\n"
+        "mine = whole[a.value:b.value].clone()\n"
+        "out = torch.zeros(n, dtype=torch.float64, device='cuda')\n"
+        "st = torch.cuda.current_stream().cuda_stream\n"
+        "assert lib.rr_allgather_metric(comm, mine.data_ptr(), mine.numel(), "
+        "out.data_ptr(), n, st) == 0, lib.rr_last_error()\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(out, whole)\n"
+        "assert lib.rr_comm_destroy(comm) == 0\n"
+        "print('rank', rank, 'ok')\n" % REPO)
+    idfile = str(tmp_path / "rccl.id")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), idfile],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok" % r in o, o[-2000:]

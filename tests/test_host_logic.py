@@ -592,3 +592,37 @@ def test_counter_results_are_tied_to_the_kernel_sources(monkeypatch):
     monkeypatch.setattr(buildid, "kernel_source_id", lambda m: "0" * 16)
     assert bench.traffic_record(args, 1_000_000, 10957) == (None, None)
     assert bench.traffic_is_stale("hbvedu") is True
+
+
+def test_shard_bounds_and_the_collectives_argument_checks():
+    """rr_shard_bounds (the C-ABI's partition of the parameter-set axis) is
+    rrmpg_amd.sharding.shard_bounds; the RCCL entry points reject bad
+    arguments before they touch the communication library (no GPU here)."""
+    import ctypes
+    from rrmpg_amd.sharding import shard_bounds
+    lib = _lib.load()
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    for n in (0, 1, 7, 64, 1000, 1_000_003):
+        for world in (1, 2, 3, 8, 64):
+            prev = 0
+            for r in range(world):
+                assert lib.rr_shard_bounds(n, world, r, ctypes.byref(a),
+                                           ctypes.byref(b)) == 0
+                assert (a.value, b.value) == shard_bounds(n, world, r)
+                assert a.value == prev
+                prev = b.value
+            assert prev == n
+    assert lib.rr_shard_bounds(10, 3, 3, ctypes.byref(a),
+                               ctypes.byref(b)) == -2          # RR_E_SIZE
+    assert lib.rr_shard_bounds(10, 0, 0, ctypes.byref(a), ctypes.byref(b)) == -2
+    assert lib.rr_shard_bounds(10, 2, 0, None, ctypes.byref(b)) == -1
+    comm = ctypes.c_void_p()
+    ident = (ctypes.c_char * 128)()
+    assert lib.rr_comm_init(ctypes.byref(comm), 2, 2, ident) == -2
+    assert lib.rr_comm_init(ctypes.byref(comm), 0, 0, ident) == -2
+    assert lib.rr_comm_init(None, 1, 0, ident) == -1
+    assert lib.rr_comm_init(ctypes.byref(comm), 1, 0, None) == -1
+    assert lib.rr_comm_unique_id(None) == -1
+    assert lib.rr_allgather_metric(None, None, 0, None, 0, None) == -1
+    assert b"NULL" in lib.rr_last_error()
+    assert lib.rr_comm_destroy(None) == 0
