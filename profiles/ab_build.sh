@@ -13,5 +13,5 @@ obj=exp/${src%.hip}_$tag.o
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall \
     -Wno-unused-function "$@" -c rrmpg_amd/csrc/$src -o $obj
 others=$(ls rrmpg_amd/csrc/*.o | grep -v "/${src%.hip}.o")
-hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o exp/librrhip_$tag.so $obj $others
+hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o exp/librrhip_$tag.so $obj $others -ldl
 echo "built exp/librrhip_$tag.so ($*)"

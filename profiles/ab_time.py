@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--gr4j-variant", type=int, default=0)
     ap.add_argument("--catchments", type=int, default=0)
     ap.add_argument("--warm-records", type=int, default=-1)
+    ap.add_argument("--force-lds", type=int, default=0)
     a = ap.parse_args()
     from rrmpg_amd import _lib
     if a.lib:
@@ -59,6 +60,7 @@ def main():
             lib.rr_debug_set_option(_lib.OPTIONS["fused_variant"],
                                     a.fused_variant)
         lib.rr_debug_set_option(_lib.OPTIONS["warm_records"], a.warm_records)
+        lib.rr_debug_set_option(_lib.OPTIONS["gr4j_force_lds"], a.force_lds)
         if a.gr4j_variant:
             lib.rr_debug_set_option(_lib.OPTIONS["gr4j_variant"],
                                     a.gr4j_variant)

@@ -33,7 +33,8 @@
 //   observation (cema_day_meta)
 // `insane`: counts the values that rule out the SANE form of the snow routine
 // (snow_core.h cema_day, snownext.hip cema_hyst_day): a snowfall that is not
-// a number in [0, 1e290], a temperature that is not finite (or beyond 1e300).
+// a number in [0, 1e290], a temperature that is not finite (or beyond 1e300),
+// a rain whose sign bit is set.
 // Zeroed by rr_cema_prepass before the launch.
 __global__ void cema_pack(const double *__restrict__ prec,
                           const double *__restrict__ mean_temp,
@@ -56,7 +57,10 @@ __global__ void cema_pack(const double *__restrict__ prec,
     d[L + l] = rain;
     d[2 * L + l] = temp;
     if (etp && l == 0) d[3 * L] = etp[t];
-    if (!(snow >= 0.0 && snow <= 1e290) || !(fabs(temp) <= 1e300))
+    // (... or a rain of -0 or below: on a day without melt the hysteresis
+    // routine's outflow is the rain itself, snownext.hip)
+    if (!(snow >= 0.0 && snow <= 1e290) || !(fabs(temp) <= 1e300) ||
+        __builtin_signbit(rain))
         atomicAdd(insane, 1ull);
     // forcing the GR4J half's fast forms are not meant for
     // (gr4j_reference.h): with any, every set takes the reference's sequence

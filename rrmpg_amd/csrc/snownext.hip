@@ -39,6 +39,31 @@
 // c / L as the reference's mean forms them, and a plain snow_balance / Thacc
 // -- the outflow is then the reference's to the bit (snow_core.h
 // cema_ref_day says why it has to be).
+// IDLE DAYS (SANE waves, every day but the first; HYST_IDLE_DAYS): most days of
+// a year no layer sees snowfall and no lane of the wave melts anything --
+// summer without a pack, dry frost.  The day is therefore evaluated in two
+// steps: pack + snowfall, thermal state and potential melt of every layer
+// (eleven vector instructions a layer, straight line), then ONE wave-uniform
+// question -- any snowfall (the record's own bits), any lane with a potential
+// melt that is not zero?  If not, the reference's statements reduce to: the
+// covered area keeps its bits (prev + (+0) / Thacc, and min(., 1) of a value
+// that was clamped the day before), the SWE maximum takes the pack's (:128),
+// melt = factor * (+0) = +0 with a finite positive factor, the pack keeps its
+// bits, `if G == 0: max = 0` finds the zero the day before left, and the
+// outflow is the layers' rain (rain + (+0), rain never -0: the pre-pass
+// counts a rain with the sign bit set among the forcing values that rule out
+// SANE).  Two instructions per layer instead of thirty.
+// What the synthetic forcing of the bench has of such days: 22 % -- dry frost.
+// A warm day is never idle: a pack melts by a tenth of itself a day at the end
+// (factor 0.9 sca + 0.1 -> 0.1) and is never exactly gone, in no lane.
+// (Measured and dropped, round 5: the other days split the same way -- every
+// lane of every layer accumulating / melting -- with the five layers' quotients
+// in one basic block for the scheduler to interleave: 16-24 more VGPRs, spills
+// to scratch in the 3- and 10-slot tiers, 135 -> 159 ms.
+// profiles/r05_hyst_days_ab.txt)
+#ifndef HYST_IDLE_DAYS
+#define HYST_IDLE_DAYS 1
+#endif
 template <int L, bool FIRST, bool SANE = false, bool REF = false>
 __device__ __forceinline__ double cema_hyst_day(
     const double *__restrict__ day, const double *__restrict__ psol,
@@ -48,28 +73,65 @@ __device__ __forceinline__ double cema_hyst_day(
     double (&G)[L], double (&eTG)[L],
     double (&sca)[L], double (&swe_max)[L])
 {
+    constexpr bool TWO_STEPS = HYST_IDLE_DAYS && SANE && !FIRST && !REF;
+    double g_[L], e_[L], pot_[L];
+    if constexpr (TWO_STEPS) {
+        lanemask_t busy = 0;
+        unsigned snowfall = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const double snow = day[l], temp = day[2 * L + l];
+            snowfall |= (unsigned)__double2hiint(snow) |
+                        (unsigned)__double2loint(snow);
+            g_[l] = G[l] + snow;
+            double e = CTG * eTG[l] + one_minus_CTG * temp;
+            asm("v_min_f64 %0, %1, 0" : "=v"(e) : "v"(e));
+            e_[l] = e;
+            const double pm = rr_hw_min(Kf * temp, g_[l]);
+            pot_[l] = (e == 0 && temp > 0) ? pm : 0.0;
+            busy |= RR_LANES(pot_[l] != 0.0);
+        }
+        if (snowfall == 0 && busy == 0) {
+            double c = 0.0;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                swe_max[l] = rr_hw_max(swe_max[l], g_[l]);
+                G[l] = g_[l];
+                eTG[l] = e_[l];
+                const double rain = day[L + l];
+                c = (l == 0) ? rain : c + rain;
+            }
+            return cema_layer_mean<L>(c);
+        }
+    }
     double c = 0.0;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const double snow = day[l], rain = day[L + l], temp = day[2 * L + l];
         double g, e;
-        if (FIRST) {                                       // :98-110
-            g = snow_pack_init;
-            e = thermal_state_init;
-        } else {
-            g = G[l] + snow;
-            e = CTG * eTG[l] + one_minus_CTG * temp;
-        }
-        if (SANE && !FIRST) {
-            asm("v_min_f64 %0, %1, 0" : "=v"(e) : "v"(e));
-        } else {
-            if (e > 0) e = 0.0;
-        }
         double pot_melt = 0.0;                             // :113-120
-        if (e == 0 && temp > 0) {
-            pot_melt = Kf * temp;
-            if (SANE) pot_melt = rr_hw_min(pot_melt, g);   // (Kf is not NaN)
-            else if (pot_melt > g) pot_melt = g;
+        if constexpr (TWO_STEPS) {
+            g = g_[l];
+            e = e_[l];
+            pot_melt = pot_[l];
+        } else {
+            if (FIRST) {                                   // :98-110
+                g = snow_pack_init;
+                e = thermal_state_init;
+            } else {
+                g = G[l] + snow;
+                e = CTG * eTG[l] + one_minus_CTG * temp;
+            }
+            if (SANE && !FIRST) {
+                asm("v_min_f64 %0, %1, 0" : "=v"(e) : "v"(e));
+            } else {
+                if (e > 0) e = 0.0;
+            }
+            if (e == 0 && temp > 0) {
+                pot_melt = Kf * temp;
+                if (SANE) pot_melt = rr_hw_min(pot_melt, g);  // (Kf is not NaN)
+                else if (pot_melt > g) pot_melt = g;
+            }
         }
         const double snow_balance = snow - pot_melt;       // :123
         double sc;
