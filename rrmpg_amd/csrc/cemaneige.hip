@@ -34,7 +34,7 @@
 // `insane`: counts the values that rule out the SANE form of the snow routine
 // (snow_core.h cema_day, snownext.hip cema_hyst_day): a snowfall that is not
 // a number in [0, 1e290], a temperature that is not finite (or beyond 1e300),
-// a rain whose sign bit is set.
+// a rain whose sign bit is set, a positive subnormal temperature.
 // Zeroed by rr_cema_prepass before the launch.
 __global__ void cema_pack(const double *__restrict__ prec,
                           const double *__restrict__ mean_temp,
@@ -60,7 +60,7 @@ __global__ void cema_pack(const double *__restrict__ prec,
     // (... or a rain of -0 or below: on a day without melt the hysteresis
     // routine's outflow is the rain itself, snownext.hip)
     if (!(snow >= 0.0 && snow <= 1e290) || !(fabs(temp) <= 1e300) ||
-        __builtin_signbit(rain))
+        __builtin_signbit(rain) || (temp > 0.0 && temp < 0x1p-1022))
         atomicAdd(insane, 1ull);
     // forcing the GR4J half's fast forms are not meant for
     // (gr4j_reference.h): with any, every set takes the reference's sequence

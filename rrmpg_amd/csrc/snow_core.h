@@ -163,6 +163,9 @@ __device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 #ifndef CEMA_GT_SELECT_FORM
 #define CEMA_GT_SELECT_FORM 1
 #endif
+#ifndef CEMA_FROST_DAYS
+#define CEMA_FROST_DAYS 1
+#endif
 template <int L>
 struct CemaGtRegs { double gt[L], rgt[L]; };
 
@@ -206,6 +209,35 @@ __device__ __forceinline__ double cema_day_io(
     const CemaGtRegs<L> *gt_regs = nullptr, V &&votes = V())
 {
     double c = 0.0;
+    if constexpr (CEMA_FROST_DAYS && SANE && !FIRST) {
+        // Frost in every layer (a third of the days of a temperate year): no
+        // lane melts anything, whatever its thermal state -- `temp > 0` is
+        // false (:99) --, so melt = pot_melt = 0, the pack keeps g = G + snow
+        // (g - (+0), g never -0) and the layer gives its rain (rain + (+0),
+        // rain never -0: the pre-pass counts such forcing among what rules out
+        // SANE, as it does a positive subnormal temperature -- for every other
+        // finite one `temp > 0` is `high word > 0`).  One scalar question per
+        // day, six vector instructions a layer instead of ten.
+        int warmest = __double2hiint(day[2 * L]);
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            const int h = __double2hiint(day[2 * L + l]);
+            warmest = h > warmest ? h : warmest;
+        }
+        if (warmest <= 0) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const double snow = day[l], rain = day[L + l],
+                             temp = day[2 * L + l];
+                double e = CTG * eTG_in[l] + one_minus_CTG * temp;
+                asm("v_min_f64 %0, %1, 0" : "=v"(e) : "v"(e));
+                G[l] = G_in[l] + snow;
+                eTG[l] = e;
+                c = (l == 0) ? rain : c + rain;
+            }
+            return cema_layer_mean<L>(c, votes);
+        }
+    }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const double snow = day[l], rain = day[L + l], temp = day[2 * L + l];

@@ -59,7 +59,9 @@
 // (Measured and dropped, round 5: the other days split the same way -- every
 // lane of every layer accumulating / melting -- with the five layers' quotients
 // in one basic block for the scheduler to interleave: 16-24 more VGPRs, spills
-// to scratch in the 3- and 10-slot tiers, 135 -> 159 ms.
+// to scratch in the 3- and 10-slot tiers, 135 -> 159 ms.  Nor a frost-and-dry
+// day decided from the record alone in front of the layers' first step (what
+// snow_core.h cema_day_io gains from, 25.9 -> 23.8 ms): 135 -> 197 ms.
 // profiles/r05_hyst_days_ab.txt)
 #ifndef HYST_IDLE_DAYS
 #define HYST_IDLE_DAYS 1
