@@ -450,6 +450,57 @@ def test_cemaneige_vs_oracle(models, oracle):
         assert np.array_equal(o2, out[0])      # with / without storages
 
 
+def test_cemaneige_frost_days_and_the_forcing_that_rules_them_out(oracle):
+    """The snow routine decides a day of frost in every layer from the
+    record's high words (snow_core.h cema_day_io).  Temperatures of exactly
+    +0 and -0, layers that disagree about frost, and -- the forcing the
+    pre-pass takes that shortcut away for -- a positive subnormal temperature
+    and a solid fraction above one (negative rain): thermal state bit-exact,
+    pack and outflow within SNOW_TOL of the oracle, with and without a score
+    (the sweep that keeps nothing but scores takes other kernel forms)."""
+    import torch
+    from rrmpg_amd import device as rrdev
+    rng = np.random.default_rng(11)
+    T, L, n = 800, 5, 200
+    base = 6 * np.sin(2 * np.pi * np.arange(T) / 365.25) + rng.normal(0, 3, T)
+    temp = base[:, None] - np.linspace(0.3, 2.8, L)[None, :]
+    temp[40] = 0.0
+    temp[41] = -0.0
+    temp[42, :3] = 0.5           # warm below, frost above
+    temp[42, 3:] = -0.5
+    prec = np.repeat((rng.random(T) < 0.4) * rng.gamma(0.8, 6.0, T), L
+                     ).reshape(T, L)
+    frac = np.clip(0.5 - temp / 6.0, 0.0, 1.0)
+    flat = rng.random((n, 2)) * np.array([1., 10.])
+    cases = {"civil": (temp, frac)}
+    t2 = temp.copy()
+    t2[100, 2] = 5e-310
+    cases["subnormal temperature"] = (t2, frac)
+    f2 = frac.copy()
+    f2[prec[:, 0] > 0, 1] = 1.25
+    cases["negative rain"] = (temp, f2)
+    for what, (tt, ff) in cases.items():
+        ref = oracle.simulate_cemaneige(prec, tt, ff, (2.0, -0.5), flat,
+                                        return_storages=True)
+        ens = rrdev.CemaneigeEnsemble(prec, tt, ff, 2.0, -0.5)
+        par = ens.upload_params(flat)
+        out = ens.new_output(n)
+        G = ens.new_output(n, L)
+        eTG = ens.new_output(n, L)
+        ens.run(par, out, (G, eTG))
+        torch.cuda.synchronize()
+        got = (out.cpu().numpy(), G.cpu().numpy().reshape(T, L, n),
+               eTG.cpu().numpy().reshape(T, L, n))
+        for k, (a, b) in enumerate(zip(got, ref)):
+            snow_same(a, np.asarray(b).reshape(a.shape), exact=(k == 2),
+                      what=what)
+        qobs = torch.as_tensor(np.asarray(ref[0])[:, 0].copy(),
+                               device=ens.device)
+        sse = ens.run(par, None, None, qobs=qobs)
+        want = ((got[0] - got[0][:, :1]) ** 2).sum(0)
+        assert np.allclose(sse.cpu().numpy(), want, rtol=1e-9, atol=1e-18), what
+
+
 # --------------------------------------------------------- CemaneigeGR4J
 def test_cemaneigegr4j_kat_excel(models, fused_variant):
     g = golden("kat_cemaneigegr4j")
