@@ -169,6 +169,23 @@ __device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 template <int L>
 struct CemaGtRegs { double gt[L], rgt[L]; };
 
+// "No layer's temperature is above zero", read off the record's high words
+// (scalar integer maxima).  For the forcing of a SANE wave only: every finite
+// temperature but a positive subnormal one has `temp > 0` == `high word > 0`
+// (cemaneige.hip cema_pack counts those among what rules SANE out).
+template <int L>
+__device__ __forceinline__ bool cema_frost_everywhere(
+    const double *__restrict__ day)
+{
+    int warmest = __double2hiint(day[2 * L]);
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        const int h = __double2hiint(day[2 * L + l]);
+        warmest = h > warmest ? h : warmest;
+    }
+    return warmest <= 0;
+}
+
 template <int L>
 __device__ __forceinline__ void cema_gt_to_regs(cema_gt_ptr_t gt_tab,
                                                 CemaGtRegs<L> &g)
@@ -218,13 +235,7 @@ __device__ __forceinline__ double cema_day_io(
         // SANE, as it does a positive subnormal temperature -- for every other
         // finite one `temp > 0` is `high word > 0`).  One scalar question per
         // day, six vector instructions a layer instead of ten.
-        int warmest = __double2hiint(day[2 * L]);
-#pragma unroll
-        for (int l = 1; l < L; ++l) {
-            const int h = __double2hiint(day[2 * L + l]);
-            warmest = h > warmest ? h : warmest;
-        }
-        if (warmest <= 0) {
+        if (cema_frost_everywhere<L>(day)) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const double snow = day[l], rain = day[L + l],

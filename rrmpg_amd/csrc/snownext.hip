@@ -66,6 +66,9 @@
 #ifndef HYST_IDLE_DAYS
 #define HYST_IDLE_DAYS 1
 #endif
+#ifndef SNOW_ICE_FROST_DAYS
+#define SNOW_ICE_FROST_DAYS 1
+#endif
 template <int L, bool FIRST, bool SANE = false, bool REF = false>
 __device__ __forceinline__ double cema_hyst_day(
     const double *__restrict__ day, const double *__restrict__ psol,
@@ -278,6 +281,15 @@ snow_gr4j_kernel(
     double acc = 0.0;
     const bool we = sse != nullptr;
     constexpr int D = cema_record_len(L, true);
+    // (ice melt: every lane's factor in [+0, 1e300], every layer's glaciated
+    // fraction finite -- what the frost days' shortcut below asks for)
+    bool ice_tame = false;
+    if constexpr (ICE) {
+        ice_tame = (rr_exec() & ~(RR_LANES(ddf >= 0.0) &
+                                  RR_LANES(ddf <= 1e300))) == 0;
+        for (int l = 0; l < L; ++l)
+            ice_tame = ice_tame && fabs(frac_ice[l]) <= 1e300;
+    }
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
     auto one_day = [&](auto first, auto sane, int64_t t) {
@@ -302,14 +314,24 @@ snow_gr4j_kernel(
             // (icemelt_model.py:55-63), weighted by the glaciated fraction
             // and summed over the layers left to right
             // (cemaneigegr4jice_model.py:81-87)
+            // (under frost in every layer -- snow_core.h
+            // cema_frost_everywhere -- a factor in [+0, 1e300] melts +-0 of
+            // ice, the finite fractions' sum of it from +0 is +0, and the
+            // snow routine's outflow, the layers' rain, never -0, keeps its
+            // bits: the loop is skipped)
+            bool frost = false;
+            if constexpr (SNOW_ICE_FROST_DAYS && SANE && !FIRST)
+                frost = ice_tame && cema_frost_everywhere<L>(day);
+            if (!frost) {
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-                double melt = ddf * day[2 * L + l];
-                if (melt < 0) melt = 0.0;
-                const double lw = (G[l] > 1) ? 0.0 : melt;
-                ice_total += lw * frac_ice[l];
+                for (int l = 0; l < L; ++l) {
+                    double melt = ddf * day[2 * L + l];
+                    if (melt < 0) melt = 0.0;
+                    const double lw = (G[l] > 1) ? 0.0 : melt;
+                    ice_total += lw * frac_ice[l];
+                }
+                liquid = snowmelt + ice_total;
             }
-            liquid = snowmelt + ice_total;
         }
         const double q = gr4j_step<UH, ICE ? GR4J_CONSTS_JIT_EXP : GR4J_CONSTS_JIT>(
             P, s, r, uh, liquid, day[3 * L]);
