@@ -234,16 +234,18 @@ __device__ __forceinline__ double cema_day_io(
         // rain never -0: the pre-pass counts such forcing among what rules out
         // SANE, as it does a positive subnormal temperature -- for every other
         // finite one `temp > 0` is `high word > 0`).  One scalar question per
-        // day, six vector instructions a layer instead of ten.
+        // day, five vector instructions a layer instead of ten.
         if (cema_frost_everywhere<L>(day)) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const double snow = day[l], rain = day[L + l],
                              temp = day[2 * L + l];
-                double e = CTG * eTG_in[l] + one_minus_CTG * temp;
-                asm("v_min_f64 %0, %1, 0" : "=v"(e) : "v"(e));
+                // (no clamp: CTG and 1 - CTG in [0, 1], yesterday's state
+                // and the temperature not above zero -- neither is their
+                // weighted sum, and `if e > 0: e = 0` (:93-96) leaves a zero of
+                // either sign alone)
                 G[l] = G_in[l] + snow;
-                eTG[l] = e;
+                eTG[l] = CTG * eTG_in[l] + one_minus_CTG * temp;
                 c = (l == 0) ? rain : c + rain;
             }
             return cema_layer_mean<L>(c, votes);
