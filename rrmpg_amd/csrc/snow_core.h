@@ -177,12 +177,16 @@ template <int L>
 __device__ __forceinline__ bool cema_frost_everywhere(
     const double *__restrict__ day)
 {
+    // (s_max_i32 written out: from C++ hipcc forms the maximum on the vector
+    // unit -- three v_mov, two v_max3_i32 and a v_cmp a day, 80.1 -> 82.3
+    // instructions per set-day instead of fewer)
     int warmest = __double2hiint(day[2 * L]);
 #pragma unroll
-    for (int l = 1; l < L; ++l) {
-        const int h = __double2hiint(day[2 * L + l]);
-        warmest = h > warmest ? h : warmest;
-    }
+    for (int l = 1; l < L; ++l)
+        asm("s_max_i32 %0, %1, %2"
+            : "=s"(warmest)
+            : "s"(warmest), "s"(__double2hiint(day[2 * L + l]))
+            : "scc");
     return warmest <= 0;
 }
 
@@ -235,7 +239,17 @@ __device__ __forceinline__ double cema_day_io(
         // SANE, as it does a positive subnormal temperature -- for every other
         // finite one `temp > 0` is `high word > 0`).  One scalar question per
         // day, five vector instructions a layer instead of ten.
-        if (cema_frost_everywhere<L>(day)) {
+        // (the question spelled out HERE, not asked through
+        // cema_frost_everywhere: behind the call's bool hipcc lays the frost
+        // days' block out of line, allocates 20 VGPRs more and the sweep takes
+        // 28.3 ms instead of 22.8 -- 25.9 without the frost days;
+        // profiles/r05_hyst_days_ab.txt)
+        int warmest = __double2hiint(day[2 * L]);
+#pragma unroll
+        for (int l = 1; l < L; ++l)
+            asm("s_max_i32 %0, %1, %2" : "=s"(warmest)
+                : "s"(warmest), "s"(__double2hiint(day[2 * L + l])) : "scc");
+        if (warmest <= 0) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const double snow = day[l], rain = day[L + l],
@@ -244,8 +258,9 @@ __device__ __forceinline__ double cema_day_io(
                 // and the temperature not above zero -- neither is their
                 // weighted sum, and `if e > 0: e = 0` (:93-96) leaves a zero of
                 // either sign alone)
+                const double e = CTG * eTG_in[l] + one_minus_CTG * temp;
                 G[l] = G_in[l] + snow;
-                eTG[l] = CTG * eTG_in[l] + one_minus_CTG * temp;
+                eTG[l] = e;
                 c = (l == 0) ? rain : c + rain;
             }
             return cema_layer_mean<L>(c, votes);
