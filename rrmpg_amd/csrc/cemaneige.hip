@@ -315,6 +315,9 @@ typedef const double __attribute__((address_space(4))) *cema_rec_ptr_t;
 // TILED (register hydrograph tiers 3 and 5 only): the time axis in pieces,
 // one workgroup per ticket (common.h RrTiles: million-set sweeps); handed over:
 // the snow states, both stores, the hydrograph slots, the score sum.
+#ifndef COUPLED_FETCH_AT_TOP
+#define COUPLED_FETCH_AT_TOP 0
+#endif
 #ifndef COUPLED_TILED_MINWAVES
 #define COUPLED_TILED_MINWAVES 3
 #endif
@@ -405,11 +408,23 @@ cemaneigegr4j_kernel(
         }
     }
     double day[D];
+    // (COUPLED_FETCH_AT_TOP: the many-waves kernel requests the day's record at
+    // the top of its own day -- a measurement switch)
+    constexpr bool FETCH_AT_TOP = COUPLED_FETCH_AT_TOP && !SMALL;
+    if constexpr (!FETCH_AT_TOP) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) day[k] = drec[t_begin * D + k];
+        for (int k = 0; k < D; ++k) day[k] = drec[t_begin * D + k];
+    }
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
     auto one_day = [&](auto first, auto sane, int64_t t) {
+        if constexpr (FETCH_AT_TOP) {
+            cema_rec_ptr_t now =
+                drec + (int64_t)__builtin_amdgcn_readfirstlane((int)t) * D;
+            asm volatile("" : "+s"(now));
+#pragma unroll
+            for (int k = 0; k < D; ++k) day[k] = now[k];
+        }
         const double liquid =
             cema_day<L, decltype(first)::value, SMALL, decltype(sane)::value>(
                 day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
@@ -422,8 +437,11 @@ cemaneigegr4j_kernel(
 #pragma unroll
             for (int k = 0; k < D; ++k) day[k] = nx[k];
         };
-        const double q =
-            gr4j_step<UH, CONSTS>(P, s, r, uh, liquid, etp_t, fetch_next);
+        double q;
+        if constexpr (FETCH_AT_TOP)
+            q = gr4j_step<UH, CONSTS>(P, s, r, uh, liquid, etp_t);
+        else
+            q = gr4j_step<UH, CONSTS>(P, s, r, uh, liquid, etp_t, fetch_next);
         // (per-lane addresses here: row stores through a buffer descriptor,
         // as in cemaneige_kernel, cost this kernel 1.5-2.5 % -- four more
         // SGPRs it does not have)
