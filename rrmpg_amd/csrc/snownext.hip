@@ -66,6 +66,15 @@
 #ifndef HYST_IDLE_DAYS
 #define HYST_IDLE_DAYS 1
 #endif
+#ifndef HYST_SCALAR_WARM
+#define HYST_SCALAR_WARM 1
+#endif
+// (measured, off: 135.0 -> 140.0 ms -- these kernels wait, at two or three
+// waves per SIMD, for their dependent chains, not for issue slots, and the
+// masked move sits on the chain)
+#ifndef HYST_POT_BY_EXEC
+#define HYST_POT_BY_EXEC 0
+#endif
 #ifndef SNOW_ICE_FROST_DAYS
 #define SNOW_ICE_FROST_DAYS 1
 #endif
@@ -93,7 +102,29 @@ __device__ __forceinline__ double cema_hyst_day(
             asm("v_min_f64 %0, %1, 0" : "=v"(e) : "v"(e));
             e_[l] = e;
             const double pm = rr_hw_min(Kf * temp, g_[l]);
-            pot_[l] = (e == 0 && temp > 0) ? pm : 0.0;
+            // (`temp > 0` off the record's high word -- a SANE wave's
+            // temperatures are finite and not positive subnormals, snow_core.h
+            // cema_frost_everywhere --: a scalar compare instead of a vector
+            // one per layer and day)
+            const bool warm = HYST_SCALAR_WARM ? __double2hiint(temp) > 0
+                                               : temp > 0;
+#if HYST_POT_BY_EXEC
+            // (the lanes without melt get their +0 by ONE v_mov_b64 under an
+            // exec mask, where a 64-bit select is two v_cndmask_b32 --
+            // hbvedu.hip's snow routine does the same)
+            {
+                double pot = pm;
+                const lanemask_t melts = RR_LANES(e == 0 && warm);
+                lanemask_t saved;
+                asm("s_andn1_saveexec_b64 %1, %2\n\t"
+                    "v_mov_b64 %0, 0\n\t"
+                    "s_mov_b64 exec, %1"
+                    : "+v"(pot), "=&s"(saved) : "s"(melts) : "scc");
+                pot_[l] = pot;
+            }
+#else
+            pot_[l] = (e == 0 && warm) ? pm : 0.0;
+#endif
             busy |= RR_LANES(pot_[l] != 0.0);
         }
         if (snowfall == 0 && busy == 0) {
