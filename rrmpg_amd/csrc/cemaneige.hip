@@ -426,7 +426,8 @@ cemaneigegr4j_kernel(
             for (int k = 0; k < D; ++k) day[k] = now[k];
         }
         const double liquid =
-            cema_day<L, decltype(first)::value, SMALL, decltype(sane)::value>(
+            cema_day<L, decltype(first)::value, SMALL, decltype(sane)::value,
+                     true>(
                 day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
                 omc, Kf, G, eTG, &gt_regs);
         const double etp_t = day[3 * L], qobs_t = day[D - 1];
@@ -603,7 +604,8 @@ cemaneigegr4j_opt_kernel(
     auto one_day = [&](auto first, auto sane, const Gen &in, Gen &out,
                        int64_t t) __attribute__((always_inline)) {
         const double liquid =
-            cema_day<L, decltype(first)::value, SMALL, decltype(sane)::value>(
+            cema_day<L, decltype(first)::value, SMALL, decltype(sane)::value,
+                     true>(
                 day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
                 omc, Kf, G, eTG, &gt_regs);
         const double etp_t = day[3 * L], qobs_t = day[D - 1];

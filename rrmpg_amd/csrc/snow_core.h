@@ -166,6 +166,9 @@ __device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 #ifndef CEMA_FROST_DAYS
 #define CEMA_FROST_DAYS 1
 #endif
+#ifndef CEMA_SCALAR_WARM
+#define CEMA_SCALAR_WARM 1
+#endif
 template <int L>
 struct CemaGtRegs { double gt[L], rgt[L]; };
 
@@ -221,7 +224,7 @@ __device__ __forceinline__ void cema_gt_to_regs(cema_gt_ptr_t gt_tab,
 // loops, common.h OptimisticVotes), or the same arrays (a layer's state is
 // read before it is written).
 template <int L, bool FIRST, bool GT_REGS = false, bool SANE = false,
-          class V = CarefulVotes>
+          class V = CarefulVotes, bool COUPLED = false>
 __device__ __forceinline__ double cema_day_io(
     const double *__restrict__ day, cema_gt_ptr_t gt_tab, lanemask_t gt_ok,
     double snow_pack_init, double thermal_state_init, double CTG,
@@ -288,6 +291,14 @@ __device__ __forceinline__ double cema_day_io(
             if (e > 0) e = 0.0;
         }
         double pot_melt = 0.0;                             // :99-106
+        // (`temp > 0`: in a SANE wave the sign of the record's high word --
+        // cema_frost_everywhere --, one scalar compare where the vector unit
+        // would compare a uniform value in every lane)
+        // (COUPLED -- the kernels with a GR4J day behind the snow routine --
+        // only: they gain 1 % from it, 125k and 1M sets alike, the plain
+        // Cemaneige kernel loses 2 %; profiles/r05_hyst_days_ab.txt)
+        const bool warm = (CEMA_SCALAR_WARM && COUPLED && SANE && !FIRST)
+                              ? __double2hiint(temp) > 0 : temp > 0;
         if (SANE && !FIRST && GT_REGS && CEMA_GT_SELECT_FORM) {
             // (the small-sweep kernels evaluate it for every lane and select:
             // no exec-masked block, no branch over it -- at two waves per
@@ -295,8 +306,8 @@ __device__ __forceinline__ double cema_day_io(
             // 14.98 -> 14.68 ms; at a million sets the block wins, 92.2 vs
             // 92.8)
             const double pm = rr_hw_min(Kf * temp, g);
-            pot_melt = (e == 0 && temp > 0) ? pm : 0.0;
-        } else if (e == 0 && temp > 0) {
+            pot_melt = (e == 0 && warm) ? pm : 0.0;
+        } else if (e == 0 && warm) {
             pot_melt = Kf * temp;
             // (SANE: Kf is not NaN, so neither is the product, and numba's
             // `if pot_melt > G: pot_melt = G` is the hardware minimum)
@@ -401,14 +412,15 @@ __device__ __forceinline__ double cema_day_io(
     return cema_layer_mean<L>(c, votes);
 }
 
-template <int L, bool FIRST, bool GT_REGS = false, bool SANE = false>
+template <int L, bool FIRST, bool GT_REGS = false, bool SANE = false,
+          bool COUPLED = false>
 __device__ __forceinline__ double cema_day(
     const double *__restrict__ day, cema_gt_ptr_t gt_tab, lanemask_t gt_ok,
     double snow_pack_init, double thermal_state_init, double CTG,
     double one_minus_CTG, double Kf, double (&G)[L], double (&eTG)[L],
     const CemaGtRegs<L> *gt_regs = nullptr)
 {
-    return cema_day_io<L, FIRST, GT_REGS, SANE>(
+    return cema_day_io<L, FIRST, GT_REGS, SANE, CarefulVotes, COUPLED>(
         day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
         one_minus_CTG, Kf, G, eTG, G, eTG, gt_regs);
 }

@@ -335,7 +335,7 @@ snow_gr4j_kernel(
                 day, psol, snow_pack_init, thermal_state_init, sca_prev0, CTG,
                 omc, Kf, inv_Thacc, thacc_m, Rsp, G, eTG, sca, swe_max);
         else
-            snowmelt = cema_day<L, FIRST, false, SANE>(day, gt_tab, gt_ok, snow_pack_init,
+            snowmelt = cema_day<L, FIRST, false, SANE, true>(day, gt_tab, gt_ok, snow_pack_init,
                                           thermal_state_init, CTG, omc, Kf, G,
                                           eTG);
         double liquid = snowmelt;
