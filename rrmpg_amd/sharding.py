@@ -30,6 +30,75 @@ def shard_bounds(num_sets, world_size, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
+class ScoreExchange:
+    """An all-gather of per-set scores under way (allgather_scores_begin).
+    finish() makes the current stream wait for it -- the host does not -- and
+    returns the [num_sets] tensor; until then the object keeps the buffers
+    the collective reads and writes alive."""
+
+    def __init__(self, result=None, work=None, out=None, lens=None,
+                 keep=None):
+        self._result, self._work, self._out = result, work, out
+        self._lens, self._keep = lens, keep
+
+    def finish(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            out, lens = self._out, self._lens
+            if lens is None:
+                self._result = out
+            else:
+                longest = max(lens)
+                self._result = torch.cat(
+                    [out[r * longest:r * longest + lens[r]]
+                     for r in range(len(lens))])
+            self._out = self._keep = None
+        return self._result
+
+
+def allgather_scores_begin(local_scores, num_sets=None, group=None,
+                           always_collective=False):
+    """allgather_scores in two halves: the collective is ENQUEUED (on the
+    process group's own stream, behind what the current stream holds so far)
+    and the call returns a ScoreExchange; work enqueued on the current
+    stream before its finish() -- the next sweep's kernel -- runs beside the
+    exchange instead of behind it.  One process per GPU at eight GPUs: the
+    8 MB all-gather of a million scores then hides under the next shard's
+    2.4 ms instead of adding to every step."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return ScoreExchange(result=local_scores)
+    world = dist.get_world_size(group)
+    if world == 1 and not always_collective:
+        return ScoreExchange(result=local_scores)
+    rank = dist.get_rank(group)
+    if num_sets is None:
+        n = torch.tensor([local_scores.numel()], device=local_scores.device)
+        dist.all_reduce(n, group=group)
+        num_sets = int(n.item())
+    lens = [shard_bounds(num_sets, world, r) for r in range(world)]
+    lens = [b - a for a, b in lens]
+    if lens[rank] != local_scores.numel():
+        raise ValueError("rank %d holds %d scores, expected %d"
+                         % (rank, local_scores.numel(), lens[rank]))
+    longest = max(lens)
+    if min(lens) == longest:
+        src = local_scores.contiguous()
+        out = torch.empty(num_sets, dtype=src.dtype, device=src.device)
+        work = dist.all_gather_into_tensor(out, src, group=group,
+                                           async_op=True)
+        return ScoreExchange(work=work, out=out, keep=src)
+    # ragged: pad every block to the longest, gather, drop the padding
+    padded = torch.zeros(longest, dtype=local_scores.dtype,
+                         device=local_scores.device)
+    padded[:local_scores.numel()] = local_scores
+    out = torch.empty(world * longest, dtype=local_scores.dtype,
+                      device=local_scores.device)
+    work = dist.all_gather_into_tensor(out, padded, group=group,
+                                       async_op=True)
+    return ScoreExchange(work=work, out=out, lens=lens, keep=padded)
+
+
 def allgather_scores(local_scores, num_sets=None, group=None,
                      always_collective=False):
     """All-gather the per-set scores of every rank's block, in set order.
@@ -228,6 +297,16 @@ class ResidentSweep:
         local = self.local_scores().reshape(-1)
         return allgather_scores(local.cpu() if self.on_host else local,
                                 self.total_units, group=self.group)
+
+    def gather_begin(self):
+        """gather() in two halves (allgather_scores_begin): returns a
+        ScoreExchange; a gloo group's host tensors are exchanged at once."""
+        local = self.local_scores().reshape(-1)
+        if self.on_host:
+            return ScoreExchange(result=allgather_scores(
+                local.cpu(), self.total_units, group=self.group))
+        return allgather_scores_begin(local, self.total_units,
+                                      group=self.group)
 
     def step(self):
         self.launch()

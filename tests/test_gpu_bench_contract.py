@@ -216,6 +216,16 @@ def test_rccl_collectives_on_one_rank(tmp_path):
         "torch.cuda.synchronize()\n"
         "assert torch.equal(x, y) and y.data_ptr() != x.data_ptr()\n"
         "assert t.tolist() == [3.0, 1.0]\n"
+        "# the exchange in two halves (the bench's pipelined steps): two\n"
+        "# under way, kernels enqueued in between, finished in order\n"
+        "from rrmpg_amd.sharding import allgather_scores_begin\n"
+        "h1 = allgather_scores_begin(x, 1001, always_collective=True)\n"
+        "z = (x * 3).sum()\n"
+        "h2 = allgather_scores_begin(x * 2, 1001, always_collective=True)\n"
+        "y1 = h1.finish(); w = (y1 - x).abs().sum(); y2 = h2.finish()\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(y1, x) and torch.equal(y2, x * 2)\n"
+        "assert float(w) == 0.0 and float(z) == float((x * 3).sum())\n"
         "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n"
         % REPO)
     out = subprocess.run([sys.executable, str(script)], capture_output=True,

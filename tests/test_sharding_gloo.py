@@ -53,6 +53,14 @@ def _worker(rank, world, port, num_sets, out_dir):
         full2 = allgather_scores(local)          # num_sets inferred
         np.save(os.path.join(out_dir, "r%d.npy" % rank), full.numpy())
         assert torch.equal(full, full2)
+        # the same exchange in two halves, two of them under way at once (the
+        # bench's pipelined steps): finished in the order they were begun
+        from rrmpg_amd.sharding import allgather_scores_begin
+        h1 = allgather_scores_begin(local, num_sets)
+        h2 = allgather_scores_begin(local * 2, num_sets)
+        assert torch.equal(h1.finish(), full)
+        assert torch.equal(h2.finish(), full * 2)
+        assert h1.finish() is h1.finish()
     finally:
         dist.destroy_process_group()
 
