@@ -88,9 +88,11 @@ int fail(const Rccl *r, const char *what, ncclResult_t rc)
 const Rccl *need_rccl(const char *who)
 {
     const Rccl *r = rccl();
-    if (!r)
+    if (!r) {
+        const char *why = dlerror();      // (a second call would return NULL)
         rr_set_error("%s: librccl.so.1 could not be opened (or lacks an entry "
-                     "point): %s", who, dlerror() ? dlerror() : "-");
+                     "point): %s", who, why ? why : "-");
+    }
     return r;
 }
 }  // namespace
