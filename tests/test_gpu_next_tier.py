@@ -345,6 +345,62 @@ def test_next_tier_resident_ensembles_match_host_path(models):
         assert np.array_equal(sse.cpu().numpy(), sse_h)
 
 
+def test_next_tier_days_decided_from_the_record(models, oracle):
+    """The days the kernels decide for the whole wave from the day's record
+    (snow_core.h cema_day_io: frost in every layer; snownext.hip: the
+    hysteresis routine's idle days, the ice-melt loop skipped under frost):
+    long frosts, dry spells, temperatures of exactly +0 and -0, layers that
+    disagree -- and a wave that must NOT take the ice-melt shortcut, because
+    one of its sets has a negative degree-day factor and melts ice in the
+    frost.  Discharge against the oracle at 1e-10."""
+    import torch
+    from rrmpg_amd import device as rrdev
+    rng = np.random.default_rng(5)
+    T, L, n = 700, 5, 96
+    base = 5 * np.sin(2 * np.pi * np.arange(T) / 180.0) + rng.normal(0, 2, T)
+    temp = base[:, None] - np.linspace(0.2, 2.5, L)[None, :]
+    temp[100:140] -= 12.0                        # a long frost
+    temp[50] = 0.0
+    temp[51] = -0.0
+    temp[52, :2] = 0.4
+    temp[52, 2:] = -0.4
+    wet = rng.random(T) < 0.35
+    wet[110:130] = False                         # ... and dry inside it
+    prec = np.repeat(wet * rng.gamma(0.8, 6.0, T), L).reshape(T, L)
+    frac = np.clip(0.5 - temp / 5.0, 0.0, 1.0)
+    etp = np.clip(1.5 + 0.1 * base, 0, None)
+    fice = np.array([0.0, 0.1, 0.3, 0.6, 0.9])
+    inits = (2.0, -0.3, 0.4, 0.5, 0.6)
+    for (hyst, ice), cls in [((True, False), models.CemaneigeHystGR4J),
+                             ((False, True), models.CemaneigeGR4JIce),
+                             ((True, True), models.CemaneigeHystGR4JIce)]:
+        np.random.seed(33)
+        p = cls().get_random_params(n)
+        if ice:
+            p["DDF"][70] = -0.5              # second wave: no shortcut
+        flat = np.stack([p[k] for k in cls._param_list], axis=1)
+        ref = oracle.simulate_snow_gr4j(hyst, ice, prec, temp, etp, frac,
+                                        inits, flat,
+                                        frac_ice=fice if ice else None)
+        ens = rrdev.SnowGR4JEnsemble(
+            hyst, ice, prec, temp, frac, etp,
+            frac_ice=fice if ice else None, snow_pack_init=inits[0],
+            thermal_state_init=inits[1], sca_init=inits[2], s_init=inits[3],
+            r_init=inits[4])
+        par = ens.upload_params(p)
+        q = ens.new_output(n)
+        ens.run(par, q)
+        torch.cuda.synchronize()
+        got = q.cpu().numpy()
+        assert rel_err(got, ref, floor=1e-6) < RTOL, (hyst, ice)
+        if ice:      # the set that melts ice in the frost is not a zero
+            assert np.abs(got[100:140, 70] - got[100:140, 69]).max() > 0
+        qobs = torch.from_numpy(np.ascontiguousarray(ref[:, 5])).cuda()
+        sse = ens.run(par, None, qobs=qobs).cpu().numpy()
+        want = ((ref - ref[:, 5:6]) ** 2).sum(0)
+        assert np.allclose(sse, want, rtol=1e-8, atol=1e-12), (hyst, ice)
+
+
 def test_score_only_sweeps_sorted_by_tier_keep_every_sets_bits(models):
     """A score-only sweep of four or more waves per SIMD takes its sets in
     the order of their ceil(x4) (csrc/gr4j.hip rr_gr4j_tier_sort_async) and
