@@ -246,9 +246,19 @@ struct SnowParLayout {
 // configurations (<= 5 layers, unit hydrographs in 3+7 registers or in LDS)
 // are held at 3 (hysteresis: four states per layer) or 4 waves; a handful of
 // spills cost less than the lost wave.
+// (the hysteresis couplings' 5-slot tier held to three waves per SIMD: 180 ->
+// 168 VGPRs and a few spills, 135.4 -> 133.3 ms, hysteresis + ice 155.4 ->
+// 152.9 -- these kernels wait for their chains, a third wave hides more of
+// them than the spills cost)
+#ifndef SNOW_TIER5_WAVES
+#define SNOW_TIER5_WAVES 3
+#endif
 template <int L, class UH, bool HYST>
 constexpr int snow_min_waves()
 {
+    if (SNOW_TIER5_WAVES > 2 && HYST && L <= 5 &&
+        std::is_same<UH, UhRegs<5>>::value)
+        return SNOW_TIER5_WAVES;
     return (L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
                        uh_is_indexed<UH>)) ? (HYST ? 3 : 4) : 2;
 }
