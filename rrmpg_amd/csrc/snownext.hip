@@ -249,7 +249,8 @@ struct SnowParLayout {
 // (the hysteresis couplings' 5-slot tier held to three waves per SIMD: 180 ->
 // 168 VGPRs and a few spills, 135.4 -> 133.3 ms, hysteresis + ice 155.4 ->
 // 152.9 -- these kernels wait for their chains, a third wave hides more of
-// them than the spills cost)
+// them than the spills cost; the 3-slot tier at four waves 144.6 ms, the
+// 10-slot tier at three 412.8)
 #ifndef SNOW_TIER5_WAVES
 #define SNOW_TIER5_WAVES 3
 #endif
