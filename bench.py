@@ -688,6 +688,23 @@ class SocketSampler:
                 "source": "hwmon power1_input / freq1_input of this GPU"}
 
 
+# what a SIMD with four or more waves needs per fp64 vector instruction
+# (profiles/ubench/valu_cost.hip): 4 is the hardware's rate,
+# 4.3 what a stream of dependent-free fp64 instructions is measured at
+VALU_CYCLES_MEASURED = 4.3
+
+
+def valu_at_clock(floor_ms_at_clock, kernel_ms):
+    """The fp64 issue roof at the clock the chip sustained under the sweep:
+    at the hardware's 4 cycles per instruction and at the measured 4.3."""
+    issue_ms = floor_ms_at_clock * VALU_CYCLES_MEASURED / VALU_CYCLES_PER_INSTR
+    return {"floor_ms_at_measured_clock": floor_ms_at_clock,
+            "frac_at_measured_clock": floor_ms_at_clock / kernel_ms,
+            "cycles_per_instr_measured": VALU_CYCLES_MEASURED,
+            "issue_ms_at_measured_clock": issue_ms,
+            "issue_frac_at_measured_clock": issue_ms / kernel_ms}
+
+
 def power_soak(sweep, per_step_s, device, world, seconds=2.5):
     """Socket power and shader clock of the sweep in steady state: the same
     step repeated for `seconds` AFTER the timed region (the sensor is an
@@ -888,12 +905,23 @@ def extra_configs(args, device):
             traffic, valu = traffic_record(a, r["n"], r["t"])
             if traffic:
                 rec["traffic"] = traffic
+            # clock and socket power under THIS sweep (a 1.2-s soak): the
+            # issue roof below is taken at that clock as well
+            pw = (None if args.no_power_soak else
+                  power_soak(r["sweep"], r["kernel_ms"] * 1e-3, device, 1,
+                             seconds=1.2))
+            if pw:
+                rec["power"] = {k: pw[k] for k in
+                                ("socket_w", "sclk_mhz", "cap_w")}
             if valu:
                 floor_ms = (valu / 64.0 * r["n"] * r["t"]
                             * VALU_CYCLES_PER_INSTR / SIMDS
                             / (CLOCK_GHZ_NOMINAL * 1e9) * 1e3)
                 rec["valu"] = {"instr_per_unit": valu, "floor_ms": floor_ms,
                                "frac": floor_ms / r["kernel_ms"]}
+                if pw and pw.get("sclk_mhz"):
+                    f_ms = floor_ms * CLOCK_GHZ_NOMINAL * 1e3 / pw["sclk_mhz"]
+                    rec["valu"].update(valu_at_clock(f_ms, r["kernel_ms"]))
             if not args.no_cpu_baseline:
                 # the oracle on the host cores for THIS model (a short
                 # sample); the HBV-Edu configurations share the headline's
@@ -1017,8 +1045,7 @@ def main():
                 # sweep (the soak's mean shader clock): what is left in the
                 # kernel once the socket's power cap has been paid
                 f_ms = floor_ms * CLOCK_GHZ_NOMINAL * 1e3 / pw["sclk_mhz"]
-                roof["valu"]["floor_ms_at_measured_clock"] = f_ms
-                roof["valu"]["frac_at_measured_clock"] = f_ms / kernel_ms
+                roof["valu"].update(valu_at_clock(f_ms, kernel_ms))
         pw = r["power"] or {}
         if pw.get("socket_w") and pw.get("cap_w"):
             # `bound` stays what the contract asks for (the HBM roof the

@@ -92,6 +92,10 @@ def test_default_line_carries_every_config_and_the_valu_roof():
         if r["power"] and r["power"]["sclk_mhz"]:
             # the same floor at the clock the chip sustains under the sweep
             assert v["frac"] <= v["frac_at_measured_clock"] < 1.05
+            # ... and at the 4.3 cycles an fp64 instruction is measured at
+            assert v["cycles_per_instr_measured"] == 4.3
+            assert (v["frac_at_measured_clock"]
+                    < v["issue_frac_at_measured_clock"] < 1.1)
             assert r["binding_roof"] in ("socket power", "hbm", "fp64 issue")
     assert 0.3 < r["frac"] < 1.0
     # socket power / shader clock of the same sweep in steady state, read
@@ -108,6 +112,10 @@ def test_default_line_carries_every_config_and_the_valu_roof():
         # carries its parity spot against the oracle
         assert 0 <= e["parity_spot"] < 1e-10, e
         assert e["steps"] >= 2
+        # its own clock and socket power, and with them its issue roof
+        if e.get("power") and e["power"]["sclk_mhz"] and "valu" in e:
+            assert 500 < e["power"]["sclk_mhz"] < 3000
+            assert 0.0 < e["valu"]["issue_frac_at_measured_clock"] < 1.1, e
         if e["bytes_per_unit"]:
             assert 0 < e["frac"] < 1
     by = {e["workload"].split(",")[0]: e for e in ex}
