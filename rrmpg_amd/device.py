@@ -60,6 +60,22 @@ class _Ensemble:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def replica(self, device=None):
+        """A second ensemble over the same forcing with a workspace of its
+        own, so that both can have sweeps in flight: on this GPU (the forcing
+        tensors are shared, nothing is copied) or, with `device`, on another
+        GPU (the forcing -- 1.4 MB at most -- is copied there once).  What
+        the shards of ``monte_carlo(sampler='device', gpus=G)`` run on."""
+        import copy
+        new = copy.copy(self)
+        new._ws = None
+        if device is not None and torch.device(device) != self.device:
+            new.device = torch.device(device)
+            for key, val in vars(self).items():
+                if isinstance(val, torch.Tensor):
+                    setattr(new, key, val.to(new.device))
+        return new
+
     def upload_params(self, params):
         """Structured numpy parameter array (or [N, k] float array) -> device
         block double[N][k]."""

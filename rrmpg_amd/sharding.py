@@ -183,8 +183,14 @@ def _rank_world(group=None):
     return 0, 1
 
 
+def _group_on_device(group=None):
+    """True if the group's collectives take device tensors only (backend
+    nccl = RCCL): host scores must move to this rank's GPU first."""
+    return "nccl" in str(dist.get_backend(group)).lower()
+
+
 def sweep(model, params, qobs, score="mse", gpus=None, return_qsim=False,
-          group=None, **forcing):
+          group=None, always_collective=False, **forcing):
     """One Monte-Carlo sweep of `model` over ALL rows of `params`, over
     several GPUs, scored per set -- the library call behind
     ``monte_carlo(..., gpus=...)`` and behind a torchrun job.
@@ -194,8 +200,11 @@ def sweep(model, params, qobs, score="mse", gpus=None, return_qsim=False,
       or ``torch.cuda.set_device``): every rank passes the SAME `params`; rank
       r simulates the contiguous block ``shard_bounds(len(params), world, r)``
       and the per-set scores are exchanged with the job's one collective, the
-      all-gather of 8 B per set (gloo on the host here: the scores leave the
-      GPU with the call).  `gpus` is ignored.
+      all-gather of 8 B per set.  The host-pointer call brings the scores to
+      the host; a gloo group exchanges them there, an nccl-only group gets
+      them back on this rank's GPU for the exchange over RCCL.  `gpus` is
+      ignored.  (always_collective: run the collective for a group of one
+      rank as well -- tests on a one-GPU box.)
     * Without a process group: the host-pointer call itself fans the
       parameter-set axis out over `gpus` devices (an int, or 'all'; None: the
       current device), one host thread per device inside librrhip
@@ -211,13 +220,18 @@ def sweep(model, params, qobs, score="mse", gpus=None, return_qsim=False,
         raise ValueError("score must be one of %s" % (SCORES,))
     n = len(params)
     rank, world = _rank_world(group)
-    if world > 1:
+    in_group = dist.is_available() and dist.is_initialized()
+    if world > 1 or (always_collective and in_group):
         first, stop = shard_bounds(n, world, rank)
         qsim, sse = model._sweep(params[first:stop], qobs, bool(return_qsim),
                                  **forcing)
         local = torch.from_numpy(np.ascontiguousarray(
             scores_from_sse(sse, qobs, score)))
-        scores = allgather_scores(local, n, group=group).numpy()
+        if _group_on_device(group):
+            local = local.to(torch.device("cuda", torch.cuda.current_device()))
+        scores = allgather_scores(
+            local, n, group=group,
+            always_collective=always_collective).cpu().numpy()
     else:
         first, stop = 0, n
         with _lib.call_options(host_shards=_lib.host_shards_of(gpus)):

@@ -23,15 +23,29 @@ class DeviceParams:
     they were drawn in HBM and stay there until somebody looks --
     ``np.asarray(p)``, ``p[i]``, ``p['x1']``, ``len(p)`` and ``p.dtype`` work
     as on the structured array ``get_random_params`` returns, the first
-    access downloading the block once; ``p.tensor`` is the [num, k] device
-    tensor itself."""
+    access downloading the block once.  ``p.shards`` are the [n_j, k] device
+    tensors in set order (one per shard of a ``gpus=G`` sweep, each on its
+    shard's GPU; one tensor otherwise); ``p.tensor`` is the whole [num, k]
+    block on the first shard's GPU (of a sharded sweep: gathered there on
+    first access)."""
 
-    def __init__(self, model, tensor):
-        self._model, self.tensor, self._host = model, tensor, None
+    def __init__(self, model, shards):
+        if not isinstance(shards, (list, tuple)):
+            shards = [shards]
+        self._model, self.shards, self._host = model, list(shards), None
+        self._tensor = self.shards[0] if len(self.shards) == 1 else None
+
+    @property
+    def tensor(self):
+        if self._tensor is None:
+            import torch
+            dev = self.shards[0].device
+            self._tensor = torch.cat([s.to(dev) for s in self.shards])
+        return self._tensor
 
     def numpy(self):
         if self._host is None:
-            flat = self.tensor.cpu().numpy()
+            flat = np.concatenate([s.cpu().numpy() for s in self.shards])
             rec = np.zeros(flat.shape[0], dtype=self._model._dtype)
             for j, name in enumerate(self._model._param_list):
                 rec[name] = flat[:, j]
@@ -46,7 +60,7 @@ class DeviceParams:
         return self.numpy()[key]
 
     def __len__(self):
-        return int(self.tensor.shape[0])
+        return sum(int(s.shape[0]) for s in self.shards)
 
     @property
     def dtype(self):
@@ -57,32 +71,146 @@ class DeviceParams:
         return (len(self),)
 
 
-def _monte_carlo_resident(model, num, qobs, score, seed, kwargs):
+def _shard_devices(gpus):
+    """The HIP device of every shard of a ``gpus=`` argument: shard j runs on
+    device (current + j) % device_count, the rule of the host-pointer
+    family's fan-out (csrc/api.hip host_fan_out) -- more shards than devices
+    is allowed, they then share a GPU on streams of their own."""
+    import torch
+    shards = _lib.host_shards_of(gpus)
+    if shards is None:
+        return None
+    ndev = max(1, _lib.device_count())
+    cur = torch.cuda.current_device()
+    count = ndev if shards < 0 else shards
+    return [(cur + j) % ndev for j in range(count)]
+
+
+def _resident_scores(sse, qobs, score):
+    result = {'mse': mse_from_sse(sse, len(qobs))}
+    if score == "nse":
+        result['nse'] = nse_from_sse(sse, qobs)
+    return result
+
+
+def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs):
     """sampler='device': sets drawn in HBM (numpy's Philox stream under
     `seed`, rrmpg_amd.device.sample_params), swept against the resident
-    forcing, only the scores come back."""
+    forcing, only the scores come back.
+
+    The population is ONE counter-based stream of `num` rows whatever the
+    number of GPUs: a shard draws rows [first, stop) of it
+    (rr_sample_params_dev(first, n_total)), so the scores of a sharded sweep
+    equal the single-GPU sweep's bit for bit.
+
+    * ``gpus=G`` / ``'all'``: one host thread per shard, shard j on device
+      (current + j) % device_count with a stream of its own; it draws its
+      rows, sweeps them score-only against that device's replica of the
+      forcing and sends its 8 B per set straight into its slice of ONE
+      pinned host vector -- G copies of num/G x 8 B over G PCIe links beside
+      each other, no GPU-to-GPU step: the scores' destination is the host
+      (the all-gather of rrmpg_amd.sharding / rr_allgather_metric is for
+      jobs whose ranks each need all scores in HBM).
+    * inside an initialised ``torch.distributed`` group of several ranks (one
+      process per GPU under torchrun): this rank draws and sweeps its block
+      of rrmpg_amd.sharding.shard_bounds and the one collective of the job,
+      the all-gather of the per-set sums, gives every rank all of them (RCCL
+      for an nccl group, gloo on the host otherwise); 'params' holds this
+      rank's block."""
+    import threading
     import torch
+    import torch.distributed as dist
     from .. import device as rrdev
+    from .. import sharding
     if not hasattr(model, "_resident"):
         raise ValueError("sampler='device' is not available for %s"
                          % type(model).__name__)
+    devices = _shard_devices(gpus)
     ens = model._resident(**kwargs)
     if seed is None:
         # no key given: one draw from numpy's global generator, so that
         # np.random.seed(s) in front of the call still fixes the sweep
         seed = int(np.random.randint(0, 2 ** 31 - 1))
-    params = rrdev.sample_params(model, num, int(seed), device=ens.device)
-    q = torch.as_tensor(qobs, dtype=torch.float64, device=ens.device)
-    if q.numel() != ens.num_timesteps:
+    seed = int(seed)
+    if len(qobs) != ens.num_timesteps:
         raise ValueError("Arrays must have the same size.")
-    sse = ens.run(params, None, qobs=q)
-    if hasattr(ens, "check"):
-        ens.check()
-    sse = sse.cpu().numpy()
-    result = {'params': DeviceParams(model, params),
-              'mse': mse_from_sse(sse, len(qobs))}
-    if score == "nse":
-        result['nse'] = nse_from_sse(sse, qobs)
+
+    world = (dist.get_world_size() if dist.is_available()
+             and dist.is_initialized() else 1)
+    if world > 1:
+        first, stop = sharding.shard_bounds(num, world, dist.get_rank())
+        params = rrdev.sample_params(model, stop - first, seed, n_total=num,
+                                     first=first, device=ens.device)
+        q = torch.as_tensor(qobs, dtype=torch.float64, device=ens.device)
+        sse = ens.run(params, None, qobs=q)
+        if hasattr(ens, "check"):
+            ens.check()
+        on_host = dist.get_backend() != "nccl"
+        sse = sharding.allgather_scores(sse.cpu() if on_host else sse, num)
+        result = _resident_scores(sse.cpu().numpy(), qobs, score)
+        result['params'] = DeviceParams(model, params)
+        result['bounds'] = (first, stop)
+        return result
+
+    if devices is None or len(devices) == 1 or num == 1:
+        params = rrdev.sample_params(model, num, seed, device=ens.device)
+        q = torch.as_tensor(qobs, dtype=torch.float64, device=ens.device)
+        sse = ens.run(params, None, qobs=q)
+        if hasattr(ens, "check"):
+            ens.check()
+        result = _resident_scores(sse.cpu().numpy(), qobs, score)
+        result['params'] = DeviceParams(model, params)
+        return result
+
+    devices = devices[:num]
+    count = len(devices)
+    host = torch.empty(num, dtype=torch.float64).pin_memory()
+    blocks, errors = [None] * count, [None] * count
+    # one replica of the forcing per GPU, made here (the copies are ordered
+    # behind the upload on this thread's stream); shards sharing a GPU share
+    # its forcing tensors and differ in workspace and stream only
+    replicas = {}
+    for d in devices:
+        if d not in replicas:
+            dev = torch.device("cuda", d)
+            replicas[d] = ens if dev == ens.device else ens.replica(dev)
+    for d in replicas:
+        torch.cuda.synchronize(d)
+
+    def shard(j):
+        try:
+            dev = torch.device("cuda", devices[j])
+            first, stop = sharding.shard_bounds(num, count, j)
+            with torch.cuda.device(dev):
+                mine = replicas[devices[j]].replica()
+                stream = torch.cuda.Stream(dev)
+                with torch.cuda.stream(stream):
+                    params = rrdev.sample_params(model, stop - first, seed,
+                                                 n_total=num, first=first,
+                                                 device=dev)
+                    q = torch.as_tensor(qobs, dtype=torch.float64).to(
+                        dev, non_blocking=True)
+                    sse = mine.run(params, None, qobs=q)
+                    host[first:stop].copy_(sse, non_blocking=True)
+                    if hasattr(mine, "check"):
+                        mine.check()
+                stream.synchronize()
+            blocks[j] = params
+        except BaseException as exc:         # re-raised on the calling thread
+            errors[j] = exc
+
+    threads = [threading.Thread(target=shard, args=(j,))
+               for j in range(1, count)]
+    for t in threads:
+        t.start()
+    shard(0)
+    for t in threads:
+        t.join()
+    for exc in errors:
+        if exc is not None:
+            raise exc
+    result = _resident_scores(host.numpy().copy(), qobs, score)
+    result['params'] = DeviceParams(model, blocks)
     return result
 
 
@@ -116,7 +244,15 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
             unless looked at -- 'params' is then a DeviceParams; needs qobs
             and return_qsim=False.  The mode for million-set sweeps: at
             100,000 HBV-Edu sets drawing and uploading the sets on the host
-            is three quarters of the call.
+            is three quarters of the call.  With ``gpus=G`` every GPU draws
+            and sweeps its contiguous block of the ONE population `seed`
+            names and only 8 B per set leave it: the scores equal the
+            single-GPU call's bit for bit (BASELINE configs[3] as one call:
+            ``monte_carlo(CemaneigeGR4J(), 1_000_000, qobs,
+            return_qsim=False, score='nse', sampler='device', gpus=8)``).
+            Called on every rank of a torchrun job (an initialised
+            ``torch.distributed`` group), each rank sweeps its block and the
+            scores are all-gathered (RCCL for an nccl group).
         seed: (optional) the key of sampler='device'.
         **kwargs: Keyword arguments matching the inputs the model needs to
             perform a simulation; see help(model.simulate).
@@ -147,10 +283,11 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
     if sampler not in ("numpy", "device"):
         raise ValueError("sampler must be 'numpy' or 'device'")
     if sampler == "device":
-        if qobs is None or return_qsim or gpus is not None:
+        if qobs is None or return_qsim:
             raise ValueError("sampler='device' scores resident sets: it "
-                             "needs qobs, return_qsim=False and gpus=None")
-        return _monte_carlo_resident(model, num, qobs, score, seed, kwargs)
+                             "needs qobs and return_qsim=False")
+        return _monte_carlo_resident(model, num, qobs, score, seed, gpus,
+                                     kwargs)
     params = model.get_random_params(num=num)
     sweep = model._sweep
     accepted = inspect.signature(sweep).parameters

@@ -242,6 +242,95 @@ def test_rccl_collectives_on_one_rank(tmp_path):
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_sharding_sweep_and_monte_carlo_under_an_nccl_only_group(tmp_path):
+    """A torchrun job initialised with backend "nccl" alone: sharding.sweep
+    gets its host scores back onto the GPU for the exchange (round 5 handed
+    RCCL a CPU tensor there), and monte_carlo(sampler='device') called inside
+    the group draws, sweeps and all-gathers over RCCL -- with the one rank a
+    single-GPU box can host (always_collective runs the collective anyway)."""
+    script = tmp_path / "nccl_sweep.py"
+    script.write_text(
+        "import os, sys, numpy as np, torch\n"
+        "import torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from rrmpg_amd import models, sharding\n"
+        "from rrmpg_amd.tools import monte_carlo\n"
+        "from rrmpg_amd.utils import synthetic as syn\n"
+        "f = syn.make_forcing(900)\n"
+        "kw = dict(prec=f['prec'], etp=f['etp'], s_init=0.6, r_init=0.7)\n"
+        "m = models.GR4J()\n"
+        "np.random.seed(4); p = m.get_random_params(777)\n"
+        "qobs = m.simulate(params=p[:2], **kw)[:, 1] * 0.9\n"
+        "want = sharding.sweep(m, p, qobs, score='nse', **kw)['scores']\n"
+        "ref = monte_carlo(m, 777, qobs=qobs, return_qsim=False,\n"
+        "                  sampler='device', seed=9, **kw)\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29613',\n"
+        "                  RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "got = sharding.sweep(m, p, qobs, score='nse', always_collective=True,"
+        " **kw)\n"
+        "assert got['bounds'] == (0, 777)\n"
+        "assert np.array_equal(got['scores'], want)\n"
+        "mc = monte_carlo(m, 777, qobs=qobs, return_qsim=False,\n"
+        "                 sampler='device', seed=9, **kw)\n"
+        "assert np.array_equal(mc['mse'], ref['mse'])\n"
+        "dist.barrier(); dist.destroy_process_group(); print('nccl sweep ok')\n"
+        % REPO)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True,
+                         text=True, timeout=300,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "nccl sweep ok" in out.stdout, \
+        (out.stdout + out.stderr)[-2000:]
+
+
+def test_monte_carlo_device_sampler_inside_a_two_rank_group(tmp_path):
+    """monte_carlo(sampler='device') called on every rank of a job (two
+    ranks sharing this GPU, gloo): each draws and sweeps its block of the one
+    population, the per-set sums are all-gathered, every rank returns the
+    scores of the single-process call; 'params' is the rank's block."""
+    script = tmp_path / "mc_ranks.py"
+    script.write_text(
+        "import os, sys, numpy as np, torch\n"
+        "import torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from rrmpg_amd import models\n"
+        "from rrmpg_amd.tools import monte_carlo\n"
+        "from rrmpg_amd.utils import synthetic as syn\n"
+        "rank = int(sys.argv[1])\n"
+        "f = syn.make_forcing(700)\n"
+        "kw = dict(temp=f['temp'], prec=f['prec'], month=f['month'],\n"
+        "          PE_m=f['PE_m'], T_m=f['T_m'], **syn.HBV_INITS)\n"
+        "m = models.HBVEdu()\n"
+        "qobs = f['prec'] * 0.4 + 0.1\n"
+        "call = dict(qobs=qobs, return_qsim=False, sampler='device', seed=11,\n"
+        "            score='nse')\n"
+        "ref = monte_carlo(m, 1001, **call, **kw)\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2],\n"
+        "                  RANK=str(rank), WORLD_SIZE='2')\n"
+        "dist.init_process_group('gloo')\n"
+        "got = monte_carlo(m, 1001, **call, **kw)\n"
+        "a, b = got['bounds']\n"
+        "assert (a, b) == ((0, 501) if rank == 0 else (501, 1001))\n"
+        "assert np.array_equal(got['mse'], ref['mse'])\n"
+        "assert np.array_equal(got['nse'], ref['nse'])\n"
+        "assert np.array_equal(np.asarray(got['params']),\n"
+        "                      np.asarray(ref['params'])[a:b])\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "print('rank', rank, 'ok')\n" % REPO)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok" % r in o, o[-2000:]
+
+
 def test_c_abi_allgather_over_rccl_on_one_rank(tmp_path):
     """The collective of the C-ABI itself (include/rrhip.h rr_comm_* /
     rr_allgather_metric: RCCL opened at first use, one group of broadcasts,

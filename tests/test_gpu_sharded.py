@@ -184,11 +184,75 @@ def test_monte_carlo_device_sampler(env):
     b = monte_carlo(model, 500, qobs=qobs, return_qsim=False,
                     sampler="device", **kw)
     assert np.array_equal(a["mse"], b["mse"])
-    for bad in (dict(return_qsim=True), dict(gpus=2, return_qsim=False)):
+    for bad in (dict(return_qsim=True), dict(gpus=0, return_qsim=False)):
         with pytest.raises(ValueError):
             monte_carlo(model, 10, qobs=qobs, sampler="device", **bad, **kw)
     with pytest.raises(ValueError):
         monte_carlo(model, 10, qobs=qobs, sampler="gpu", **kw)
+
+
+def _fused_kw(env):
+    f = env["f"]
+    return dict(prec=f["prec"], mean_temp=f["temp"], min_temp=f["tmin"],
+                max_temp=f["tmax"], etp=f["etp"],
+                met_station_height=env["syn"].STATION_HEIGHT,
+                altitudes=list(env["syn"].ALTITUDES), s_init=0.6, r_init=0.7)
+
+
+@pytest.mark.parametrize("model_name", ["HBVEdu", "CemaneigeGR4J"])
+def test_monte_carlo_device_sampler_over_eight_gpus_in_one_call(env,
+                                                                model_name):
+    """BASELINE configs[3] as a user writes it (reference seam:
+    rrmpg/tools/monte_carlo.py:47-76): ``monte_carlo(model, 1_000_003, qobs,
+    return_qsim=False, score='nse', sampler='device', seed=s, gpus=8)`` --
+    every shard draws ITS rows of the one Philox population in HBM, sweeps
+    them score-only against its GPU's replica of the forcing and sends 8 B
+    per set to the host.  On this one-GPU box the eight shards share the
+    device (a stream each); the scores must equal the single sweep's bit for
+    bit, ragged blocks included, and so must the parameter sets."""
+    from rrmpg_amd.tools import monte_carlo
+    m, f = env["models"], env["f"]
+    model = getattr(m, model_name)()
+    kw = (_fused_kw(env) if model_name == "CemaneigeGR4J" else
+          dict(temp=f["temp"], prec=f["prec"], month=f["month"],
+               PE_m=f["PE_m"], T_m=f["T_m"], **env["syn"].HBV_INITS))
+    rec = model.get_random_params(4)
+    qobs = np.asarray(model.simulate(params=rec, **kw))[:, 1] * 0.9 + 0.05
+    n = 1_000_003
+    call = dict(qobs=qobs, return_qsim=False, score="nse", sampler="device",
+                seed=20260930)
+    one = monte_carlo(model, n, **call, **kw)
+    eight = monte_carlo(model, n, gpus=8, **call, **kw)
+    assert eight["mse"].shape == (n,) and np.isfinite(eight["mse"]).all()
+    assert np.array_equal(one["mse"], eight["mse"])
+    assert np.array_equal(one["nse"], eight["nse"])
+    assert len(eight["params"].shards) == 8 and len(eight["params"]) == n
+    sizes = [int(s.shape[0]) for s in eight["params"].shards]
+    assert sizes == [125001] * 3 + [125000] * 5
+    assert env["torch"].equal(one["params"].tensor, eight["params"].tensor)
+    # ragged small sweeps, 'all' (= the one device here), more shards than sets
+    small = monte_carlo(model, 1001, **call, **kw)
+    for g in (3, 7, "all", 2000):
+        got = monte_carlo(model, 1001, gpus=g, **call, **kw)
+        assert np.array_equal(got["mse"], small["mse"]), g
+        assert np.array_equal(np.asarray(got["params"]),
+                              np.asarray(small["params"])), g
+    with pytest.raises(ValueError):
+        monte_carlo(model, 10, gpus=2, qobs=qobs[:-1], return_qsim=False,
+                    sampler="device", **kw)
+
+
+def test_ensemble_replica_shares_forcing_not_workspace(env):
+    dev, f, torch = env["device"], env["f"], env["torch"]
+    ens = dev.GR4JEnsemble(f["prec"], f["etp"], s_init=0.6, r_init=0.7)
+    p = dev.sample_params(env["models"].GR4J(), 500, 5)
+    q = torch.as_tensor(f["prec"] * 0.3, device=ens.device)
+    a = ens.run(p, None, qobs=q).clone()
+    twin = ens.replica()
+    assert twin.prec.data_ptr() == ens.prec.data_ptr() and twin._ws is None
+    b = twin.run(p, None, qobs=q)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and twin._ws.data_ptr() != ens._ws.data_ptr()
 
 
 def test_concurrent_sweeps_keep_their_own_options(env):
