@@ -387,6 +387,8 @@ def cpu_baseline(args, f, params_host, seconds=10.0):
         "unit": "model-timesteps/s",
         "cores": cores,
         "kind": "port",
+        "sample_short": "%d sets x %d d, %d threads, %.1f s"
+                        % (nall, args.days, cores, tall),
         "sample": "%d %s parameter sets x %d days, all %d host threads "
                   "(OpenMP over sets), reference-shaped: one run per set, "
                   "fresh [T] arrays, column scatter into qsim[T,N]; %.1f s"
@@ -541,6 +543,42 @@ def end_to_end(args, n=100_000):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         dev_times[nn] = (best, bool(np.isfinite(r_dev["mse"]).all()))
+    # ... and the same million as ONE call over eight shards (gpus=8: on this
+    # one GPU the shards share it, a stream each; on a node each has its
+    # own): against eight single-shard calls back to back
+    def best_of(fn, k=3):
+        best = None
+        for _ in range(k):
+            t0 = time.perf_counter()
+            res = fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, res
+    t_shard, _ = best_of(lambda: monte_carlo(
+        m, 125_000, qobs=qobs, return_qsim=False, sampler="device", seed=7,
+        **kw))
+    t_g8, r_g8 = best_of(lambda: monte_carlo(
+        m, 1_000_000, qobs=qobs, return_qsim=False, sampler="device", seed=7,
+        gpus=8, **kw))
+    g8_equal = bool(np.array_equal(r_g8["mse"], r_dev["mse"]))
+    # BASELINE configs[3] as the user writes it: CemaneigeGR4J, 1M sets,
+    # per-set NSE, eight shards, one call
+    fm = models.CemaneigeGR4J()
+    fkw = dict(prec=f["prec"], mean_temp=f["temp"], min_temp=f["tmin"],
+               max_temp=f["tmax"], etp=f["etp"],
+               met_station_height=syn.STATION_HEIGHT,
+               altitudes=list(syn.ALTITUDES), s_init=0.6, r_init=0.7)
+    fq = syn.make_qobs(np.asarray(fm.simulate(
+        params=fm.get_random_params(1), **fkw))[:, :1].copy())
+    fcall = dict(qobs=fq, return_qsim=False, score="nse", sampler="device",
+                 seed=7)
+    monte_carlo(fm, 1000, **fcall, **fkw)
+    tf_shard, _ = best_of(lambda: monte_carlo(fm, 125_000, **fcall, **fkw), 2)
+    tf_one, rf_one = best_of(lambda: monte_carlo(fm, 1_000_000, **fcall,
+                                                 **fkw), 2)
+    tf_g8, rf_g8 = best_of(lambda: monte_carlo(fm, 1_000_000, gpus=8, **fcall,
+                                               **fkw), 2)
+    fused_equal = bool(np.array_equal(rf_g8["nse"], rf_one["nse"]))
     _lib.load().rr_release_cached_memory()
     steps = n * args.days
     return {
@@ -569,7 +607,23 @@ def end_to_end(args, n=100_000):
             "seconds_1m": dev_times[1_000_000][0],
             "model_timesteps_per_s_1m":
                 1_000_000 * args.days / dev_times[1_000_000][0],
-            "finite": dev_times[n][1] and dev_times[1_000_000][1]},
+            "finite": dev_times[n][1] and dev_times[1_000_000][1],
+            # gpus=8 in ONE call (the eight shards share this GPU) against
+            # eight single-shard calls back to back
+            "seconds_125k": t_shard,
+            "seconds_1m_gpus8": t_g8,
+            "gpus8_over_8_shards": t_g8 / (8 * t_shard),
+            "gpus8_equals_one_gpu": g8_equal},
+        "monte_carlo_configs3": {
+            "workload": "monte_carlo(CemaneigeGR4J(), 1_000_000, qobs, "
+                        "return_qsim=False, score='nse', sampler='device', "
+                        "gpus=8): BASELINE configs[3] as one call, the eight "
+                        "shards sharing this GPU (best of two)",
+            "seconds_125k": tf_shard,
+            "seconds_1m": tf_one,
+            "seconds_1m_gpus8": tf_g8,
+            "gpus8_over_8_shards": tf_g8 / (8 * tf_shard),
+            "gpus8_equals_one_gpu": fused_equal},
         "note": "PCIe-inclusive, single GPU; never the line's `value`",
     }
 
@@ -848,26 +902,29 @@ def run_workload(args, device, rank, world, on_host, steps, warmup,
 # the same driver run after the headline: label -> bench arguments.  One
 # GPU's share where the config names eight.
 EXTRA_CONFIGS = [
-    ("GR4J 1M sets, qsim + MSE (configs[2])",
-     dict(model="gr4j", mode="qsim", sets=1_000_000)),
-    ("CemaneigeGR4J 125k sets = one GPU's shard of 1M over 8, per-set NSE "
-     "(configs[3])",
-     dict(model="cemaneigegr4j", mode="metric", sets=125_000, score="nse")),
-    ("HBV-Edu 125 catchments x 10k sets = one GPU's share of 1000 x 10k, "
-     "per-set MSE (configs[4])",
-     dict(model="hbvedu", mode="metric", sets=10_000, catchments=125)),
-    ("HBV-Edu 100k sets, qsim + MSE (configs[1])",
+    # (id, label, bench arguments); BASELINE configs[1]..[4] first: the
+    # driver keeps the END of stdout, and the line is short enough to fit
+    ("cfg1", "HBV-Edu 100k sets, qsim + MSE (configs[1])",
      dict(model="hbvedu", mode="qsim", sets=100_000)),
-    ("HBV-Edu 400k sets, all five outputs (40 B per model-timestep)",
+    ("cfg2", "GR4J 1M sets, qsim + MSE (configs[2])",
+     dict(model="gr4j", mode="qsim", sets=1_000_000)),
+    ("cfg3", "CemaneigeGR4J 125k sets = one GPU's shard of 1M over 8, "
+     "per-set NSE (configs[3])",
+     dict(model="cemaneigegr4j", mode="metric", sets=125_000, score="nse")),
+    ("cfg4", "HBV-Edu 125 catchments x 10k sets = one GPU's share of 1000 x "
+     "10k, per-set MSE (configs[4])",
+     dict(model="hbvedu", mode="metric", sets=10_000, catchments=125)),
+    ("hbv5out", "HBV-Edu 400k sets, all five outputs (40 B per "
+     "model-timestep)",
      dict(model="hbvedu", mode="storages", sets=400_000)),
-    ("ABC 1M sets, qsim + MSE (8 B per model-timestep)",
+    ("abc", "ABC 1M sets, qsim + MSE (8 B per model-timestep)",
      dict(model="abc", mode="qsim", sets=1_000_000)),
     # the hysteresis / ice-melt couplings, L = 5, default bounds
-    ("CemaneigeHystGR4J 1M sets, per-set MSE (next tier)",
+    ("hyst", "CemaneigeHystGR4J 1M sets, per-set MSE (next tier)",
      dict(model="cemaneigehystgr4j", mode="metric", sets=1_000_000)),
-    ("CemaneigeGR4JIce 1M sets, per-set MSE (next tier)",
+    ("ice", "CemaneigeGR4JIce 1M sets, per-set MSE (next tier)",
      dict(model="cemaneigegr4jice", mode="metric", sets=1_000_000)),
-    ("CemaneigeHystGR4JIce 1M sets, per-set MSE (next tier)",
+    ("hystice", "CemaneigeHystGR4JIce 1M sets, per-set MSE (next tier)",
      dict(model="cemaneigehystgr4jice", mode="metric", sets=1_000_000)),
 ]
 
@@ -880,7 +937,7 @@ def extra_configs(args, device):
     import gc
     import torch
     out = []
-    for label, spec in EXTRA_CONFIGS:
+    for ident, label, spec in EXTRA_CONFIGS:
         a = copy.copy(args)
         a.catchments, a.scaling, a.sampler = 0, "strong", args.sampler
         score = spec.get("score", "mse")
@@ -890,8 +947,8 @@ def extra_configs(args, device):
         try:
             r = run_workload(a, device, 0, 1, False, args.extra_steps, 1,
                              score=score, settle_s=0.3, min_timed_s=0.06)
-            rec = {"workload": label, "kernel_ms": r["kernel_ms"],
-                   "steps": r["steps"],
+            rec = {"id": ident, "workload": label,
+                   "kernel_ms": r["kernel_ms"], "steps": r["steps"],
                    "model_timesteps_per_s": r["n"] * r["t"]
                    / (r["kernel_ms"] * 1e-3),
                    "bytes_per_unit": r["bytes_per_step"],
@@ -930,7 +987,7 @@ def extra_configs(args, device):
                     else cpu_baseline(a, r["f"], r["params_host"],
                                       seconds=2.5))
         except Exception as exc:                # keep the headline line
-            rec = {"workload": label, "error": "%s: %s"
+            rec = {"id": ident, "workload": label, "error": "%s: %s"
                    % (type(exc).__name__, exc)}
             r = None
         out.append(rec)
@@ -938,6 +995,136 @@ def extra_configs(args, device):
         gc.collect()
         torch.cuda.empty_cache()
     return out
+
+
+def _sig(x, digits=5):
+    """Floats of a record to `digits` significant digits (ints, strings,
+    None and bools stay)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+LINE_LIMIT = 7500        # the driver keeps 8 KB of stdout
+
+
+def compact_line(d):
+    """The ONE line bench.py prints, from the full record `d` (which goes to
+    the side file the line names under "detail"): numbers and short keys
+    only -- every key is explained in profiles/BENCH_KEYS.md.  The contract's
+    fields keep their names; headline numbers keep full precision."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+            "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: d[k] for k in keep}
+    c = d["config"]
+    out["config"] = {k: c[k] for k in
+                     ("workload", "model", "sets_total", "sets_per_gpu",
+                      "timesteps", "mode", "score", "sampler") if k in c}
+    if "shards" in c and d["n_gpus"] > 1:
+        out["config"]["shards"] = c["shards"]
+    r = d["roofline"]
+    roof = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac",
+                              "traffic", "kernel_ms")}
+    roof["traffic_from"] = ("stale" if "stale" in r["source"]
+                            else "profiles/traffic.json")
+    roof["valu_instr_per_unit"] = r.get("valu_instr_per_unit")
+    if "valu" in r:
+        roof["valu"] = _sig({k: r["valu"].get(k) for k in
+                             ("instr_per_unit", "floor_ms", "frac",
+                              "frac_at_measured_clock",
+                              "issue_frac_at_measured_clock")})
+    if r.get("power"):
+        roof["power"] = _sig({k: r["power"].get(k) for k in
+                              ("socket_w", "sclk_mhz", "cap_w")})
+    if "binding_roof" in r:
+        roof["binding_roof"] = r["binding_roof"]
+    out["roofline"] = roof
+    for k in ("kernel_ms_per_rank", "allgather_ms", "scores_finite",
+              "scores_digest", "parity_spot", "parity_spot_host_population"):
+        if k in d:
+            out[k] = d[k]
+    cb = d.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = _sig({
+            "value": cb["value"], "unit": cb["unit"], "cores": cb["cores"],
+            "kind": cb["kind"], "sample": cb["sample_short"],
+            "value_1thread": cb["value_1thread"]}, 6)
+    ex = []
+    for e in d.get("extra_configs", []):
+        if "error" in e:
+            ex.append({"id": e["id"], "error": e["error"][:120]})
+            continue
+        rec = {"id": e["id"], "kernel_ms": e["kernel_ms"],
+               "rate": e["model_timesteps_per_s"], "B": e["bytes_per_unit"],
+               "frac": e["frac"], "score": e["score"],
+               "finite": e["scores_finite"], "parity_spot": e["parity_spot"]}
+        if e.get("traffic"):
+            rec["traffic"] = e["traffic"]
+        if e.get("power"):
+            rec["w"] = e["power"].get("socket_w")
+            rec["mhz"] = e["power"].get("sclk_mhz")
+        if e.get("valu"):
+            v = e["valu"]
+            rec["valu"] = {"n": v["instr_per_unit"], "frac": v["frac"],
+                           "frac_clk": v.get("frac_at_measured_clock"),
+                           "issue_clk": v.get("issue_frac_at_measured_clock")}
+        cpu = e.get("cpu_baseline")
+        if isinstance(cpu, dict):
+            rec["cpu"] = [cpu["value"], cpu["cores"], cpu["value_1thread"]]
+        ex.append(_sig(rec, 4))
+    if ex:
+        out["extra_configs"] = ex
+    ee = d.get("end_to_end")
+    if ee and "error" in ee:
+        out["end_to_end"] = {"error": ee["error"][:200]}
+    elif ee:
+        mh, md = ee["monte_carlo_scores_only"], ee["monte_carlo_device_sampler"]
+        m3 = ee["monte_carlo_configs3"]
+        out["end_to_end"] = _sig({
+            "simulate_100k_s": ee["seconds"],
+            "gb_per_s_into_numpy": ee["gb_per_s_into_numpy"],
+            "mc_host_100k_s": mh["seconds"],
+            "mc_dev_100k_s": md["seconds_100k"],
+            "mc_dev_1m_s": md["seconds_1m"],
+            "mc_dev_125k_s": md["seconds_125k"],
+            "mc_dev_1m_gpus8_s": md["seconds_1m_gpus8"],
+            "gpus8_over_8_shards": md["gpus8_over_8_shards"],
+            "cfg3_125k_s": m3["seconds_125k"], "cfg3_1m_s": m3["seconds_1m"],
+            "cfg3_1m_gpus8_s": m3["seconds_1m_gpus8"],
+            "cfg3_gpus8_over_8_shards": m3["gpus8_over_8_shards"],
+            "gpus8_equal": bool(md["gpus8_equals_one_gpu"]
+                                and m3["gpus8_equals_one_gpu"]),
+            "finite": bool(ee["finite"] and mh["finite"] and md["finite"])}, 4)
+    out["keys"] = "profiles/BENCH_KEYS.md"
+    if d.get("detail"):
+        out["detail"] = d["detail"]
+    return out
+
+
+def write_detail(full):
+    """The full record (prose included) beside the line: gpurun_out/ of the
+    tree bench.py runs from (merged back by gpurun), else the temp dir."""
+    import tempfile
+    for folder in (os.path.join(REPO, "gpurun_out"), tempfile.gettempdir()):
+        try:
+            os.makedirs(folder, exist_ok=True)
+            path = os.path.join(folder, "bench_detail.json")
+            with open(path, "w") as fh:
+                json.dump(full, fh, indent=1)
+            return os.path.relpath(path, REPO) if path.startswith(REPO) \
+                else path
+        except OSError:
+            continue
+    return None
 
 
 def main():
@@ -1122,7 +1309,12 @@ def main():
             except Exception as exc:            # keep the headline line
                 out["end_to_end"] = {"error": "%s: %s"
                                      % (type(exc).__name__, exc)}
-        print(json.dumps(out), flush=True)
+        out["detail"] = write_detail(out)
+        line = json.dumps(compact_line(out), separators=(",", ":"))
+        if len(line) > LINE_LIMIT:
+            print("warning: bench line is %d characters (limit %d)"
+                  % (len(line), LINE_LIMIT), file=sys.stderr)
+        print(line, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -27,7 +27,9 @@ def _run(cmd, env=None):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    d["_line_chars"] = len(lines[0])
+    return d
 
 
 def test_single_gpu_line():
@@ -68,63 +70,74 @@ def test_single_gpu_line():
 def test_default_line_carries_every_config_and_the_valu_roof():
     """The driver's command (default workload = BASELINE.json's metric
     configuration): besides the headline fields the line holds the other
-    BASELINE configurations timed in the same run, each with its parity spot
-    against the oracle, and the fp64-issue roof computed from this run's
-    kernel time."""
+    BASELINE configurations timed in the same run -- configs[1]..[4] first --
+    each with its parity spot against the oracle, and the fp64-issue roof
+    computed from this run's kernel time.  The WHOLE line fits the 8 KB of
+    stdout the driver keeps (numbers and short keys, profiles/BENCH_KEYS.md;
+    the prose is in the side file the line names)."""
     d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3",
               "--warmup", "1", "--extra-steps", "2", "--no-cpu-baseline"])
+    assert d["_line_chars"] <= 7500, d["_line_chars"]
     assert d["config"]["sets_total"] == 1_000_000
     assert d["config"]["timesteps"] == 10957 and d["config"]["mode"] == "qsim"
     assert 0 <= d["parity_spot"] < 1e-10
     r = d["roofline"]
-    assert "profiles/traffic.json" in r["source"]["traffic"]
-    if "stale" in r["source"]:
+    if r["traffic_from"] == "stale":
         # the kernels have changed since the committed counter passes
         # (rrmpg_amd/utils/buildid.py): their numbers are withheld
         assert r["traffic"] is None and r["valu_instr_per_unit"] is None
         assert "valu" not in r
     else:
+        assert r["traffic_from"] == "profiles/traffic.json"
         assert r["traffic"] and r["valu_instr_per_unit"]
         v = r["valu"]
-        assert v["cycles_per_instr"] == 4 and v["simds"] == 1024
-        assert abs(v["frac"] - v["floor_ms"] / r["kernel_ms"]) < 1e-12
+        assert abs(v["frac"] - v["floor_ms"] / r["kernel_ms"]) < 1e-3
         assert 0.4 < v["frac"] < 1.0
-        if r["power"] and r["power"]["sclk_mhz"]:
-            # the same floor at the clock the chip sustains under the sweep
+        if r.get("power") and r["power"]["sclk_mhz"]:
+            # the same floor at the clock the chip sustains under the sweep,
+            # and at the 4.3 cycles an fp64 instruction is measured at
             assert v["frac"] <= v["frac_at_measured_clock"] < 1.05
-            # ... and at the 4.3 cycles an fp64 instruction is measured at
-            assert v["cycles_per_instr_measured"] == 4.3
             assert (v["frac_at_measured_clock"]
                     < v["issue_frac_at_measured_clock"] < 1.1)
             assert r["binding_roof"] in ("socket power", "hbm", "fp64 issue")
     assert 0.3 < r["frac"] < 1.0
     # socket power / shader clock of the same sweep in steady state, read
-    # after the timed region (None where the GPU has no hwmon files)
-    pw = r["power"]
-    assert pw is None or (pw["samples"] >= 1 and 50 < pw["socket_w"] < 3000
-                          and pw["soak_steps"] >= 4)
+    # after the timed region (absent where the GPU has no hwmon files)
+    pw = r.get("power")
+    assert pw is None or 50 < pw["socket_w"] < 3000
     ex = d["extra_configs"]
-    assert len(ex) == 9
+    assert [e["id"] for e in ex] == ["cfg1", "cfg2", "cfg3", "cfg4", "hbv5out",
+                                     "abc", "hyst", "ice", "hystice"]
     for e in ex:
         assert "error" not in e, e
-        assert e["kernel_ms"] > 0 and e["scores_finite"] is True
+        assert e["kernel_ms"] > 0 and e["finite"] is True
         # every configuration -- the hysteresis / ice couplings included --
         # carries its parity spot against the oracle
         assert 0 <= e["parity_spot"] < 1e-10, e
-        assert e["steps"] >= 2
         # its own clock and socket power, and with them its issue roof
-        if e.get("power") and e["power"]["sclk_mhz"] and "valu" in e:
-            assert 500 < e["power"]["sclk_mhz"] < 3000
-            assert 0.0 < e["valu"]["issue_frac_at_measured_clock"] < 1.1, e
-        if e["bytes_per_unit"]:
+        if e.get("mhz") and "valu" in e:
+            assert 500 < e["mhz"] < 3000
+            assert 0.0 < e["valu"]["issue_clk"] < 1.1, e
+        if e["B"]:
             assert 0 < e["frac"] < 1
-    by = {e["workload"].split(",")[0]: e for e in ex}
-    assert by["ABC 1M sets"]["frac"] > 0.6          # the HBM-bound kernels
-    assert by["HBV-Edu 400k sets"]["frac"] > 0.6
-    assert any(e["score"] == "nse" for e in ex)     # configs[3]
-    for name in ("CemaneigeHystGR4J", "CemaneigeGR4JIce",
-                 "CemaneigeHystGR4JIce"):
-        assert by[name + " 1M sets"]["kernel_ms"] > 0
+    by = {e["id"]: e for e in ex}
+    assert by["abc"]["frac"] > 0.6                  # the HBM-bound kernels
+    assert by["hbv5out"]["frac"] > 0.6
+    assert by["cfg3"]["score"] == "nse"
+    # the full record (prose, every field of round 5's line) is beside it
+    with open(os.path.join(REPO, d["detail"])) as fh:
+        full = json.load(fh)
+    assert len(full["extra_configs"]) == 9
+    assert "configs[2]" in full["extra_configs"][1]["workload"]
+    assert full["roofline"]["valu"]["cycles_per_instr"] == 4 \
+        if "valu" in full["roofline"] else True
+    # one call over eight shards (sampler='device', gpus=8): the scores of
+    # the single sweep, within 1.3 x eight single-shard calls
+    ee = d["end_to_end"]
+    assert "error" not in ee, ee
+    assert ee["gpus8_equal"] is True and ee["finite"] is True
+    assert ee["gpus8_over_8_shards"] < 1.3
+    assert ee["cfg3_gpus8_over_8_shards"] < 1.3
 
 
 def test_eight_ranks_rehearsal_on_one_gpu():
