@@ -944,7 +944,7 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_dyn_kernel(
                                 ws ? G_out + (t * L) * ld + i : nullptr,
                                 ws ? eTG_out + (t * L) * ld + i : nullptr, ld,
                                 ws && active);
-        if constexpr (coupled) q = gr4j_step<UH, GR4J_CONSTS_JIT>(P, s, r, uh, q, day[3 * L]);
+        if constexpr (coupled) q = gr4j_step<UH, GR4J_CONSTS_JIT, true>(P, s, r, uh, q, day[3 * L]);
         if (active) {
             if (wq) rr_out(&qsim[t * ld + i], q);
             if (coupled && ws) {

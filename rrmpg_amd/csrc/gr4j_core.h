@@ -728,8 +728,14 @@ struct Gr4jUniformWet { int word; };
 #ifndef GR4J_STEP_UNIFORM_WET
 #define GR4J_STEP_UNIFORM_WET 0
 #endif
-template <class UH, int CONSTS_ = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook,
-          class V = CarefulVotes, class W = bool>
+// ANY_FORCING: the kernel has no one-lane reference kernel behind it that
+// would redo a launch with a non-finite forcing value (the kernels for more
+// than RR_CEMANEIGE_MAX_LAYERS layers; the HBM-scratch tier, UhMem, always):
+// a dry day's excess is then the reference's literal 0 (gr4j_model.py:104,
+// :123) by per-lane select, not net - frac times a factor 0.0 -- which is NaN
+// for etp = +inf, where the reference's p_r = perc is finite.
+template <class UH, int CONSTS_ = GR4J_CONSTS_SGPR, bool ANY_FORCING_ = false,
+          class MID = Gr4jNoHook, class V = CarefulVotes, class W = bool>
 __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
                                                   double net, W wet_arg,
                                                   lanemask_t net_m,
@@ -737,6 +743,8 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
                                                   V &&votes = V())
 {
     constexpr bool uniform_wet = std::is_same<W, Gr4jUniformWet>::value;
+    constexpr bool any_forcing =
+        ANY_FORCING_ || std::is_same<UH, UhMem>::value;
     bool wet;
     int wet_word = 0;
     if constexpr (uniform_wet) {
@@ -852,9 +860,17 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     // rounding of the sum it replaces, so the bits are the per-lane form's --
     // where round 4 flipped frac's sign bit and masked e with integer
     // instructions: 2 vector instructions instead of 6, GR4J 97.9 -> 94
-    // per set-day.  e is a number: the sets of this kernel are civil.)
+    // per set-day.  e is a number: a launch with a forcing value that is not
+    // civil is redone by the reference kernel behind this one -- where there
+    // is none, any_forcing selects the excess per lane instead.)
     double keep_excess = 0.0;
-    if constexpr (uniform_wet) {
+    if constexpr (any_forcing) {
+        const double sgn = __hiloint2double(
+            wet ? 0x3ff00000 : (int)0xbff00000, 0);
+        keep_excess = 1.0;
+        sn = __builtin_fma(frac, sgn, s);
+        excess = wet ? net - frac : 0.0;
+    } else if constexpr (uniform_wet) {
         const int flip = (int)((unsigned)(wet_word ^ 1) << 31);
         const int keep = -wet_word;                 // all ones on a wet day
         const double sgn = __hiloint2double(0x3ff00000 | flip, 0);
@@ -913,7 +929,8 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     mid();
     s = sn - perc;                                              // :120
 #endif
-    return __builtin_fma(excess, keep_excess, perc);            // p_r, :123
+    if constexpr (any_forcing) return perc + excess;            // p_r, :123
+    return __builtin_fma(excess, keep_excess, perc);
 }
 
 // `in` -> `out`: the hydrograph slots' two generations (UhRegs::Slots), or
@@ -982,18 +999,20 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
     }
 }
 
-template <class UH, int CONSTS = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook>
+template <class UH, int CONSTS = GR4J_CONSTS_SGPR, bool ANY_FORCING = false,
+          class MID = Gr4jNoHook>
 __device__ __forceinline__ double gr4j_step_net(const Gr4jPar &P, double &s,
                                                 double &r, UH &uh, double net,
                                                 bool wet, lanemask_t net_m,
                                                 MID &&mid = MID())
 {
-    const double p_r = gr4j_production<UH, CONSTS>(
+    const double p_r = gr4j_production<UH, CONSTS, ANY_FORCING>(
         P, s, net, wet, net_m, static_cast<MID &&>(mid));
     return gr4j_routing<UH>(P, r, uh, p_r);
 }
 
-template <class UH, int CONSTS = GR4J_CONSTS_SGPR, class MID = Gr4jNoHook>
+template <class UH, int CONSTS = GR4J_CONSTS_SGPR, bool ANY_FORCING = false,
+          class MID = Gr4jNoHook>
 __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
                                             double &r, UH &uh, double prec,
                                             double etp, MID &&mid = MID())
@@ -1014,16 +1033,16 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
     double p_r;
     if (wet_m == 0 || wet_m == rr_exec()) {
         const Gr4jUniformWet uw = {wet_m != 0 ? 1 : 0};
-        p_r = gr4j_production<UH, CONSTS>(P, s, net, uw, net_m,
-                                          static_cast<MID &&>(mid));
+        p_r = gr4j_production<UH, CONSTS, ANY_FORCING>(
+            P, s, net, uw, net_m, static_cast<MID &&>(mid));
     } else {
         asm volatile("");                           // keep this a branch
-        p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
-                                          static_cast<MID &&>(mid));
+        p_r = gr4j_production<UH, CONSTS, ANY_FORCING>(
+            P, s, net, wet, net_m, static_cast<MID &&>(mid));
     }
     return gr4j_routing<UH>(P, r, uh, p_r);
 #else
-    return gr4j_step_net<UH, CONSTS>(P, s, r, uh, net, wet, net_m,
-                                        static_cast<MID &&>(mid));
+    return gr4j_step_net<UH, CONSTS, ANY_FORCING>(
+        P, s, r, uh, net, wet, net_m, static_cast<MID &&>(mid));
 #endif
 }

@@ -653,8 +653,9 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_dyn_kernel(
         }
         const double snowmelt = c / (double)L;
         const double liquid = ICE ? snowmelt + ice_total : snowmelt;
-        const double q = gr4j_step<UH, ICE ? GR4J_CONSTS_JIT_EXP : GR4J_CONSTS_JIT>(
-            P, s, r, uh, liquid, day[3 * L]);
+        // (no reference kernel behind this one: the excess by select)
+        const double q = gr4j_step<UH, ICE ? GR4J_CONSTS_JIT_EXP : GR4J_CONSTS_JIT,
+                                   true>(P, s, r, uh, liquid, day[3 * L]);
         if (active) {
             if (wq) rr_out(&o.qsim[t * ld + i], q);
             if (ws) {

@@ -641,6 +641,51 @@ def test_snow_kernels_with_poisoned_forcing(models, oracle, poison):
                 _same(a, ref[k], "%s hyst %s" % (poison, k))
 
 
+def test_infinite_etp_where_no_reference_kernel_follows(models, oracle):
+    """etp = +inf on a day with finite rain: the reference's dry arm gives
+    p_r = perc + (0 - 0), a number (gr4j_model.py:102-123).  The fast GR4J
+    kernels form that excess as (net - frac) times a factor 0.0 -- NaN here --
+    and leave such launches to the one-lane reference kernel behind them;
+    the two kinds of kernel that have none (the HBM-scratch tier for x4 > 20,
+    the coupled kernels for more than eight layers) select the excess per
+    lane instead (round 5's advisor finding: they returned NaN)."""
+    from rrmpg_amd.models import cemaneigegr4j as fmod
+    g = golden("syn_gr4j")
+    rng = np.random.default_rng(107 + 1000 * SEED)
+    t = 300
+    prec, etp = g["prec"][:t].copy(), g["etp"][:t].copy()
+    etp[[40, 41, 200]] = np.inf
+    n = 130
+    flat = np.column_stack([rng.uniform(100, 1200, n), rng.uniform(-5, 3, n),
+                            rng.uniform(20, 300, n), rng.uniform(20.5, 33, n)])
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_gr4j(prec, etp, (0.6, 0.7), flat,
+                                   return_storage=True, nthreads=8)
+    assert np.isfinite(ref[0]).all()
+    out = models.GR4J().simulate(prec, etp, 0.6, 0.7, return_storage=True,
+                                 params=_records(models.GR4J, flat))
+    for a, b, name in zip(out, ref, ["qsim", "s_store", "r_store"]):
+        _same(a, b, "gr4j x4 > 20, etp = inf: " + name)
+    # nine layers (> RR_CEMANEIGE_MAX_LAYERS): the five of the fixture + four
+    h = golden("syn_cemaneigehystgr4j")
+    lp, lm, fr = (np.concatenate([h[k][:t], h[k][:t, :4]], axis=1)
+                  for k in ("layer_prec", "layer_mean", "frac_solid"))
+    etp9 = h["etp"][:t].copy()
+    etp9[[40, 41, 200]] = np.inf
+    flat = np.column_stack([rng.uniform(0, 1, n), rng.uniform(0, 10, n),
+                            rng.uniform(100, 1200, n), rng.uniform(-5, 3, n),
+                            rng.uniform(20, 300, n), rng.uniform(0.5, 9.5, n)])
+    inits = (3.0, -0.2, 0.4, 0.5)
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_cemaneigegr4j(lp, lm, etp9, fr, inits, flat,
+                                            return_storages=True, nthreads=8)
+    assert np.isfinite(ref[0]).all()
+    out, _ = fmod._run((lp, lm, fr, etp9), inits,
+                       _records(models.CemaneigeGR4J, flat), True, True, None)
+    for a, b, name in zip(out, ref, ["qsim", "G", "eTG", "s_store", "r_store"]):
+        _same(a, b, "nine layers, etp = inf: " + name)
+
+
 @pytest.mark.parametrize("poison", ["nan_prec", "negative_prec",
                                     "minus_zero_prec", "nan_snow_init",
                                     "minus_zero_snow_init", "none"])
