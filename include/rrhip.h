@@ -136,9 +136,10 @@ int rr_release_cached_memory(void);
  *                       all ranks have called (ncclCommInitRank)
  *   rr_allgather_metric local: this rank's n_local device doubles; all:
  *                       n_total device doubles, block r of rank r in set
- *                       order (local may be all + first: in place).  One
- *                       group of broadcasts, rank r the root of block r:
- *                       ragged blocks need no padding and nothing is
+ *                       order (local may be all + first: in place).  Equal
+ *                       blocks (n_total % world == 0): one ncclAllGather;
+ *                       ragged blocks: one group of broadcasts, rank r the
+ *                       root of block r -- no padding, nothing
  *                       allocated.  Enqueued on `stream` (hipStream_t),
  *                       returns at once like the *_simulate_dev family.
  *   rr_comm_destroy                                                          */

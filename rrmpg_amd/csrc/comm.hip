@@ -16,24 +16,34 @@
 //
 // The blocks are rrmpg_amd.sharding.shard_bounds' (contiguous, sizes differ
 // by at most one, the first n_total % world ranks hold the longer ones).
-// Ragged blocks rule out ncclAllGather's equal counts, so the exchange is one
-// group of `world` broadcasts, rank r the root of block r, each landing in
-// its place of `all` -- no padding, no staging buffer, nothing allocated.
+// Equal blocks (n_total % world == 0 -- every BASELINE configuration) are ONE
+// ncclAllGather; ragged blocks rule out its equal counts, so that exchange is
+// one group of `world` broadcasts, rank r the root of block r, each landing
+// in its place of `all` -- no padding, no staging buffer, nothing allocated.
 // Asynchronous on `stream` like the *_simulate_dev family.
 //
 // librccl is opened at first use (dlopen "librccl.so.1": the copy a host
 // program -- PyTorch, say -- has already loaded is the one that answers),
 // so librrhip.so itself carries no link-time dependency on it and every other
-// entry point works on a box without RCCL.
+// entry point works on a box without RCCL.  Nor does the BUILD need RCCL's
+// development headers: the handful of types and the seven entry points used
+// are declared here (NCCL's stable C ABI: rccl.h ncclResult_t,
+// ncclDataType_t ncclFloat64 = 8, NCCL_UNIQUE_ID_BYTES 128).
 #include <dlfcn.h>
 #include <string.h>
-#include <rccl/rccl.h>
 
 #include <mutex>
 
 #include "common.h"
 
 namespace {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[RR_COMM_ID_BYTES]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclFloat64 = 8;
+
 struct Rccl {
     void *handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -41,6 +51,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t,
                               int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t,
+                              ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -48,9 +60,15 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
+// rrdbg_comm_inject: a table of stand-ins for the entry points (tests: the
+// shape of the exchange -- which collective, which offsets, counts and roots
+// -- checked on a box without a GPU)
+Rccl g_injected;
+bool g_use_injected = false;
 
 const Rccl *rccl()
 {
+    if (g_use_injected) return &g_injected;
     std::call_once(g_rccl_once, [] {
         for (const char *name : {"librccl.so.1", "librccl.so"}) {
             g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -63,13 +81,14 @@ const Rccl *rccl()
             (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
         g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
         g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
+        g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
         g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
         g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
         g_rccl.GetErrorString =
             (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
         g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank &&
                     g_rccl.CommDestroy && g_rccl.Broadcast &&
-                    g_rccl.GroupStart && g_rccl.GroupEnd;
+                    g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd;
     });
     return g_rccl.ok ? &g_rccl : nullptr;
 }
@@ -97,7 +116,30 @@ const Rccl *need_rccl(const char *who)
 }
 }  // namespace
 
-static_assert(RR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "rrhip.h");
+static_assert(sizeof(ncclUniqueId) == RR_COMM_ID_BYTES, "rrhip.h");
+
+// Test hook (not part of include/rrhip.h): table = seven function pointers in
+// the order {GetUniqueId, CommInitRank, CommDestroy, Broadcast, AllGather,
+// GroupStart, GroupEnd} that answer instead of librccl from now on; NULL
+// restores the library.
+extern "C" int rrdbg_comm_inject(void *const *table)
+{
+    if (!table) {
+        g_use_injected = false;
+        return RR_OK;
+    }
+    g_injected = Rccl();
+    g_injected.GetUniqueId = (decltype(g_injected.GetUniqueId))table[0];
+    g_injected.CommInitRank = (decltype(g_injected.CommInitRank))table[1];
+    g_injected.CommDestroy = (decltype(g_injected.CommDestroy))table[2];
+    g_injected.Broadcast = (decltype(g_injected.Broadcast))table[3];
+    g_injected.AllGather = (decltype(g_injected.AllGather))table[4];
+    g_injected.GroupStart = (decltype(g_injected.GroupStart))table[5];
+    g_injected.GroupEnd = (decltype(g_injected.GroupEnd))table[6];
+    g_injected.ok = true;
+    g_use_injected = true;
+    return RR_OK;
+}
 
 extern "C" int rr_comm_unique_id(void *id_out)
 {
@@ -193,6 +235,15 @@ extern "C" int rr_allgather_metric(void *comm, const double *local,
     const Rccl *r = need_rccl(who);
     if (!r) return RR_E_NODEVICE;
     hipStream_t st = (hipStream_t)stream;
+    if (n_total % c->world == 0) {
+        // equal blocks: the one all-gather (in place when local is this
+        // rank's block of `all`, as ncclAllGather defines in place)
+        if (n_local == 0) return RR_OK;
+        const ncclResult_t grc = r->AllGather(local, all, (size_t)n_local,
+                                              ncclFloat64, c->comm, st);
+        if (grc != ncclSuccess) return fail(r, "ncclAllGather", grc);
+        return RR_OK;
+    }
     ncclResult_t nrc = r->GroupStart();
     if (nrc != ncclSuccess) return fail(r, "ncclGroupStart", nrc);
     for (int root = 0; root < c->world; ++root) {

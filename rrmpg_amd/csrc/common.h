@@ -283,6 +283,9 @@ __device__ __forceinline__ void rr_store_row(double *row_base, unsigned bytes,
 // every store of a row behind the first was dropped), so the descriptor's
 // size is soffset + bytes: lanes at or beyond `bytes` are still dropped.
 // soffset + bytes < 2^32: the caller's business.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "rr_store_row_at relies on gfx950's raw-buffer range check (SOFFSET included): build with ARCH=gfx950"
+#endif
 __device__ __forceinline__ void rr_store_row_at(double *row_base, unsigned bytes,
                                                 int lane_byte_off,
                                                 unsigned soffset, double v,

@@ -602,7 +602,7 @@ namespace {
 struct TierStreams {
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, done[3] = {nullptr, nullptr, nullptr};
-    bool ok = false;
+    bool ok = false, failed = false;
 };
 constexpr int RR_TIER_MAX_DEVICES = 64;
 thread_local TierStreams tl_tier[RR_TIER_MAX_DEVICES];
@@ -613,17 +613,29 @@ TierStreams *tier_streams()
         dev >= RR_TIER_MAX_DEVICES)
         return nullptr;
     TierStreams &t = tl_tier[dev];
+    if (t.failed) return nullptr;       // (tried once: everything on `st`)
     if (!t.ok) {
-        for (int k = 0; k < 3; ++k) {
-            if (hipStreamCreateWithFlags(&t.side[k], hipStreamNonBlocking) !=
-                    hipSuccess ||
-                hipEventCreateWithFlags(&t.done[k], hipEventDisableTiming) !=
-                    hipSuccess)
-                return nullptr;
-        }
-        if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) !=
-            hipSuccess)
+        bool good = hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) ==
+                    hipSuccess;
+        for (int k = 0; k < 3 && good; ++k)
+            good = hipStreamCreateWithFlags(&t.side[k],
+                                            hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&t.done[k],
+                                           hipEventDisableTiming) == hipSuccess;
+        if (!good) {
+            // give back what was created and do not try again: a later call
+            // would create -- and leak -- the same handles once more
+            for (int k = 0; k < 3; ++k) {
+                if (t.side[k]) (void)hipStreamDestroy(t.side[k]);
+                if (t.done[k]) (void)hipEventDestroy(t.done[k]);
+                t.side[k] = nullptr;
+                t.done[k] = nullptr;
+            }
+            if (t.fork) (void)hipEventDestroy(t.fork);
+            t.fork = nullptr;
+            t.failed = true;
             return nullptr;
+        }
         t.ok = true;
     }
     return &t;
@@ -637,24 +649,43 @@ int rr_tier_fork(hipStream_t st)
         (void)hipGetLastError();
         return RR_OK;                  // no side streams: everything on `st`
     }
-    RR_HIP(hipEventRecord(tl_tier_now->fork, st));
-    for (int k = 0; k < 3; ++k)
-        RR_HIP(hipStreamWaitEvent(tl_tier_now->side[k], tl_tier_now->fork, 0));
+    TierStreams *const t = tl_tier_now;
+    bool good = hipEventRecord(t->fork, st) == hipSuccess;
+    for (int k = 0; k < 3 && good; ++k)
+        good = hipStreamWaitEvent(t->side[k], t->fork, 0) == hipSuccess;
+    if (!good) {
+        // nothing has been enqueued on a side stream yet: this launch runs
+        // on `st` alone
+        (void)hipGetLastError();
+        tl_tier_now = nullptr;
+    }
     return RR_OK;
 }
 hipStream_t rr_tier_stream(int k)
 {
     return tl_tier_now ? tl_tier_now->side[k] : nullptr;
 }
+// Always leaves the thread without a fork (also on an error, so that the
+// next launch starts clean); a side stream whose join could not be enqueued
+// is waited for on the host -- `st` must not run ahead of kernels that write
+// the same score vector.
 int rr_tier_join(hipStream_t st)
 {
-    if (!tl_tier_now) return RR_OK;
-    for (int k = 0; k < 3; ++k) {
-        RR_HIP(hipEventRecord(tl_tier_now->done[k], tl_tier_now->side[k]));
-        RR_HIP(hipStreamWaitEvent(st, tl_tier_now->done[k], 0));
-    }
+    TierStreams *const t = tl_tier_now;
     tl_tier_now = nullptr;
-    return RR_OK;
+    if (!t) return RR_OK;
+    int rc = RR_OK;
+    for (int k = 0; k < 3; ++k) {
+        if (hipEventRecord(t->done[k], t->side[k]) == hipSuccess &&
+            hipStreamWaitEvent(st, t->done[k], 0) == hipSuccess)
+            continue;
+        (void)hipGetLastError();
+        if (hipStreamSynchronize(t->side[k]) != hipSuccess) {
+            rr_set_error("rr_tier_join: side stream %d could not be joined", k);
+            rc = RR_E_HIP;
+        }
+    }
+    return rc;
 }
 
 // ---- the sets of a launch ordered by ceil(x4) -------------------------------

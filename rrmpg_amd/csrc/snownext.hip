@@ -298,7 +298,14 @@ snow_gr4j_kernel(
     const int64_t i = perm ? (int64_t)perm[g_set] : g_lane;
     const double *p = params + (perm ? i : g_set) * lay.npar;
     int n1cap, n2cap;
-    if (!gr4j_wave_selects<UH>(plan, force_lds, p[lay.i_x1 + 3], n1cap, n2cap))
+    // per-wave tiers only with the sets ordered (perm: the by-tier launch,
+    // whose tier kernels share the GPU on streams of their own); any other
+    // launch keeps the launch's tier -- one kernel does the work, the others
+    // return at once -- as before round 5: on ONE stream the tier kernels of
+    // a block that happens to be ordered by x4 would take turns
+    if (!(perm ? gr4j_wave_selects<UH>(plan, force_lds, p[lay.i_x1 + 3], n1cap,
+                                       n2cap)
+               : gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)))
         return;
     const double CTG = p[0], Kf = p[1];
     const double Rsp = HYST ? p[3] : 0.0;
@@ -777,10 +784,12 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     // stays on the caller's: a launch inside the default bounds of the plain
     // GR4J family runs as it always has): with the waves choosing their tiers
     // all of them have work, and they are to share the GPU, not to take turns
+    int join_rc = RR_OK;
     if (by_tier) {
         rc = rr_tier_fork(st);
         if (rc != RR_OK) return rc;
     }
+    // (no early return between the fork and the join inside dispatch_layers)
     dispatch_layers((int)L, [&](auto LL) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
@@ -796,7 +805,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
                          lay, N, d_plan, force_lds, qsim != nullptr,
                          G != nullptr, qo, sse, uh_mem, perm);
         });
-        if (by_tier) (void)rr_tier_join(st);
+        if (by_tier) join_rc = rr_tier_join(st);
         // ... and behind them the sets that are not civil
         // (gr4j_reference.h)
         snow_gr4j_reference_kernel<LL.value, HYST, ICE>
@@ -805,6 +814,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
                 thermal_state_init, sca_init, s_init, r_init, params, lay, N,
                 d_plan, qo ? sse : nullptr);
     });
+    if (join_rc != RR_OK) return join_rc;
     RR_HIP(hipGetLastError());
     return RR_OK;
 }
