@@ -95,11 +95,11 @@ def parse_args():
     ap.add_argument("--fused-variant", type=int, default=0,
                     help="measurement hook: pin the CemaneigeGR4J kernel "
                          "variant (RR_OPT_FUSED_VARIANT: 1 many-waves, "
-                         "2 small-sweep)")
+                         "2 small-sweep, 3 small-sweep optimistic)")
     ap.add_argument("--gr4j-variant", type=int, default=0,
                     help="measurement hook: pin the GR4J kernel variant "
-                         "(RR_OPT_GR4J_VARIANT: 1 one wave per 64 sets, "
-                         "2 wave-specialised)")
+                         "(RR_OPT_GR4J_VARIANT: 1 every vote decided on "
+                         "the spot)")
     ap.add_argument("--no-parity-spot", action="store_true")
     ap.add_argument("--no-power-soak", action="store_true",
                     help="skip the 2.5-s steady-state soak after the timed "

@@ -90,6 +90,8 @@ extern "C" {
 /* Cemaneige: up to this many elevation layers keep their snow states in
  * registers; more layers run through an HBM scratch (slower, same results). */
 #define RR_CEMANEIGE_MAX_LAYERS 8
+/* ... and the hysteresis / ice-melt couplings (next tier) up to this many */
+#define RR_SNOWNEXT_REG_LAYERS 5
 /* GR4J: largest x4 whose unit hydrographs (ceil(x4) ordinates for UH1,
  * ceil(2*x4+1) for UH2) live on chip -- registers up to 10, LDS up to this.
  * Longer ones run too, as in the reference, from a scratch in HBM behind the
@@ -171,9 +173,11 @@ int rr_comm_destroy(void *comm);
  * rr_debug_set_option / rr_call_options_set return RR_E_PARAM for an unknown
  * option or value; rr_debug_get_option returns the process-wide value (or
  * INT64_MIN for an unknown option). */
-#define RR_OPT_HBV_VARIANT     1 /* -1 heuristic (default); 0 one scalar load
-                                  * per day; 1 forcing staged in LDS; 2 next
-                                  * day's record prefetched                 */
+#define RR_OPT_HBV_VARIANT     1 /* -1 by sweep size (default); 0 the plain
+                                  * loop (one scalar record load at the top of
+                                  * each day; time-tiled for many waves); 3
+                                  * three records rotating, a day's record
+                                  * asked for two days ahead                 */
 #define RR_OPT_GR4J_FORCE_LDS  2 /* 0 (default) / 1: unit hydrographs in LDS
                                   * even where a register tier would do      */
 #define RR_OPT_MAX_BLOCK_COLS  3 /* 0 (default) = sized to free HBM; > 0 caps
@@ -188,20 +192,12 @@ int rr_comm_destroy(void *comm);
                                   * thresholds in VGPRs) wherever it exists; 3
                                   * the small-sweep kernel with an optimistic
                                   * GR4J half (votes noted, the half redone if
-                                  * one failed); 4 the many-waves kernel with
-                                  * an optimistic GR4J half; 5 (score-only
-                                  * sweeps) the two-wave pipeline: snow routine
-                                  * and GR4J day in two waves of a workgroup,
-                                  * an LDS ring between them                  */
+                                  * one failed)                              */
 #define RR_OPT_GR4J_VARIANT    6 /* GR4J kernel: 0 the library's choice
-                                  * (default: the optimistic kernel where it
-                                  * exists); 1 gr4j_kernel, one wave per 64
-                                  * sets, every vote decided on the spot; 2
-                                  * wave-specialised (production / routing
-                                  * halves of the day in two waves of a
-                                  * workgroup); 3 gr4j_kernel in workgroups of
-                                  * four waves; 4 optimistic (branch-free day,
-                                  * redone if a vote failed)                 */
+                                  * (default: the optimistic kernel --
+                                  * branch-free day, redone if a vote failed
+                                  * -- where it exists); 1 gr4j_kernel in
+                                  * every tier, every vote decided on the spot */
 #define RR_OPT_HOST_SHARDS     7 /* the host-pointer family (rr_<model>_simulate
                                   * [_opt]) over several GPUs inside ONE call
                                   * -- the `ndev` of the call: 0 / 1
@@ -504,7 +500,7 @@ int rr_sample_params_dev(uint64_t key, int k, const double *lo,
 /* ==== next tier: SWE-SCA hysteresis snow routine, ice melt, couplings ====
  * The reference's CemaneigeHystGR4J, CemaneigeGR4JIce, CemaneigeHystGR4JIce
  * (SURVEY.md section 8f N1).  Same conventions as above; any L >= 1 (more
- * than RR_CEMANEIGE_MAX_LAYERS layers run from an HBM state scratch that is
+ * than RR_SNOWNEXT_REG_LAYERS layers run from an HBM state scratch that is
  * part of the workspace, so size it with the N of the call);
  * `frac_ice` is [L]; sca is [T][L][ld]; icemelt, snowmelt are [T][ld]
  * (snowmelt = the snow routine's layer-mean outflow before the ice melt is

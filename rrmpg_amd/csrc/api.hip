@@ -63,10 +63,10 @@ int64_t rr_option(int option)
 static bool option_value_ok(int option, int64_t value)
 {
     switch (option) {
-    case RR_OPT_HBV_VARIANT: return value >= -1 && value <= 3;
+    case RR_OPT_HBV_VARIANT: return value == -1 || value == 0 || value == 3;
     case RR_OPT_GR4J_FORCE_LDS: return value == 0 || value == 1;
-    case RR_OPT_FUSED_VARIANT: return value >= 0 && value <= 5;
-    case RR_OPT_GR4J_VARIANT: return value >= 0 && value <= 4;
+    case RR_OPT_FUSED_VARIANT: return value >= 0 && value <= 3;
+    case RR_OPT_GR4J_VARIANT: return value == 0 || value == 1;
     case RR_OPT_MAX_BLOCK_COLS: return value >= 0;
     case RR_OPT_GATHER_THREADS: return value >= 0 && value <= 256;
     case RR_OPT_HOST_SHARDS: return value >= -1 && value <= 1024;

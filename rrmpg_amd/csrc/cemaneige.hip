@@ -263,20 +263,13 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
 // Small configurations (<= 5 layers, unit hydrographs in 3+7 registers or in
 // LDS) are held at 128 registers = 4 waves per SIMD: a handful of spills cost
 // less than the lost wave (137 -> 130 ms at L = 5).
-// (measurement switches: the many-waves kernel held to COUPLED_BIG_MINWAVES
-// waves per SIMD, and with its polynomial constants in VGPR pairs instead of
-// fetched at the point of use.  The kernel executes 38 lane moves a day --
-// scalar values parked in VGPR lanes -- at four waves per SIMD; round 5
-// measured what giving it registers instead costs: 1M sets, scores, 72.6 ms
-// as shipped, 78.1 at three waves per SIMD, 74.7 with the constants in VGPRs
-// as well, 73.1 for the optimistic many-waves form, 77.9 / 82.7 for the
-// small-sweep forms; profiles/r05_fused_forms_ab.txt)
-#ifndef COUPLED_BIG_MINWAVES
+// (The many-waves kernel executes 38 lane moves a day -- scalar values parked
+// in VGPR lanes -- at four waves per SIMD; round 5 measured what giving it
+// registers instead costs: 1M sets, scores, 72.6 ms as shipped, 78.1 at three
+// waves per SIMD, 74.7 with the constants in VGPRs as well, 73.1 for an
+// optimistic many-waves form, 77.9 / 82.7 for the small-sweep forms;
+// profiles/r05_fused_forms_ab.txt)
 #define COUPLED_BIG_MINWAVES 4
-#endif
-#ifndef COUPLED_BIG_VCONST
-#define COUPLED_BIG_VCONST 0
-#endif
 template <int L, class UH, bool SMALL = false>
 constexpr int coupled_min_waves()
 {
@@ -312,19 +305,10 @@ struct CoupledOut {
 typedef const CoupledOut __attribute__((address_space(4))) *coupled_out_ptr_t;
 
 typedef const double __attribute__((address_space(4))) *cema_rec_ptr_t;
-// TILED (register hydrograph tiers 3 and 5 only): the time axis in pieces,
-// one workgroup per ticket (common.h RrTiles: million-set sweeps); handed over:
-// the snow states, both stores, the hydrograph slots, the score sum.
-#ifndef COUPLED_FETCH_AT_TOP
-#define COUPLED_FETCH_AT_TOP 0
-#endif
-#ifndef COUPLED_TILED_MINWAVES
-#define COUPLED_TILED_MINWAVES 3
-#endif
-template <int L, class UH, bool SMALL = false, bool TILED = false>
-__global__ __launch_bounds__(
-    RR_BLOCK, (TILED ? COUPLED_TILED_MINWAVES
-                     : coupled_min_waves<L, UH, SMALL>())) void
+// (A time-tiled form of this kernel was measured slower -- 1M sets 89.8 -> 99.9
+// ms: 168 VGPRs, three waves per SIMD -- and removed in round 6.)
+template <int L, class UH, bool SMALL = false>
+__global__ __launch_bounds__(RR_BLOCK, (coupled_min_waves<L, UH, SMALL>())) void
 cemaneigegr4j_kernel(
     CoupledOut /* read through the kernarg segment, see above */,
     const double *__restrict__ days, const double *__restrict__ gtresh,
@@ -332,21 +316,14 @@ cemaneigegr4j_kernel(
     double s_init, double r_init, const double *__restrict__ params,
     int64_t N, const int *__restrict__ plan, int force_lds, int wq, int ws,
     const double *__restrict__ qobs, double *__restrict__ sse,
-    double *__restrict__ uh_mem, RrTiles tiles)
+    double *__restrict__ uh_mem, int warm)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
     if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
-    if (tiles.warm)
+    if (warm)
         rr_warm_l2(days, (T + 1) * (int64_t)cema_record_len(L, true) * 8);
-    int job = blockIdx.x, piece = 0;
-    const int njobs = TILED ? (int)((N + RR_BLOCK - 1) / RR_BLOCK) : 0;
-    if constexpr (TILED) {
-        const int item = rr_tile_ticket(tiles);
-        piece = __builtin_amdgcn_readfirstlane(item / njobs);
-        job = __builtin_amdgcn_readfirstlane(item - piece * njobs);
-    }
-    const int64_t i = (int64_t)job * RR_BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + threadIdx.x;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 6;
     const double CTG = p[0], Kf = p[1];
@@ -376,55 +353,14 @@ cemaneigegr4j_kernel(
     // shorter of SGPRs still, lose with it and keep the load at the top).
     CemaGtRegs<L> gt_regs;
     if constexpr (SMALL) cema_gt_to_regs<L>(gt_tab, gt_regs);
-    constexpr int CONSTS = (SMALL || (COUPLED_BIG_VCONST && !TILED &&
-                                      std::is_same<UH, UhRegs<3>>::value))
-                               ? GR4J_CONSTS_VGPR : GR4J_CONSTS_JIT;
+    constexpr int CONSTS = SMALL ? GR4J_CONSTS_VGPR : GR4J_CONSTS_JIT;
     const cema_rec_ptr_t drec = (cema_rec_ptr_t)days;
-    int64_t t_begin = 0, t_end = T;
-    double *const hand = TILED ? tiles.state + ((int64_t)job * RR_BLOCK +
-                                                threadIdx.x) : nullptr;
-    const int64_t hs = (int64_t)njobs * RR_BLOCK;
-    if constexpr (TILED) {
-        int b, e;
-        rr_tile_range(0, (int)T, tiles.pieces, piece, 1, b, e);
-        t_begin = b;
-        t_end = e;
-        if (piece > 0) {
-            rr_tile_wait(tiles, job, piece);
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                G[l] = hand[(2 * l) * hs];
-                eTG[l] = hand[(2 * l + 1) * hs];
-            }
-            s = hand[(2 * L) * hs];
-            r = hand[(2 * L + 1) * hs];
-            acc = hand[(2 * L + 2) * hs];
-#pragma unroll
-            for (int j = 0; j < UH::TIER; ++j)
-                uh.z.u1[j] = hand[(2 * L + 3 + j) * hs];
-#pragma unroll
-            for (int j = 0; j < UH::N2MAX; ++j)
-                uh.z.u2[j] = hand[(2 * L + 3 + UH::TIER + j) * hs];
-        }
-    }
     double day[D];
-    // (COUPLED_FETCH_AT_TOP: the many-waves kernel requests the day's record at
-    // the top of its own day -- a measurement switch)
-    constexpr bool FETCH_AT_TOP = COUPLED_FETCH_AT_TOP && !SMALL;
-    if constexpr (!FETCH_AT_TOP) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) day[k] = drec[t_begin * D + k];
-    }
+    for (int k = 0; k < D; ++k) day[k] = drec[k];
     // one day; `first` (a std::bool_constant) marks day 0, which is peeled
     // off the time loop
     auto one_day = [&](auto first, auto sane, int64_t t) {
-        if constexpr (FETCH_AT_TOP) {
-            cema_rec_ptr_t now =
-                drec + (int64_t)__builtin_amdgcn_readfirstlane((int)t) * D;
-            asm volatile("" : "+s"(now));
-#pragma unroll
-            for (int k = 0; k < D; ++k) day[k] = now[k];
-        }
         const double liquid =
             cema_day<L, decltype(first)::value, SMALL, decltype(sane)::value,
                      true>(
@@ -438,11 +374,8 @@ cemaneigegr4j_kernel(
 #pragma unroll
             for (int k = 0; k < D; ++k) day[k] = nx[k];
         };
-        double q;
-        if constexpr (FETCH_AT_TOP)
-            q = gr4j_step<UH, CONSTS>(P, s, r, uh, liquid, etp_t);
-        else
-            q = gr4j_step<UH, CONSTS>(P, s, r, uh, liquid, etp_t, fetch_next);
+        const double q =
+            gr4j_step<UH, CONSTS>(P, s, r, uh, liquid, etp_t, fetch_next);
         // (per-lane addresses here: row stores through a buffer descriptor,
         // as in cemaneige_kernel, cost this kernel 1.5-2.5 % -- four more
         // SGPRs it does not have)
@@ -473,52 +406,17 @@ cemaneigegr4j_kernel(
         }
     };
     // (two copies of the time loop, see cemaneige_kernel)
-    if constexpr (!TILED) {
-        if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
-                              thermal_state_init)) {
-            one_day(std::true_type{}, std::true_type{}, 0);
-            for (int64_t t = 1; t < T; ++t)
-                one_day(std::false_type{}, std::true_type{}, t);
-        } else {
-            one_day(std::true_type{}, std::false_type{}, 0);
-            for (int64_t t = 1; t < T; ++t)
-                one_day(std::false_type{}, std::false_type{}, t);
-        }
-        if (we && active) sse[i] = acc;
+    if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
+                          thermal_state_init)) {
+        one_day(std::true_type{}, std::true_type{}, 0);
+        for (int64_t t = 1; t < T; ++t)
+            one_day(std::false_type{}, std::true_type{}, t);
     } else {
-        // (a piece that starts at day 0 peels it; the others start mid-run)
-        const bool from_start = t_begin == 0 && t_begin < t_end;
-        const int64_t t1 = t_begin + (from_start ? 1 : 0);
-        if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
-                              thermal_state_init)) {
-            if (from_start) one_day(std::true_type{}, std::true_type{}, 0);
-            for (int64_t t = t1; t < t_end; ++t)
-                one_day(std::false_type{}, std::true_type{}, t);
-        } else {
-            if (from_start) one_day(std::true_type{}, std::false_type{}, 0);
-            for (int64_t t = t1; t < t_end; ++t)
-                one_day(std::false_type{}, std::false_type{}, t);
-        }
-        if (piece + 1 < tiles.pieces) {
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                hand[(2 * l) * hs] = G[l];
-                hand[(2 * l + 1) * hs] = eTG[l];
-            }
-            hand[(2 * L) * hs] = s;
-            hand[(2 * L + 1) * hs] = r;
-            hand[(2 * L + 2) * hs] = acc;
-#pragma unroll
-            for (int j = 0; j < UH::TIER; ++j)
-                hand[(2 * L + 3 + j) * hs] = uh.z.u1[j];
-#pragma unroll
-            for (int j = 0; j < UH::N2MAX; ++j)
-                hand[(2 * L + 3 + UH::TIER + j) * hs] = uh.z.u2[j];
-            rr_tile_publish(tiles, job, piece);
-        } else {
-            if (we && active) sse[i] = acc;
-        }
+        one_day(std::true_type{}, std::false_type{}, 0);
+        for (int64_t t = 1; t < T; ++t)
+            one_day(std::false_type{}, std::false_type{}, t);
     }
+    if (we && active) sse[i] = acc;
 }
 
 // ---- optimistic variant of the fused kernel -----------------------------------
@@ -545,19 +443,12 @@ constexpr bool coupled_has_optimistic()
                       std::is_same<UH, UhRegs<5>>::value);
 }
 
-// The optimistic fused kernels' production store in its wave-uniform form on
-// the days every lane of the wave agrees on wet / dry (one_day).  Measured
-// and left off: the vote and the second copy of the production store cost
-// what the selects did -- 1M sets 73.9 -> 74.3 ms, 125k 10.72 -> 11.12
-// (profiles/r04_uniform_wet_ab.txt).
-#ifndef COUPLED_UNIFORM_WET
-#define COUPLED_UNIFORM_WET 0
-#endif
-#ifndef COUPLED_OPT_MINWAVES
-#define COUPLED_OPT_MINWAVES 3
-#endif
-template <int L, class UH, bool SMALL>
-__global__ __launch_bounds__(RR_BLOCK, (SMALL ? 2 : COUPLED_OPT_MINWAVES)) void
+// The small-sweep form only (polynomial constants and melt thresholds in
+// VGPRs, two waves per SIMD): the many-waves form with an optimistic GR4J
+// half was measured slower than the careful kernel (97 vs 90 ms at a million
+// sets) and removed in round 6.
+template <int L, class UH>
+__global__ __launch_bounds__(RR_BLOCK, 2) void
 cemaneigegr4j_opt_kernel(
     CoupledOut /* read through the kernarg segment, see above */,
     const double *__restrict__ days, const double *__restrict__ gtresh,
@@ -592,8 +483,8 @@ cemaneigegr4j_opt_kernel(
     const bool we = sse != nullptr;
     constexpr int D = cema_record_len(L, true);
     CemaGtRegs<L> gt_regs;
-    if constexpr (SMALL) cema_gt_to_regs<L>(gt_tab, gt_regs);
-    constexpr int CONSTS = SMALL ? GR4J_CONSTS_VGPR : GR4J_CONSTS_JIT;
+    cema_gt_to_regs<L>(gt_tab, gt_regs);
+    constexpr int CONSTS = GR4J_CONSTS_VGPR;
     const cema_rec_ptr_t drec = (cema_rec_ptr_t)days;
     double day[D];
 #pragma unroll
@@ -604,7 +495,7 @@ cemaneigegr4j_opt_kernel(
     auto one_day = [&](auto first, auto sane, const Gen &in, Gen &out,
                        int64_t t) __attribute__((always_inline)) {
         const double liquid =
-            cema_day<L, decltype(first)::value, SMALL, decltype(sane)::value,
+            cema_day<L, decltype(first)::value, true, decltype(sane)::value,
                      true>(
                 day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
                 omc, Kf, G, eTG, &gt_regs);
@@ -625,28 +516,8 @@ cemaneigegr4j_opt_kernel(
         OptimisticVotes votes;
         double s = in.s, r = in.r;
         double p_r;
-#if COUPLED_UNIFORM_WET
-        // Most days every lane of a wave is on the same side of :89 (the
-        // evapotranspiration is shared, the snow routines' outflows differ
-        // by little): such a wave takes the production store's wave-uniform
-        // form (gr4j_core.h Gr4jUniformWet: one arm of the store's
-        // coefficients, masks for the outcome) instead of evaluating both
-        // arms and selecting per lane -- seven v_cndmask_b32 and as many
-        // v_mov_b32 of constants a day.  The same bits either way.
-        const lanemask_t wet_m = RR_LANES(wet);
-        if (wet_m == 0 || wet_m == rr_exec()) {
-            const Gr4jUniformWet uw = {wet_m != 0 ? 1 : 0};
-            p_r = gr4j_production<UH, CONSTS>(P, s, net, uw, net_m,
-                                              fetch_next, votes);
-        } else {
-            asm volatile("");                       // keep this a branch
-            p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
-                                              fetch_next, votes);
-        }
-#else
         p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
                                           fetch_next, votes);
-#endif
         double q = gr4j_routing<UH>(P, r, uh, in.u, out.u, p_r, votes);
         if (RR_VOTES_FAILED(votes)) {
             // some lane left a fast form's domain: the GR4J day again from
@@ -704,154 +575,11 @@ cemaneigegr4j_opt_kernel(
     if (we && active) sse[i] = acc;
 }
 
-// ---- the fused sweep as a pipeline of two waves (round 5) ---------------------
-// What makes the fused kernels hard on hipcc is that ONE wave carries both
-// halves of the day: the snow routine's record (3 L + 2 doubles in SGPRs, its
-// successor prefetched in the middle of the GR4J half) AND the GR4J half's
-// polynomial constants -- more scalar values than the 102 SGPRs hold, so the
-// constants are fetched from constant memory at their point of use (a scalar
-// load and a wait each, GR4J_CONSTS_JIT) and what still overflows is parked
-// in VGPR lanes (38 v_readlane / v_writelane a day in the many-waves kernel:
-// vector issue slots).  The day is feed-forward at one point -- the snow
-// routine's layer-mean outflow is the GR4J half's precipitation, nothing
-// flows back -- so a score-only sweep (no per-day output to keep the halves
-// together for) is cut there:
-//   * workgroups of TWO waves over the same 64 sets: wave 0 runs the snow
-//     routine (record in SGPRs, 2 L states), wave 1 the optimistic GR4J day
-//     (its constants at home in SGPRs, two generations of stores and
-//     hydrograph slots, the day's etp / qobs as one 16-byte scalar load);
-//   * the outflow travels through an LDS ring [2][K][64] (K = 8 days per
-//     half, 8 KiB a workgroup): the snow wave fills half b & 1 with block b's
-//     days and meets the GR4J wave at ONE barrier per K days; the GR4J wave
-//     works on block b while the snow wave is a block ahead.  (Half h is
-//     written again in block b + 2, behind the barrier that ended the GR4J
-//     wave's reading of block b.)
-// Twice the waves for the same arithmetic: at 125k sets a SIMD holds four
-// lighter waves instead of two heavy ones, and neither wave waits for the
-// other's scalar loads.  The same functions on the same values in the same
-// order as every other fused kernel: the same bits
-// (tests/test_gpu_fuzz.py test_kernel_variants_agree_bit_for_bit).
-#ifndef COUPLED_PIPE_DAYS
-#define COUPLED_PIPE_DAYS 8
-#endif
-#ifndef COUPLED_PIPE_MINWAVES
-#define COUPLED_PIPE_MINWAVES 4
-#endif
-template <int L, class UH>
-__global__ __launch_bounds__(2 * RR_BLOCK, COUPLED_PIPE_MINWAVES) void
-cemaneigegr4j_pipe_kernel(
-    const double *__restrict__ days, const double *__restrict__ gtresh,
-    int64_t T, double snow_pack_init, double thermal_state_init,
-    double s_init, double r_init, const double *__restrict__ params,
-    int64_t N, const int *__restrict__ plan, int force_lds,
-    double *__restrict__ sse, int warm)
-{
-    constexpr int K = COUPLED_PIPE_DAYS;
-    static_assert(K % 2 == 0, "the GR4J wave's two generations");
-    __shared__ double ring[2][K][RR_BLOCK];
-    int n1cap, n2cap;
-    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
-    constexpr int D = cema_record_len(L, true);
-    if (warm) rr_warm_l2(days, (T + 1) * (int64_t)D * 8);
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int lane = threadIdx.x & (RR_BLOCK - 1);
-    const int64_t i = (int64_t)blockIdx.x * RR_BLOCK + lane;
-    const bool active = i < N;
-    const double *p = params + (active ? i : N - 1) * 6;
-    const cema_rec_ptr_t drec = (cema_rec_ptr_t)days;
-    const int Ti = (int)T;
-    const int nblk = (Ti + K - 1) / K;
-    if (wave == 0) {
-        // ---- the snow routine, one block of K days ahead ----------------------
-        const double CTG = p[0], Kf = p[1];
-        const double omc = 1 - CTG;
-        double G[L], eTG[L];
-#pragma unroll
-        for (int l = 0; l < L; ++l) { G[l] = 0.0; eTG[l] = 0.0; }
-        const cema_gt_ptr_t gt_tab = (cema_gt_ptr_t)(gtresh + 2 * L);
-        const lanemask_t gt_ok = gtresh[4 * L] != 0.0 ? ~0ull : 0ull;
-        auto snow_day = [&](auto first, auto sane, int t)
-            __attribute__((always_inline)) {
-            double day[3 * L];   // by value: one wide scalar load per day
-            const cema_rec_ptr_t rec = drec + (int64_t)t * D;
-#pragma unroll
-            for (int k = 0; k < 3 * L; ++k) day[k] = rec[k];
-            return cema_day<L, decltype(first)::value, false,
-                            decltype(sane)::value>(
-                day, gt_tab, gt_ok, snow_pack_init, thermal_state_init, CTG,
-                omc, Kf, G, eTG, (const CemaGtRegs<L> *)nullptr);
-        };
-        auto run = [&](auto sane) __attribute__((always_inline)) {
-            // day 0 (peeled: the reference's t = 0 branch)
-            ring[0][0][lane] = snow_day(std::true_type{}, sane, 0);
-            for (int b = 0; b < nblk; ++b) {
-                double (*half)[RR_BLOCK] = ring[b & 1];
-                for (int k = (b == 0 ? 1 : 0); k < K; ++k) {
-                    const int t = b * K + k;
-                    if (t < Ti)
-                        half[k][lane] = snow_day(std::false_type{}, sane, t);
-                }
-                __syncthreads();        // block b is in the ring
-            }
-        };
-        // (two copies of the time loop, see cemaneige_kernel)
-        if (cema_wave_is_sane(gtresh, L, CTG, Kf, snow_pack_init,
-                              thermal_state_init))
-            run(std::true_type{});
-        else
-            run(std::false_type{});
-    } else {
-        // ---- the GR4J day, optimistic, two generations ------------------------
-        Gr4jPar P;
-        P.set(p[2], p[3], p[4], p[5]);
-        typedef Gr4jGen<UH> Gen;
-        Gen A, B;
-        UH uh;
-        uh.init(P.x4, A.u);
-        A.s = s_init * P.x1;
-        A.r = r_init * P.x3;
-        double acc = 0.0;
-        constexpr int CONSTS = GR4J_CONSTS_SGPR;
-        auto gr4j_day = [&](const Gen &in, Gen &out, int t, double liquid)
-            __attribute__((always_inline)) {
-            // the day's evapotranspiration and observation: the record's two
-            // trailing slots, one 16-byte scalar load
-            const cema_rec_ptr_t tail = drec + (int64_t)t * D + 3 * L;
-            const double etp_t = tail[0], qobs_t = tail[1];
-            const bool wet = liquid >= etp_t;               // gr4j_model.py:89
-            const double net = fabs(liquid - etp_t);        // :90, :102
-            const lanemask_t net_m = gr4j_num_lanes(net);
-            OptimisticVotes votes;
-            double s = in.s, r = in.r;
-            double p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m,
-                                                     Gr4jNoHook(), votes);
-            double q = gr4j_routing<UH>(P, r, uh, in.u, out.u, p_r, votes);
-            if (RR_VOTES_FAILED(votes)) {
-                // some lane left a fast form's domain: the day again from its
-                // untouched start state, every vote decided on the spot
-                asm volatile("");
-                s = in.s;
-                r = in.r;
-                p_r = gr4j_production<UH, CONSTS>(P, s, net, wet, net_m);
-                q = gr4j_routing<UH>(P, r, uh, in.u, out.u, p_r);
-            }
-            out.s = s;
-            out.r = r;
-            const double d = qobs_t - q;
-            acc = __builtin_fma(d, d, acc);
-        };
-        for (int b = 0; b < nblk; ++b) {
-            __syncthreads();            // block b has arrived
-            double (*half)[RR_BLOCK] = ring[b & 1];
-            for (int k = 0; k < K; k += 2) {
-                const int t = b * K + k;
-                if (t < Ti) gr4j_day(A, B, t, half[k][lane]);
-                if (t + 1 < Ti) gr4j_day(B, A, t + 1, half[k + 1][lane]);
-            }
-        }
-        if (active) sse[i] = acc;
-    }
-}
+// (A wave-specialised form -- snow routine and optimistic GR4J day in two
+// waves of a workgroup, the outflow through an LDS ring, 128 VGPRs, 0 lane
+// moves -- was built in round 5, is bit-identical and no faster: the fused day
+// is bound by the issue of its vector instructions, not by scalar loads or
+// lane moves.  Removed in round 6; profiles/r05_fused_pipe_ab.txt.)
 
 // ---- more than RR_CEMANEIGE_MAX_LAYERS elevation layers ----------------------
 // Same day step with a run-time layer count; the per-layer snow states live
@@ -983,7 +711,7 @@ int rr_cema_prepass(const double *prec, const double *mean_temp,
                         const double *frac, const double *etp,
                         const double *qobs, int64_t T, int L, void *workspace,
                         hipStream_t st, double **days_out, double **gt_out,
-                        double **state_out, int *uncivil)
+                        double **state_out, int *uncivil, int reg_layers)
 {
     const int D = cema_record_len(L, etp != nullptr);
     double *gt = (double *)((char *)workspace + 512);
@@ -998,7 +726,7 @@ int rr_cema_prepass(const double *prec, const double *mean_temp,
     hipLaunchKernelGGL(cema_gtresh, dim3((unsigned)L), dim3(256), 0, st, days,
                        T, D, gt);
     hipLaunchKernelGGL(cema_gt_table, dim3(1), dim3(1), 0, st, gt, L,
-                       L <= RR_CEMANEIGE_MAX_LAYERS ? L : 0);
+                       L <= reg_layers ? L : 0);
     *days_out = days;
     *gt_out = gt;
     *state_out = (double *)((char *)days + cema_days_bytes(T, L, etp != nullptr));
@@ -1330,100 +1058,46 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
         return RR_OK;
     }
     const CoupledOut out = {qsim, G, eTG, s_store, r_store, ld};
-    // at most two waves per SIMD: the small-sweep variant where there is one
-    // (1024 SIMDs on a whole MI355X)
-    const bool small = (int64_t)grid.x <= 2 * (int64_t)rr_simd_count() &&
-                       rr_option(RR_OPT_FUSED_VARIANT) != 1;
-    const int fv = (int)rr_option(RR_OPT_FUSED_VARIANT);
-    // time tiles (common.h RrTiles) for the many-waves kernel
+    // At most two waves per SIMD (1024 SIMDs on a whole MI355X; one GPU's
+    // shard of BASELINE configs[3], every `fit` population): the small-sweep
+    // forms where there is one -- optimistic GR4J half in the register
+    // hydrograph tiers 3 and 5 (125k sets 14.35 -> 13.96 ms) --, the
+    // many-waves kernel otherwise.  RR_OPT_FUSED_VARIANT pins one (tests: they
+    // agree bit for bit): 1 many-waves, 2 small-sweep careful, 3 small-sweep
+    // optimistic.
+    // (0: by sweep size; the setters accept 0..3 only)
+    const int64_t fv = rr_option(RR_OPT_FUSED_VARIANT);
+    const bool small = fv == 2 || fv == 3 ||
+                       (fv != 1 &&
+                        (int64_t)grid.x <= 2 * (int64_t)rr_simd_count());
     // (the day records -- 17 doubles a day -- prefetched into the XCDs' L2,
     // common.h rr_warm_l2: 65,536 sets, scores, 8.91 -> 7.71 ms; 125k 10.91
     // -> 10.82; a million unchanged, profiles/r05_warm_family_ab.txt)
-    RrTiles tiles = {nullptr, nullptr, 0,
-                     rr_warm_choice((int64_t)grid.x, rr_simd_count(),
-                                    qsim == nullptr && G == nullptr)};
-    {
-        const int64_t opt = rr_option(RR_OPT_TIME_TILES);
-        int pieces = 0;
-        // (only on request: measured SLOWER here, 1M sets 89.8 -> 99.9 ms --
-        // the tiled instantiation needs 168 VGPRs, three waves per SIMD, and
-        // 434 lane moves where the plain one has 125 / 270; held to four
-        // waves it spills to scratch, 136 ms)
-        if (T > 16 && !small && (fv == 0 || fv == 1) && opt > 1)
-            pieces = (int)opt;
-        if (pieces > 1) {
-            tiles.queue = (int *)((char *)workspace +
-                                  cema_tile_offset(T, L, true));
-            tiles.state = (double *)((char *)tiles.queue +
-                                     rr_tile_queue_bytes(N));
-            tiles.pieces = pieces;
-            RR_HIP(hipMemsetAsync(tiles.queue, 0, rr_tile_queue_bytes(N), st));
-        }
-    }
+    const int warm = rr_warm_choice((int64_t)grid.x, rr_simd_count(),
+                                    qsim == nullptr && G == nullptr);
     dispatch_layers((int)L, [&](auto LL) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
             const size_t lds = std::is_same<UH, UhLds>::value ? lds_bytes : 0;
             if constexpr (coupled_has_optimistic<LL.value, UH>()) {
-                // 5: the two-wave pipeline (score-only sweeps: nothing but
-                // the squared-error sums is written)
-                if (fv == 5 && !qsim && !G && qo) {
-                    cemaneigegr4j_pipe_kernel<LL.value, UH>
-                        <<<grid, dim3(2 * RR_BLOCK), 0, st>>>(
-                            days, gt, T, snow_pack_init, thermal_state_init,
-                            s_init, r_init, params, N, d_plan, force_lds, sse,
-                            tiles.warm);
-                    return;
-                }
-                // 3: small-sweep form with an optimistic GR4J half -- the
-                // default for at most two waves per SIMD (125k sets: 14.35 ->
-                // 13.96 ms) --, 4: many-waves form with one (measured slower
-                // than the careful kernel, 97 vs 90 ms at a million sets:
-                // kept for measurements and tests)
-                if (fv == 3 || fv == 4 || (fv == 0 && small)) {
-                    const bool sm = fv == 3 || (fv == 0 && small);
-#ifndef COUPLED_OPT_NO_SMALL
-                    if (sm)
-                        cemaneigegr4j_opt_kernel<LL.value, UH, true>
-                            <<<grid, block, 0, st>>>(
-                                out, days, gt, T, snow_pack_init,
-                                thermal_state_init, s_init, r_init, params, N,
-                                d_plan, force_lds, qsim != nullptr,
-                                G != nullptr, qo, sse, tiles.warm);
-#endif
-#ifndef COUPLED_OPT_NO_BIG
-                    if (!sm)
-                        cemaneigegr4j_opt_kernel<LL.value, UH, false>
-                            <<<grid, block, 0, st>>>(
-                                out, days, gt, T, snow_pack_init,
-                                thermal_state_init, s_init, r_init, params, N,
-                                d_plan, force_lds, qsim != nullptr,
-                                G != nullptr, qo, sse, tiles.warm);
-#endif
+                if (small && fv != 2) {
+                    cemaneigegr4j_opt_kernel<LL.value, UH>
+                        <<<grid, block, 0, st>>>(
+                            out, days, gt, T, snow_pack_init,
+                            thermal_state_init, s_init, r_init, params, N,
+                            d_plan, force_lds, qsim != nullptr, G != nullptr,
+                            qo, sse, warm);
                     return;
                 }
             }
             if constexpr (coupled_has_small<LL.value, UH>()) {
-                if (small || rr_option(RR_OPT_FUSED_VARIANT) == 2) {
+                if (small) {
                     cemaneigegr4j_kernel<LL.value, UH, true>
                         <<<grid, block, lds, st>>>(
                             out, days, gt, T, snow_pack_init,
                             thermal_state_init, s_init, r_init, params, N,
                             d_plan, force_lds, qsim != nullptr, G != nullptr,
-                            qo, sse, uh_mem, RrTiles{nullptr, nullptr, 0, tiles.warm});
-                    return;
-                }
-            }
-            if constexpr (std::is_same<UH, UhRegs<3>>::value ||
-                          std::is_same<UH, UhRegs<5>>::value) {
-                if (tiles.pieces > 1) {
-                    cemaneigegr4j_kernel<LL.value, UH, false, true>
-                        <<<dim3((unsigned)((int64_t)tiles.pieces * grid.x)),
-                           block, 0, st>>>(
-                            out, days, gt, T, snow_pack_init,
-                            thermal_state_init, s_init, r_init, params, N,
-                            d_plan, force_lds, qsim != nullptr, G != nullptr,
-                            qo, sse, uh_mem, tiles);
+                            qo, sse, uh_mem, warm);
                     return;
                 }
             }
@@ -1431,8 +1105,7 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                 <<<grid, block, lds, st>>>(
                     out, days, gt, T, snow_pack_init, thermal_state_init,
                     s_init, r_init, params, N, d_plan, force_lds,
-                    qsim != nullptr, G != nullptr, qo, sse, uh_mem,
-                    RrTiles{nullptr, nullptr, 0, tiles.warm});
+                    qsim != nullptr, G != nullptr, qo, sse, uh_mem, warm);
         });
         // ... and behind them the sets that are not civil
         // (gr4j_reference.h)

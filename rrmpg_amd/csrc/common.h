@@ -197,9 +197,6 @@ __device__ __forceinline__ double div_by_invariant_m(double a, lanemask_t a_ok,
 // 1.5 ulp for every numerator): the only thing to vote on is the divisor, a
 // loop invariant -- no compare per day.  Lanes whose divisor is outside
 // [2^-100, 2^100] take the IEEE division.
-#ifndef RR_FAITHFUL_QUOTIENTS
-#define RR_FAITHFUL_QUOTIENTS 1
-#endif
 template <class V = CarefulVotes>
 __device__ __forceinline__ double mul_by_inverse_m(double a,
                                                    const InvDivisor &d,
@@ -227,9 +224,6 @@ __device__ __forceinline__ double mul_by_inverse_m(double a,
 // plain stores the million-set sweeps that write qsim are a third slower
 // (HBV-Edu 19.2 -> 29.5 ms, 125k sets 2.78 -> 4.3: profiles/
 // r04_streaming_stores.txt); -DRR_OUT_NT=0 restores them.
-#ifndef RR_OUT_NT
-#define RR_OUT_NT 1
-#endif
 // cache-policy bits of the row stores (gfx94x / gfx950: 1 = sc0, 2 = nt,
 // 16 = sc1).  nt + sc1 measured against nt alone: HBV-Edu headline 19.55 ->
 // 19.18 ms, 125k sets 2.86 -> 2.82; nt + sc0 no different from nt
@@ -239,11 +233,7 @@ __device__ __forceinline__ double mul_by_inverse_m(double a,
 #endif
 __device__ __forceinline__ void rr_out(double *p, double v)
 {
-#if RR_OUT_NT
     __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
 }
 // two adjacent columns as one 16-byte store (p 16-byte aligned)
 typedef double rr_v2d __attribute__((ext_vector_type(2)));
@@ -252,16 +242,12 @@ __device__ __forceinline__ void rr_out2(double *p, double a, double b)
     rr_v2d v;
     v.x = a;
     v.y = b;
-#if RR_OUT_NT
     __builtin_nontemporal_store(v, reinterpret_cast<rr_v2d *>(p));
-#else
-    *reinterpret_cast<rr_v2d *>(p) = v;
-#endif
 }
 typedef int rr_v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void rr_store_row(double *row_base, unsigned bytes,
                                              int lane_byte_off, double v,
-                                             bool nontemporal = RR_OUT_NT != 0)
+                                             bool nontemporal = true)
 {
     // word 3: DATA_FORMAT = 32-bit, raw addressing (the value the compiler's
     // own buffer intrinsics use on gfx90a / gfx94x / gfx950)
@@ -289,7 +275,7 @@ __device__ __forceinline__ void rr_store_row(double *row_base, unsigned bytes,
 __device__ __forceinline__ void rr_store_row_at(double *row_base, unsigned bytes,
                                                 int lane_byte_off,
                                                 unsigned soffset, double v,
-                                                bool nontemporal = RR_OUT_NT != 0)
+                                                bool nontemporal = true)
 {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)row_base, (short)0, (int)(soffset + bytes), 0x00020000);

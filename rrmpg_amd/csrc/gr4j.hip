@@ -87,14 +87,8 @@ constexpr int gr4j_min_waves()
     return std::is_same<UH, UhRegs<3>>::value ? 5 : uh_is_indexed<UH> ? 6 : 2;
 }
 
-// WPG: waves per workgroup, each with its own 64 sets.  The dispatcher
-// balances workgroups over CUs, not waves over the four SIMDs of a CU
-// (profiles/ubench/wave_placement.hip: 1954 single-wave workgroups leave 108
-// SIMDs with three waves and 202 with one); the waves of ONE workgroup go to
-// different SIMDs, so groups of four waves fill every SIMD of their CU
-// evenly -- which decides the kernel time of a sweep of a few waves per SIMD.
-template <class UH, bool Q, bool S, bool E, int WPG = 1>
-__global__ __launch_bounds__(WPG * RR_BLOCK, (gr4j_min_waves<UH>() + WPG - 1) / WPG)
+template <class UH, bool Q, bool S, bool E>
+__global__ __launch_bounds__(RR_BLOCK, gr4j_min_waves<UH>())
 void gr4j_kernel(
     const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
     const double *__restrict__ params, int64_t N,
@@ -107,12 +101,8 @@ void gr4j_kernel(
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int n1cap, n2cap;
     if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
-    const int wave = (WPG == 1) ? 0
-        : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int lane = (WPG == 1) ? (int)threadIdx.x
-                                : ((int)threadIdx.x & (RR_BLOCK - 1));
-    const int64_t first = ((int64_t)blockIdx.x * WPG + wave) * RR_BLOCK;
-    if (WPG > 1 && first >= N) return;      // a wave beyond the sweep
+    const int lane = (int)threadIdx.x;
+    const int64_t first = (int64_t)blockIdx.x * RR_BLOCK;
     const int64_t i = first + lane;
     const bool active = i < N;
     const double *p = params + (active ? i : N - 1) * 4;
@@ -191,13 +181,9 @@ constexpr bool gr4j_has_optimistic()
            std::is_same<UH, UhRegs<5>>::value;
 }
 
-#ifndef GR4J_OPT_CONSTS
 #define GR4J_OPT_CONSTS GR4J_CONSTS_SGPR
-#endif
-#ifndef GR4J_OPT_MINWAVES
 #define GR4J_OPT_MINWAVES (std::is_same<UH, UhRegs<3>>::value ? 4 : 3)
-#endif
-// TILED: the time axis in pieces pulled from a work queue by persistent waves
+// TILED: the time axis in pieces handed out by a ticket counter
 // (common.h RrTiles: million-set sweeps); handed over: both stores, the
 // hydrograph slots, the score sum.  Pieces hold an even number of days, so
 // every piece starts in the same state generation.
@@ -207,10 +193,8 @@ constexpr int gr4j_tile_states()
     return 3 + UH::TIER + (2 * UH::TIER + 1);       // s, r, acc + slots
 }
 
-// TILED: 0 no, 1 one workgroup per item (the item: a ticket from the queue's
-// counter), 2 persistent waves drawing tickets until none is left (the job /
-// piece of an item kept explicitly scalar).
-template <class UH, bool Q, bool S, bool E, int TILED = 0>
+// TILED: one workgroup per item (the item: a ticket from the queue's counter).
+template <class UH, bool Q, bool S, bool E, bool TILED = false>
 __global__ __launch_bounds__(RR_BLOCK, GR4J_OPT_MINWAVES)
 void gr4j_opt_kernel(
     const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
@@ -226,21 +210,13 @@ void gr4j_opt_kernel(
     typedef const GrDay __attribute__((address_space(4))) *day_ptr_t;
     const day_ptr_t dp = (day_ptr_t)days;
     if (tiles.warm) rr_warm_l2(days, T * (int64_t)sizeof(GrDay));
-    // (TILED == 1: one single-wave workgroup per item, the item a ticket
-    // drawn when the wave starts -- common.h "the time axis in pieces";
-    // TILED == 2, the persistent loop around this kernel's two-generation
-    // day, is kept as a measurement variant: it costs scratch spills)
-  for (;;) {
+    // (TILED: one single-wave workgroup per item, the item a ticket drawn
+    // when the wave starts -- common.h "the time axis in pieces"; a
+    // persistent loop around this kernel's two-generation day cost scratch
+    // spills)
     int job = blockIdx.x, piece = 0;
-    if constexpr (TILED == 1) {
+    if constexpr (TILED) {
         const int item = rr_tile_ticket(tiles);
-        piece = __builtin_amdgcn_readfirstlane(item / njobs);
-        job = __builtin_amdgcn_readfirstlane(item - piece * njobs);
-    } else if constexpr (TILED == 2) {
-        int item = 0;
-        if (threadIdx.x == 0) item = atomicAdd(tiles.queue, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= tiles.pieces * njobs) break;
         piece = __builtin_amdgcn_readfirstlane(item / njobs);
         job = __builtin_amdgcn_readfirstlane(item - piece * njobs);
     }
@@ -260,10 +236,10 @@ void gr4j_opt_kernel(
     const int64_t first = (int64_t)job * RR_BLOCK;
     const unsigned row_bytes = rr_row_bytes(first, N);
     int k_begin = 0, k_end = (int)T;
-    double *const hand = TILED != 0 ? tiles.state + ((int64_t)job * RR_BLOCK +
+    double *const hand = TILED ? tiles.state + ((int64_t)job * RR_BLOCK +
                                                 threadIdx.x) : nullptr;
     const int64_t hs = (int64_t)njobs * RR_BLOCK;
-    if constexpr (TILED != 0) {
+    if constexpr (TILED) {
         rr_tile_range(0, (int)T, tiles.pieces, piece, 2, k_begin, k_end);
         if (piece > 0) {
             rr_tile_wait(tiles, job, piece);
@@ -338,7 +314,7 @@ void gr4j_opt_kernel(
         day(fa, fb, sa, ra, ua, sb, rb, ub, k);
         if (k + 1 < k_end) day(fb, fa, sb, rb, ub, sa, ra, ua, k + 1);
     }
-    if (TILED != 0 && piece + 1 < tiles.pieces) {
+    if (TILED && piece + 1 < tiles.pieces) {
         // (an even number of days: the states are back in generation a)
         hand[0] = sa;
         hand[hs] = ra;
@@ -353,156 +329,14 @@ void gr4j_opt_kernel(
         if (E && active) sse[i] = acc;
     }
     }
-    if constexpr (TILED != 2) break;
-  }
 }
 
-// ---- wave-specialised variant: the day's two halves in two waves ------------
-// A sweep of at most a few waves per SIMD (one GPU's shard of a strong-scaled
-// sweep, every `fit` population) cannot fill the fp64 pipe with one wave per
-// 64 sets: a lone wave issues an instruction every 5.5 cycles, two every 4.6,
-// and nothing hides their scalar work and branches.  GR4J's day is
-// feed-forward between its halves (gr4j_core.h gr4j_production /
-// gr4j_routing), so a workgroup of TWO waves serves 64 sets: one wave runs the
-// production stores of days [bK, (b+1)K) while the other routes the amounts of
-// the block before, which it finds in an LDS ring [2][K][64]; one s_barrier
-// per K days is the whole synchronisation.  Twice the waves for the same
-// arithmetic, half the dependent chain per wave; results bit-identical to
-// gr4j_kernel (the same two functions, the same order).
-#ifndef GR4J_PIPE_DAYS
-#define GR4J_PIPE_DAYS 8
-#endif
-__device__ __forceinline__ void rr_lds_release_barrier()
-{
-    // LDS writes of this wave done, then the workgroup barrier; the "memory"
-    // clobber keeps the compiler's LDS accesses on their side of it.  (Not
-    // __syncthreads(): its fence would also wait for the row stores.)
-#ifdef GR4J_PIPE_NOSYNC
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
-
-template <class UH>
-constexpr bool gr4j_has_pipe()
-{
-    return std::is_same<UH, UhRegs<3>>::value ||
-           std::is_same<UH, UhRegs<5>>::value;
-}
-
-#define GR4J_PIPE_PAIRS 2      // pairs of waves per workgroup (4 waves: one
-                               // per SIMD of the CU, see gr4j_kernel's WPG)
-template <class UH, bool Q, bool S, bool E>
-__global__ __launch_bounds__(2 * GR4J_PIPE_PAIRS * RR_BLOCK) void
-gr4j_pipe_kernel(
-    const GrDay *__restrict__ days, int64_t T, double s_init, double r_init,
-    const double *__restrict__ params, int64_t N,
-    const int *__restrict__ plan, int force_lds,
-    double *__restrict__ qsim, double *__restrict__ s_store,
-    double *__restrict__ r_store, int64_t ld,
-    const double *__restrict__ qobs, double *__restrict__ sse)
-{
-    constexpr int K = GR4J_PIPE_DAYS;
-    __shared__ double rings[GR4J_PIPE_PAIRS][2][K][RR_BLOCK];
-    int n1cap, n2cap;
-    if (!gr4j_plan_selects<UH>(plan, force_lds, n1cap, n2cap)) return;
-    const int lane = threadIdx.x & (RR_BLOCK - 1);
-    // wave w of the group: pair w % PAIRS; which half it runs alternates with
-    // the workgroup so that the heavier half does not always land on the same
-    // SIMDs of a CU
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = wave % GR4J_PIPE_PAIRS;
-    const bool producer =
-        (((wave / GR4J_PIPE_PAIRS) ^ (int)blockIdx.x) & 1) == 0;
-    double (*ring)[K][RR_BLOCK] = rings[pair];
-    const int64_t first =
-        ((int64_t)blockIdx.x * GR4J_PIPE_PAIRS + pair) * RR_BLOCK;
-    // (a pair beyond the sweep still takes part in the barriers: it runs on
-    // set N - 1 and stores nothing)
-    const int64_t i = first + lane;
-    const bool active = i < N;
-    const double *p = params + (active ? i : N - 1) * 4;
-    const int lane_off = lane * 8;
-    const unsigned row_bytes = rr_row_bytes(first, N);
-    typedef const GrDay __attribute__((address_space(4))) *day_ptr_t;
-    const day_ptr_t dp = (day_ptr_t)days;
-    const int64_t nblk = (T + K - 1) / K;
-    if (producer) {
-        Gr4jPar P;
-        P.set(p[0], p[1], p[2], p[3]);
-        double s = s_init * P.x1;   // gr4j_model.py:64
-        GrDay f;
-        f.net = dp[0].net; f.wet = dp[0].wet; f.net_ok = dp[0].net_ok;
-        int64_t row = first;
-        for (int64_t b = 0; b < nblk; ++b) {
-            double *half = &ring[b & 1][0][lane];
-#pragma unroll 1
-            for (int d = 0; d < K; ++d) {
-                const int64_t k = b * K + d;
-                if (k < T) {
-                    const double net = f.net;
-                    const bool wet = f.wet != 0;
-                    const lanemask_t net_m = f.net_ok ? ~0ull : 0ull;
-                    auto fetch_next = [&]() {
-                        day_ptr_t nx = dp + (k + 1);
-                        asm volatile("" : "+s"(nx));
-                        f.net = nx->net; f.wet = nx->wet;
-                        f.net_ok = nx->net_ok;
-                    };
-                    half[d * RR_BLOCK] =
-                        gr4j_production<UH, GR4J_CONSTS_SGPR>(
-                            P, s, net, wet, net_m, fetch_next);
-                    if (S) rr_store_row(s_store + row, row_bytes, lane_off, s);
-                    row += ld;
-                }
-            }
-            rr_lds_release_barrier();
-        }
-        rr_lds_release_barrier();       // (the consumer's last block)
-    } else {
-        Gr4jPar P;
-        P.set(p[0], p[1], p[2], p[3]);
-        UH uh;
-        uh.init(P.x4);
-        double r = r_init * P.x3;   // gr4j_model.py:65
-        double acc = 0.0;
-        int64_t row = first;
-        rr_lds_release_barrier();       // (the producer's first block)
-        // the routed amount and the observation of day k + 1 are requested
-        // while day k is worked on (LDS and scalar-cache latencies would
-        // otherwise be sat out once per day)
-        double p_next = ring[0][0][lane];
-        double qobs_next = dp[0].qobs;
-        for (int64_t b = 0; b < nblk; ++b) {
-            const double *half = &ring[b & 1][0][lane];
-#pragma unroll 1
-            for (int d = 0; d < K; ++d) {
-                const int64_t k = b * K + d;
-                if (k < T) {
-                    const double p_r = p_next, qobs_k = qobs_next;
-                    if (d + 1 < K) p_next = half[(d + 1) * RR_BLOCK];
-                    {
-                        day_ptr_t nx = dp + (k + 1);   // (spare record at T)
-                        asm volatile("" : "+s"(nx));
-                        qobs_next = nx->qobs;
-                    }
-                    const double q = gr4j_routing<UH>(P, r, uh, p_r);
-                    if (Q) rr_store_row(qsim + row, row_bytes, lane_off, q);
-                    if (S) rr_store_row(r_store + row, row_bytes, lane_off, r);
-                    if (E) {
-                        const double dq = qobs_k - q;
-                        acc = __builtin_fma(dq, dq, acc);
-                    }
-                    row += ld;
-                }
-            }
-            rr_lds_release_barrier();
-            p_next = ring[(b + 1) & 1][0][lane];
-        }
-        if (E && active) sse[i] = acc;
-    }
-}
+// (A wave-specialised variant -- the day's production and routing halves in
+// two waves of a workgroup, an LDS ring between them -- was built in round 3:
+// bit-identical, it wins at one wave per SIMD only and moves nothing at two
+// (125k sets).  Removed in round 6 together with gr4j_kernel in workgroups of
+// four waves and the persistent-wave form of the tiled optimistic kernel;
+// their A/B tables: profiles/README.md.)
 
 // ---- the reference's own sequence for the sets that are not civil ---------
 // (gr4j_reference.h)  One lane per set, launched behind the fast kernels;
@@ -551,9 +385,6 @@ static size_t gr4j_days_bytes(int64_t T)
 }
 // ... + the tiled kernels' work queue and hand-over scratch (common.h RrTiles)
 #define GR4J_TILE_STATES (gr4j_tile_states<UhRegs<5>>())
-#ifndef GR4J_TILE_MODE
-#define GR4J_TILE_MODE 1   // 1 one workgroup per ticket, 2 persistent waves
-#endif
 extern "C" size_t rr_gr4j_workspace_bytes(int64_t T, int64_t N)
 {
     return gr4j_days_bytes(T) + rr_tile_bytes(N, GR4J_TILE_STATES);
@@ -837,9 +668,11 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     const bool q = qsim != nullptr, s = s_store != nullptr, e = qobs && sse;
     const int force_lds = (int)rr_option(RR_OPT_GR4J_FORCE_LDS);
     // every tier is enqueued; the kernels pick the one the plan selects
-    const int variant = (int)rr_option(RR_OPT_GR4J_VARIANT);
+    // (RR_OPT_GR4J_VARIANT 1: gr4j_kernel, every vote decided on the spot, in
+    // the tiers that have the optimistic kernel too -- tests: the same bits)
+    const bool careful = rr_option(RR_OPT_GR4J_VARIANT) == 1;
     const int64_t waves = rr_ceil_div(N, RR_BLOCK);
-    // time-tiled persistent form of the optimistic kernel (common.h RrTiles)
+    // time tiles of the optimistic kernel (common.h RrTiles)
     // (the day records prefetched into the XCDs' L2, common.h rr_warm_l2:
     // only on request -- GR4J's day is issue-bound and its record asked for a
     // day and a half ahead: 65,536 sets 3.66 / 3.64 ms without / with,
@@ -850,7 +683,7 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
     {
         const int64_t opt = rr_option(RR_OPT_TIME_TILES);
         int pieces = 0;
-        if ((variant == 0 || variant == 4) && T > 16) {
+        if (!careful && T > 16) {
             if (opt > 1) pieces = (int)opt;
             else if (opt < 0 && waves > 6 * (int64_t)rr_simd_count()) pieces = 4;
         }
@@ -867,49 +700,18 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
             using UH = decltype(uh);
             constexpr size_t lds =
                 std::is_same<UH, UhLds>::value ? GR4J_LDS_BYTES : 0;
-            if constexpr (gr4j_has_pipe<UH>()) {
-                if (variant == 2) {
-                    gr4j_pipe_kernel<UH, Q.value, S.value, E.value>
-                        <<<dim3((unsigned)rr_ceil_div(waves, GR4J_PIPE_PAIRS)),
-                           dim3(2 * GR4J_PIPE_PAIRS * RR_BLOCK), 0, st>>>(
-                            days, T, s_init, r_init, params, N, d_plan,
-                            force_lds, qsim, s_store, r_store, ld, qobs, sse);
-                    return;
-                }
-            }
             if constexpr (gr4j_has_optimistic<UH>()) {
                 // (the default wherever it exists: faster at every sweep
                 // size, by 1-2 % at a million sets and 8-15 % at one or two
                 // waves per SIMD)
-                if (variant == 4 || variant == 0) {
-                    if (tiles.pieces > 1 && GR4J_TILE_MODE == 2) {
-                        auto kern = gr4j_opt_kernel<UH, Q.value, S.value,
-                                                    E.value, 2>;
-                        int per_cu = 0;
-                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                &per_cu, kern, RR_BLOCK, 0) != hipSuccess ||
-                            per_cu < 1) {
-                            (void)hipGetLastError();
-                            per_cu = 12;
-                        }
-                        int64_t resident =
-                            (int64_t)per_cu * (rr_simd_count() / 4);
-                        if (resident > tiles.pieces * waves)
-                            resident = tiles.pieces * waves;
-                        kern<<<dim3((unsigned)resident), block, 0, st>>>(
-                            days, T, s_init, r_init, params, N, d_plan,
-                            force_lds, qsim, s_store, r_store, ld, qobs, sse,
-                            tiles);
-                        return;
-                    }
+                if (!careful) {
                     if (tiles.pieces > 1) {
-                        auto kern = gr4j_opt_kernel<UH, Q.value, S.value,
-                                                    E.value, 1>;
-                        kern<<<dim3((unsigned)(tiles.pieces * waves)), block,
+                        gr4j_opt_kernel<UH, Q.value, S.value, E.value, true>
+                            <<<dim3((unsigned)(tiles.pieces * waves)), block,
                                0, st>>>(
-                            days, T, s_init, r_init, params, N, d_plan,
-                            force_lds, qsim, s_store, r_store, ld, qobs, sse,
-                            tiles);
+                                days, T, s_init, r_init, params, N, d_plan,
+                                force_lds, qsim, s_store, r_store, ld, qobs,
+                                sse, tiles);
                         return;
                     }
                     gr4j_opt_kernel<UH, Q.value, S.value, E.value>
@@ -917,17 +719,6 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
                             days, T, s_init, r_init, params, N, d_plan,
                             force_lds, qsim, s_store, r_store, ld, qobs, sse,
                             tiles);
-                    return;
-                }
-            }
-            if constexpr (!uh_is_indexed<UH>) {
-                if (variant == 3) {
-                    gr4j_kernel<UH, Q.value, S.value, E.value, 4>
-                        <<<dim3((unsigned)rr_ceil_div(waves, 4)),
-                           dim3(4 * RR_BLOCK), 0, st>>>(
-                            days, T, s_init, r_init, params, N, d_plan,
-                            force_lds, qsim, s_store, r_store, ld, qobs, sse,
-                            uh_mem);
                     return;
                 }
             }

@@ -33,16 +33,8 @@
 // of the routed amount (gr4j_model.py:126-127), and the two store updates
 // x - x (1 - y) are taken as x y.  -DRR_GR4J_CONTRACT=0 builds the
 // reference's own sequence.
-#ifndef RR_GR4J_CONTRACT
-#define RR_GR4J_CONTRACT 1
-#endif
-#ifndef RR_GR4J_TANH_RATIONAL
-#define RR_GR4J_TANH_RATIONAL 1
-#endif
-#if RR_GR4J_CONTRACT
 #define GR4J_UH1_SHARE 0.9
 #define GR4J_UH2_SHARE 0.1
-#endif
 
 struct Gr4jPar {
     double x1, x2, x3, x4;
@@ -95,25 +87,14 @@ __device__ __forceinline__ lanemask_t gr4j_num_mask(double a)
 // bit set, NaN, inf and anything >= 2^196 are above the bound).  The
 // per-lane choice in the slow path uses the same test, so a set's result
 // never depends on its wave neighbours.
-#ifndef RR_GR4J_STRICT_VOTES
-#define RR_GR4J_STRICT_VOTES 0
-#endif
 #define GR4J_NUM_HI_WORD 0x4C300000u        // high word of 2^196
 __device__ __forceinline__ bool gr4j_num_ok(double a)
 {
-#if RR_GR4J_STRICT_VOTES
-    return inv_div_numerator_ok0(a) && fabs(a) <= GR4J_NUM_HI;
-#else
     return (unsigned)__double2hiint(a) < GR4J_NUM_HI_WORD;
-#endif
 }
 __device__ __forceinline__ lanemask_t gr4j_num_lanes(double a)
 {
-#if RR_GR4J_STRICT_VOTES
-    return gr4j_num_mask(a);
-#else
     return RR_LANES((unsigned)__double2hiint(a) < GR4J_NUM_HI_WORD);
-#endif
 }
 
 // a / x for the per-lane invariant x; stores run dry, so exact zeros stay on
@@ -123,28 +104,14 @@ __device__ __forceinline__ double gr4j_div_m(double a, lanemask_t a_ok,
                                              const InvDivisor &d,
                                              lanemask_t d_ok, V &&votes = V())
 {
-#if RR_FAITHFUL_QUOTIENTS
     (void)a_ok;
     return mul_by_inverse_m(a, d, d_ok, votes);
-#else
-    double q = inv_div_core(a, d);
-    if (RR_VOTE(votes, a_ok & d_ok)) {
-        const bool ok = gr4j_num_ok(a) && d.ok;
-        const double exact = a / d.b;
-        q = ok ? q : exact;
-    }
-    return q;
-#endif
 }
 template <class V = CarefulVotes>
 __device__ __forceinline__ double gr4j_div(double a, const InvDivisor &d,
                                            lanemask_t d_ok, V &&votes = V())
 {
-#if RR_FAITHFUL_QUOTIENTS
     return mul_by_inverse_m(a, d, d_ok, votes);
-#else
-    return gr4j_div_m(a, gr4j_num_lanes(a), d, d_ok, votes);
-#endif
 }
 
 // _s_curve1 (gr4j_model.py:159-173); t is the integer ordinate index
@@ -216,11 +183,7 @@ struct UhRegs {
 #pragma unroll
         for (int j = 0; j < N1MAX; ++j) {
             const double cur = gr4j_s_curve1(j + 1, x4);
-#if RR_GR4J_CONTRACT
             o1[j] = (j < n1) ? GR4J_UH1_SHARE * (cur - prev) : 0.0;
-#else
-            o1[j] = (j < n1) ? cur - prev : 0.0;
-#endif
             prev = cur;
             u.u1[j] = 0.0;
         }
@@ -228,11 +191,7 @@ struct UhRegs {
 #pragma unroll
         for (int j = 0; j < N2MAX; ++j) {
             const double cur = gr4j_s_curve2(j + 1, x4);
-#if RR_GR4J_CONTRACT
             o2[j] = (j < n2) ? GR4J_UH2_SHARE * (cur - prev) : 0.0;
-#else
-            o2[j] = (j < n2) ? cur - prev : 0.0;
-#endif
             prev = cur;
             u.u2[j] = 0.0;
         }
@@ -359,22 +318,14 @@ struct UhIndexed {
         double prev = 0.0;
         for (int j = 0; j < n1w; ++j) {
             const double cur = gr4j_s_curve1(j + 1, x4);
-#if RR_GR4J_CONTRACT
             O1(j) = GR4J_UH1_SHARE * (cur - prev);
-#else
-            O1(j) = cur - prev;
-#endif
             prev = cur;
             U1(j) = 0.0;
         }
         prev = 0.0;
         for (int j = 0; j < n2w; ++j) {
             const double cur = gr4j_s_curve2(j + 1, x4);
-#if RR_GR4J_CONTRACT
             O2(j) = GR4J_UH2_SHARE * (cur - prev);
-#else
-            O2(j) = cur - prev;
-#endif
             prev = cur;
             U2(j) = 0.0;
         }
@@ -607,12 +558,9 @@ enum { GR4J_CONSTS_SGPR = 0, GR4J_CONSTS_VGPR = 1, GR4J_CONSTS_JIT = 2,
        // 165 -> 181) where every other kernel gains 3-11 %
        GR4J_CONSTS_JIT_EXP = 3 };
 
-#ifndef RR_R4_POLY
-#define RR_R4_POLY 1        // measurement switch: 0 = Newton form everywhere
-#endif
 // (every tier: a set's bits must not depend on which tier its launch runs)
 template <class UH>
-constexpr bool RR_R4_POLY_ENABLED = RR_R4_POLY != 0;
+constexpr bool RR_R4_POLY_ENABLED = true;
 template <class UH, int CONSTS>
 constexpr int gr4j_r4_consts()
 {
@@ -666,11 +614,7 @@ __device__ __forceinline__ void gr4j_store_coefficients(bool wet, double s,
                                                         double &c, double &k)
 {
     if (wet) {
-#if RR_GR4J_CONTRACT
         c = x1 * __builtin_fma(-sx, sx, 1.0);
-#else
-        c = x1 * (1 - sx * sx);
-#endif
         k = sx;
     } else {
         c = s * (2 - sx);
@@ -725,9 +669,6 @@ struct Gr4jUniformWet { int word; };
 // gr4j_step (the coupled kernels' day) can look for such days itself.
 // Measured and left off: hysteresis 147.1 -> 145.8 ms, ice melt 87.0 -> 88.7
 // (profiles/r04_uniform_wet_ab.txt).
-#ifndef GR4J_STEP_UNIFORM_WET
-#define GR4J_STEP_UNIFORM_WET 0
-#endif
 // ANY_FORCING: the kernel has no one-lane reference kernel behind it that
 // would redo a launch with a non-finite forcing value (the kernels for more
 // than RR_CEMANEIGE_MAX_LAYERS layers; the HBM-scratch tier, UhMem, always):
@@ -754,7 +695,7 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
         wet = wet_arg;
     }
     constexpr bool rational_tanh =
-        RR_GR4J_TANH_RATIONAL && CONSTS_ != GR4J_CONSTS_JIT_EXP;
+        CONSTS_ != GR4J_CONSTS_JIT_EXP;
     constexpr int CONSTS =
         CONSTS_ == GR4J_CONSTS_JIT_EXP ? (int)GR4J_CONSTS_JIT : CONSTS_;
     // tanh(net/x1) = E / D (fastmath.h: E = expm1(2a)/2, D = E + 1); its
@@ -786,13 +727,8 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     // away from zero: D + k*E >= 1 whenever 0 <= s <= x1, anything else is
     // voted out.  Any other lane sends the wave through the reference's own
     // sequence (IEEE quotient, two divisions).
-#if RR_FAITHFUL_QUOTIENTS
     const double sx = inv_mul_core(s, P.inv_x1);
-#else
-    const double sx = inv_div_core(s, P.inv_x1);
-#endif
     double c, k, den;
-#if RR_GR4J_CONTRACT
     if constexpr (uniform_wet) {
         // (the denominator inside the day's own arm of the wave-uniform
         // branch: joined behind it, k = sx / k = 1 - sx costs the wet arm a
@@ -810,10 +746,6 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
         gr4j_store_coefficients(wet, s, P.x1, sx, c, k);
         den = __builtin_fma(k, E, D);
     }
-#else
-    gr4j_store_coefficients(wet, s, P.x1, sx, c, k);
-    den = D + k * E;
-#endif
     (void)k;
     const lanemask_t fast = gr4j_num_lanes(s) & P.x1_m & a_small &
                             RR_LANES(fabs(den) >= 0x1p-100);
@@ -900,11 +832,7 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     // sane run, but the difference between r == 0 and r > 0 for a routing
     // store with a negative x3, whose exchange term is 0 in one case and NaN
     // in the other (found by the fuzz soak).  The subtraction is exact.
-#if RR_GR4J_CONTRACT
     const double b1 = __builtin_fma(v2, v2, 1.0);
-#else
-    const double b1 = 1 + v2 * v2;
-#endif
     double root;
     if constexpr (RR_R4_POLY_ENABLED<UH>) {
         const double u = b1 - 1;
@@ -918,17 +846,11 @@ __device__ __forceinline__ double gr4j_production(const Gr4jPar &P, double &s,
     } else {
         root = gr4j_inv_fourth_root<by_vote>(b1, votes);
     }
-#if RR_GR4J_CONTRACT
     // :117, :120: the store keeps sn * root and percolates the rest
     const double kept = sn * root;
     const double perc = sn - kept;
     mid();
     s = kept;
-#else
-    const double perc = sn * (1 - root);
-    mid();
-    s = sn - perc;                                              // :120
-#endif
     if constexpr (any_forcing) return perc + excess;            // p_r, :123
     return __builtin_fma(excess, keep_excess, perc);
 }
@@ -943,12 +865,7 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
                                                double p_r, V &&votes = V())
 {
     constexpr bool by_vote = true;    // (the same forms in every tier)
-#if RR_GR4J_CONTRACT
     const double p_r_uh1 = p_r, p_r_uh2 = p_r;  // (the ordinates carry the split)
-#else
-    const double p_r_uh1 = 0.9 * p_r;                           // :126-127
-    const double p_r_uh2 = 0.1 * p_r;
-#endif
 
     double head1, head2;
     if constexpr (uh_is_indexed<UH>)
@@ -956,7 +873,6 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
     else
         uh.route(in, out, p_r_uh1, p_r_uh2, head1, head2, votes);
 
-#if RR_GR4J_CONTRACT
     // (the exchange term x2 * (r/x3)**3.5 goes into the two sums that take
     // it as a fused multiply-add, and so do the squares under the roots:
     // one rounding where the reference has two)
@@ -972,18 +888,6 @@ __device__ __forceinline__ double gr4j_routing(const Gr4jPar &P, double &r,
     const double q_r = rn - kept;
     rn = kept;
     const double q_d = nb_max(0.0, __builtin_fma(P.x2, p35, head2)); // :151
-#else
-    const double gw_exchange =
-        P.x2 * pow_3_5<by_vote>(gr4j_div(r, P.inv_x3, P.x3_m, votes),
-                                votes);                         // :139
-    double rn = nb_max(0.0, r + head1 + gw_exchange);           // :142
-    const double w = gr4j_div(rn, P.inv_x3, P.x3_m, votes);
-    const double w2 = w * w;
-    const double q_r =
-        rn * (1 - gr4j_inv_fourth_root<by_vote>(1 + w2 * w2, votes)); // :145
-    rn = rn - q_r;                                              // :148
-    const double q_d = nb_max(0.0, head2 + gw_exchange);        // :151
-#endif
     r = rn;
     return q_r + q_d;                                           // :154
 }
@@ -1024,25 +928,6 @@ __device__ __forceinline__ double gr4j_step(const Gr4jPar &P, double &s,
     // per-lane selection of two cost four instructions more
     const double net = __builtin_fabs(prec - etp);
     const lanemask_t net_m = gr4j_num_lanes(net);
-#if GR4J_STEP_UNIFORM_WET
-    // (the coupled kernels: on most days every lane of a wave is on the same
-    // side of :89 -- the evapotranspiration is shared --, and such a wave
-    // takes the production store's wave-uniform form, Gr4jUniformWet above,
-    // instead of both arms and per-lane selects.  The same bits.)
-    const lanemask_t wet_m = RR_LANES(wet);
-    double p_r;
-    if (wet_m == 0 || wet_m == rr_exec()) {
-        const Gr4jUniformWet uw = {wet_m != 0 ? 1 : 0};
-        p_r = gr4j_production<UH, CONSTS, ANY_FORCING>(
-            P, s, net, uw, net_m, static_cast<MID &&>(mid));
-    } else {
-        asm volatile("");                           // keep this a branch
-        p_r = gr4j_production<UH, CONSTS, ANY_FORCING>(
-            P, s, net, wet, net_m, static_cast<MID &&>(mid));
-    }
-    return gr4j_routing<UH>(P, r, uh, p_r);
-#else
     return gr4j_step_net<UH, CONSTS, ANY_FORCING>(
         P, s, r, uh, net, wet, net_m, static_cast<MID &&>(mid));
-#endif
 }

@@ -35,32 +35,17 @@
 #include "common.h"
 #include "fastmath.h"
 
-// Tolerance-driven forms (each has its =0 build):
-// the power in plain double arithmetic, the reservoir updates contracted.
-#ifndef RR_HBV_POW_LITE
-#define RR_HBV_POW_LITE 1
-#endif
-#ifndef RR_HBV_CONTRACT
-#define RR_HBV_CONTRACT 1
-#endif
-// (round 5) the power evaluated on the soil alone, fastmath.h fastpow_soil:
-// no quotient, 512 / 256-entry tables, 28 instead of 34 instructions.
-// 0: round 4's fastpow_tab_lite_x behind the quotient soil * RN(1 / FC).
-#ifndef RR_HBV_POW_SOIL
-#define RR_HBV_POW_SOIL 1
-#endif
-// (the tame loop copy also for sweeps of exactly two waves per SIMD: since
-// the copy saves a select, a compare and two branches a day it wins there
-// too -- 125k sets 3.46 -> 3.26 ms, 100k 3.34 -> 3.14)
-#ifndef HBV_TWO_PER_SIMD_TAME
-#define HBV_TWO_PER_SIMD_TAME 1
-#endif
+// Tolerance-driven forms: the power evaluated on the
+// soil alone in plain double arithmetic (fastmath.h fastpow_soil: no quotient,
+// 512 / 256-entry tables, 28 instructions), the reservoir updates contracted.
+// The reference's own sequence is hbv_reference_day below; the A/B record of
+// the forms that lost is profiles/README.md.
 
 struct __attribute__((aligned(8))) HbvDay {
     double temp;   // temp[t]
     double prec;   // prec[t]
     double dtemp;  // temp[t] - T_m[month[t]]        (hbvedu_model.py:102);
-                   // RR_HBV_CONTRACT: times PE_m[month[t]], see day_step
+                   // times PE_m[month[t]], see day_step
     double pe_m;   // PE_m[month[t]]
     double qobs;   // observed discharge of the day (0 if no score is wanted):
                    // rides along so the score needs no second load + wait
@@ -104,9 +89,7 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
     const double dtemp = temp[g] - T_m[c * 12 + m];      // :102
     d.pe_m = PE_m[c * 12 + m];
     d.dtemp = dtemp;
-#if RR_HBV_CONTRACT
     d.dtemp *= d.pe_m;
-#endif
     d.qobs = qobs ? qobs[g] : 0.0;
     const bool odd = d.prec < 0.0 || (d.prec == 0.0 && __builtin_signbit(d.prec));
     const bool uncivil = !(fabs(d.temp) <= HBV_CIVIL) ||
@@ -124,32 +107,14 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
     dtemp_raw[g] = dtemp;
 }
 
-// The logarithm table of fastpow_tab_core (fastmath.h, pow_tables.h): 4 KiB
-// in constant memory, copied into LDS by every wave at kernel start (each lane
-// indexes it with its own subinterval, which only LDS serves at full rate).
-#if !RR_HBV_POW_SOIL
-static __device__ __constant__ const FpPowLogEntry HBV_POWLOG_TABLE[FP_POWLOG_N] =
-    FP_POWLOG_TABLE_INIT;
-#endif
-// ... and the table 2^(j/64) of its table-driven exponential (exp2_table.h)
-// qsim's rows stored non-temporal (1) or as plain write-back stores (0)
-#ifndef HBV_Q_NT
-#define HBV_Q_NT 1
-#endif
-#ifndef HBV_EXP2_TAB
-#define HBV_EXP2_TAB 1
-#endif
-#if !RR_HBV_POW_SOIL
-static __device__ __constant__ const double HBV_EXP2_TABLE[FP_EXP2_N] =
-    FP_EXP2_TABLE_INIT;
-#else
-// the two tables of fastpow_soil (pow2_tables.h): 8 + 2 KiB in LDS, sixteen
+// The two tables of fastpow_soil (pow2_tables.h): 8 + 2 KiB in constant
+// memory, copied into LDS by every wave at kernel start (each lane indexes
+// them with its own subinterval, which only LDS serves at full rate); sixteen
 // single-wave workgroups per CU = four waves per SIMD
 static __device__ __constant__ const FpSoilEntry HBV_SOIL_LOG_TABLE[FP_SOIL_LOG_N] =
     FP_SOIL_LOG_TABLE_INIT;
 static __device__ __constant__ const double HBV_SOIL_EXP_TABLE[FP_SOIL_EXP_N] =
     FP_SOIL_EXP_TABLE_INIT;
-#endif
 
 // General pow for the (never expected) arguments outside fastpow's domain.
 // Out of line on purpose: inlined, OCML's pow raised the kernel from ~100 to
@@ -253,14 +218,15 @@ __device__ __forceinline__ HbvDay hbv_load_day(const HbvDay *days, int64_t t)
 // multi-catchment launch (rr_hbvedu_simulate_catchments_dev) lays every array
 // out catchment-major: days [C][T], params [C][N][11], outputs [C][T][ld],
 // qobs [C][T], sse [C][N], inits [C][4].
-// FORCING = 1 (measurement variant, RR_OPT_HBV_VARIANT = 1): instead of one
-// scalar load per day, the wave copies 64 day records (2 KiB, coalesced) into
-// LDS and every lane reads them back by broadcast -- the staging north_star
-// sketched.  Kept to document the comparison (profiles/README.md): the scalar
-// path is the faster one, it costs no vector-memory or LDS instruction at all.
+// FORCING: the time loop.  0: two days per trip, each day's record one scalar
+// load at its top (sweeps of more than six waves per SIMD, in time tiles);
+// 3: three records rotating, a day's record asked for two days ahead (up to
+// six waves per SIMD).  (The LDS-staged records north_star sketched and the
+// mid-day prefetch of round 2 -- variants 1 and 2 -- lost to these and were
+// removed in round 6: profiles/README.md has their A/B tables.)
 // TAME: the kernel carries a second copy of the time loop for waves that
-// qualify for it (see day_step); without it the kernel is the general loop
-// alone (a measurement variant since HBV_TWO_PER_SIMD_TAME).
+// qualify for it (see day_step); without it -- the REFERENCE instantiation --
+// the kernel is the general loop alone.
 //
 // TILED: the time axis in PIECES (common.h "the time axis in pieces"), here
 // in the PERSISTENT form -- measured faster than grid-order items in the
@@ -278,47 +244,12 @@ __device__ __forceinline__ HbvDay hbv_load_day(const HbvDay *days, int64_t t)
 // a smaller index, which a resident wave took before it.  Bit-identical to
 // the untiled loop (same operations in the same order, the score summed in
 // time order across the pieces).
-#ifndef HBV_TILED_MINWAVES
 #define HBV_TILED_MINWAVES 1
-#endif
-#ifndef HBV_SMALL_TILES
-#define HBV_SMALL_TILES 0
-#endif
-// (measurement switch, off: two votes -- any lane wet? any lane outside the
-// box? --, each a compare's own mask against zero, instead of one on their
-// scalar combination.  hipcc builds a select chain around them: 125k sets
-// 2.82 -> 3.00 ms, 1M 19.7 -> 20.0)
-// The tame loop copy forms the soil's and the near-surface store's updates
-// inside the arms of the power's branch (day_step).  0: behind it.
-#ifndef HBV_SPLIT_TAIL
-#define HBV_SPLIT_TAIL 1
-#endif
-// The tame loop copy's snow routine as one transfer out of the pack, the
-// cold lanes' share written under an exec mask (day_step).  0: the select
-// form (an A/B switch).
-#ifndef HBV_SNOW_TRANSFER
-#define HBV_SNOW_TRANSFER 1
-#endif
-#ifndef HBV_SPLIT_NEED_VOTE
-#define HBV_SPLIT_NEED_VOTE 0
-#endif
 // Every wave reads a slice of the day records with ordinary vector loads when
-// it starts, so that the scalar loads of the time loop find their lines in
-// this XCD's L2 (see the kernel's prologue).  0: off (an A/B switch).
-#ifndef HBV_WARM_L2
-#define HBV_WARM_L2 1
-#endif
-// timing experiments only (wrong results): 1 every day takes the power's
-// branch, 2 no day does
-#ifndef HBV_WARM_L2_LOADS
+// it starts (where the launch says so: `warm`), so that the scalar loads of
+// the time loop find their lines in this XCD's L2 (see the kernel's
+// prologue): loads per lane
 #define HBV_WARM_L2_LOADS 4
-#endif
-#ifndef HBV_FULL_EXEC
-#define HBV_FULL_EXEC 1
-#endif
-#ifndef HBV_EXP_FORCE
-#define HBV_EXP_FORCE 0
-#endif
 template <bool WRITE_Q, bool WRITE_S, bool WITH_SSE, int FORCING = 0,
           bool TAME = true, int TILED = 0, bool REFERENCE = false>
 __global__ __launch_bounds__(RR_BLOCK, (TILED ? HBV_TILED_MINWAVES : 1)) void
@@ -333,22 +264,12 @@ hbvedu_kernel(
     const double *__restrict__ dtemp_raw, int *__restrict__ queue,
     double *__restrict__ tile_state, int pieces, int ncatch, int warm)
 {
-#if RR_HBV_POW_SOIL
     __shared__ FpSoilEntry soillog[FP_SOIL_LOG_N];
     __shared__ double soilexp[FP_SOIL_EXP_N];
     for (int j = threadIdx.x; j < FP_SOIL_LOG_N; j += RR_BLOCK)
         soillog[j] = HBV_SOIL_LOG_TABLE[j];
     for (int j = threadIdx.x; j < FP_SOIL_EXP_N; j += RR_BLOCK)
         soilexp[j] = HBV_SOIL_EXP_TABLE[j];
-#else
-    __shared__ FpPowLogEntry powlog[FP_POWLOG_N];
-    __shared__ double exptab[HBV_EXP2_TAB ? FP_EXP2_N : 1];
-    for (int j = threadIdx.x; j < FP_POWLOG_N; j += RR_BLOCK)
-        powlog[j] = HBV_POWLOG_TABLE[j];
-    if (HBV_EXP2_TAB)
-        for (int j = threadIdx.x; j < FP_EXP2_N; j += RR_BLOCK)
-            exptab[j] = HBV_EXP2_TABLE[j];
-#endif
     __syncthreads();
     const int njobs = (int)((N + RR_BLOCK - 1) / RR_BLOCK);
     // TILED == 2: several catchments (the jobs of catchment c are the slots
@@ -359,7 +280,7 @@ hbvedu_kernel(
     const double *const params0 = params, *const qobs0 = qobs;
     double *const qsim0 = qsim, *const snow0 = snow_out, *const soil0 = soil_out,
                  *const s10 = s1_out, *const s20 = s2_out, *const sse0 = sse;
-    if (HBV_WARM_L2 != 0 && !REFERENCE && warm != 0) {
+    if (!REFERENCE && warm != 0) {
         // the day records into this XCD's L2 (common.h rr_warm_l2); `warm`:
         // the launch's choice (hbv_launch)
         const int64_t ctotal = TILED == 2 ? ncatch : (int64_t)gridDim.y;
@@ -457,19 +378,13 @@ hbvedu_kernel(
         box_ok ? (unsigned)__double2hiint(FC * 0x1p9) - box_lo : 0u;
     // (opaque to the compiler, which would otherwise re-derive both every day)
     asm("" : "+v"(box_lo), "+v"(box_span));
-#if RR_HBV_POW_SOIL
     // N Beta / ln 2 and its product with ln FC, for fastpow_soil
     double beta_y2N, beta_cF;
     fastpow_soil_exponent(Beta, FC, soillog, &beta_y2N, &beta_cF);
-#else
-    // Beta / ln 2 as a double-double, for fastpow_tab_core
-    double beta2_hi, beta2_lo;
-    fastpow_tab_exponent(Beta, &beta2_hi, &beta2_lo);
-#endif
     // loop-invariant lane masks for the wave votes (common.h)
     const lanemask_t fc_m = RR_LANES(inv_FC.ok), pwp_m = RR_LANES(inv_PWP.ok);
     const bool pwp_pos = inv_PWP.ok && PWP > 0.0;
-    // what a day leaves of the two linear stores (RR_HBV_CONTRACT)
+    // what a day leaves of the two linear stores
     const double keep_1 = 1 - K_1 - K_p, keep_2 = 1 - K_2;
     const double neg_LK0 = -(L * K_0);
     // K_0: +0 or a positive number; L finite (v_cmp_class masks)
@@ -560,7 +475,7 @@ hbvedu_kernel(
         const double melt = DD * (f.temp - T_t);
         const bool cold = f.temp < T_t;
         double snow_n, liquid_water;
-        if constexpr (decltype(tame)::value && HBV_SNOW_TRANSFER) {
+        if constexpr (decltype(tame)::value) {
             // The snow routine of a tame wave as ONE quantity m that leaves
             // the pack for the soil: min(snow, melt) on a day that is not
             // cold, -prec (the precipitation stays) on a cold one --
@@ -614,14 +529,8 @@ hbvedu_kernel(
         // 125k sets 2.63 -> 2.75 ms, 65k 2.37 -> 2.62)
         // (nor in the multi-catchment launch: 125 x 10k sets, scores, 17.96
         // -> 18.29)
-        constexpr bool split_tail = decltype(tame)::value && HBV_SPLIT_TAIL &&
-                                    RR_HBV_CONTRACT &&
-                                    (FORCING == 0 || HBV_SPLIT_TAIL > 1) &&
+        constexpr bool split_tail = decltype(tame)::value && FORCING == 0 &&
                                     TILED != 2;
-        // (HBV_SPLIT_TAIL = 2: the other loops as well, their record request
-        // behind the join instead of in both arms -- measured: 125k sets
-        // unchanged, 65k and 375k 2 % slower, profiles/r04_hbv_split_tail_ab.txt)
-        constexpr bool mid_in_arms = FORCING == 0;
         double soil_lw = soil;
         if constexpr (!split_tail) {
             soil_lw = soil + liquid_water;
@@ -641,16 +550,13 @@ hbvedu_kernel(
         // FAITHFUL -- soil * RN(1/FC), within 1.5 ulp for every numerator,
         // invdiv.h inv_mul_core; their only vote is on the divisor, a loop
         // invariant.  HBV-Edu 1M sets 25.25 -> 24.70 ms, deviation from the
-        // reference semantics 5e-15 -> 6e-15.  -DRR_FAITHFUL_QUOTIENTS=0 builds the
-        // correctly rounded 3-FMA form, for which the box doubles as the
-        // numerator's guard.)
+        // reference semantics 5e-15 -> 6e-15.)
         const lanemask_t soil_m = RR_LANES(
             (unsigned)__double2hiint(soil) - box_lo < box_span);
         // lanes that need the power: wet, or outside the box (votes are done
         // on lane masks, common.h)
         const lanemask_t wet_m = RR_LANES(liquid_water != 0.0);
         double prec_eff = liquid_water;   // == liquid_water * finite (it is 0)
-#if RR_HBV_CONTRACT
         // (measured and removed in round 4: this part of the day written
         // inside both arms of the power's branch, fenced by scheduling
         // barriers behind the power's LDS table read -- hipcc hoists half of
@@ -700,33 +606,16 @@ hbvedu_kernel(
             // base-flow reservoir (:121-123): s2 (1 - K_2) + s1 K_p
             s2_n = __builtin_fma(s2, keep_2, s1 * K_p);
         };
-#endif
-#if RR_HBV_CONTRACT
         double soil_n, s1_n;
-#endif
-#if HBV_SPLIT_NEED_VOTE
-        // (two votes, each a compare's own lane mask against zero, instead of
-        // one on their combination: no scalar or / and-with-exec between the
-        // compares and the branch)
-        if (wet_m != 0 || RR_ANY_OUTSIDE(soil_m)) {
-#elif HBV_EXP_FORCE == 1
-        if (((wet_m | ~soil_m) & rr_exec()) | 1) {
-#elif HBV_EXP_FORCE == 2
-        if (((wet_m | ~soil_m) & rr_exec()) & 0) {
-#elif HBV_FULL_EXEC
         // (every wave runs with all 64 lanes: tail lanes recompute the last
         // set, workgroups are RR_BLOCK threads -- no AND with exec)
         if ((wet_m | ~soil_m) != 0) {
-#else
-        if ((wet_m | ~soil_m) & rr_exec()) {
-#endif
             if constexpr (split_tail) {
                 // (first operation of the soil update, before liquid_water
                 // becomes prec_eff in place)
                 soil_lw = soil + liquid_water;
                 asm("" : "+v"(soil_lw));
             }
-#if RR_HBV_POW_SOIL
             // fastmath.h fastpow_soil: the power from the soil alone -- the
             // quotient by FC lives in a per-lane constant of the exponent --,
             // table-driven in plain double, 28 instructions.  Inside the box
@@ -736,7 +625,7 @@ hbvedu_kernel(
             // also evaluates the general pow of the reference's own quotient
             // and every lane fastpow_soil cannot serve takes it.
             double sN;
-            double pw = fastpow_soil<FORCING >= 2>(soil, beta_y2N, beta_cF,
+            double pw = fastpow_soil<FORCING == 3>(soil, beta_y2N, beta_cF,
                                                    soillog, soilexp, &sN);
             if (RR_ANY_OUTSIDE(soil_m)) {
                 double soil_again = soil;
@@ -744,56 +633,6 @@ hbvedu_kernel(
                 const double general = pow_general(soil_again / FC, Beta);
                 pw = fastpow_soil_ok(soil_again, sN) ? pw : general;
             }
-#else
-#if RR_FAITHFUL_QUOTIENTS
-            // (a tame wave has checked its divisors once, before the loop)
-            double wetness;
-            if constexpr (decltype(tame)::value)
-                wetness = inv_mul_core(soil, inv_FC);
-            else
-                wetness = mul_by_inverse_m(soil, inv_FC, fc_m);
-#else
-            const double wetness = div_by_invariant_m(soil, soil_m, inv_FC,
-                                                      fc_m);
-#endif
-            // fastmath.h fastpow_tab_lite: the table-driven power in plain
-            // double arithmetic, a few ulp in a sane run's box (bound: (4 +
-            // 3 |Beta log2 wetness| + |Beta| / 4) 2^-53), a fifth of the
-            // general pow's instructions (-DRR_HBV_POW_LITE=0: the
-            // double-double form, 0.97 ulp, 16 instructions more); arguments
-            // outside its domain take the general pow (wave-wide)
-            double z;
-            // (small sweeps, FORCING == 2: polynomial constants in VGPRs so
-            // that the prefetched record fits the SGPR file without spills)
-#if RR_HBV_POW_LITE
-            double pw = fastpow_tab_lite_x<FORCING >= 2, HBV_EXP2_TAB != 0>(
-                wetness, beta2_hi, powlog, exptab, &z);
-#else
-            double pw = fastpow_tab_core<FORCING >= 2>(wetness, beta2_hi,
-                                                       beta2_lo, powlog, &z);
-#endif
-            // Inside the box the arguments are in fastpow's domain by
-            // construction: wetness in [2^-9, 2^9] is a positive normal
-            // number and |z| = |Beta log2 wetness| <= 64 * 9 < 1000 -- so
-            // the box mask is the vote, and no compare is spent on it.  If any lane
-            // is outside the box the wave also evaluates the general pow and
-            // every lane fastpow cannot serve takes it.
-            if (RR_ANY_OUTSIDE(soil_m)) {
-                // (a tame wave forms the quotient a second time here, from a
-                // copy of soil the compiler cannot see through: the first one
-                // then dies in the table lookup, which splits it in place --
-                // alive until here it costs the likely path a v_mov_b32 per
-                // evaluation)
-                double w = wetness;
-                if constexpr (decltype(tame)::value && RR_FAITHFUL_QUOTIENTS) {
-                    double soil_again = soil;
-                    asm volatile("" : "+v"(soil_again));
-                    w = inv_mul_core(soil_again, inv_FC);
-                }
-                const double general = pow_general(w, Beta);
-                pw = fastpow_tab_ok(w, z) ? pw : general;
-            }
-#endif
             // lanes of this wave that did not need the power sit inside the
             // box with liquid_water == 0: their pw is finite (|z| <= 64 * 9.1)
             // and 0 * pw is the 0 they already hold, so no select is needed
@@ -801,34 +640,30 @@ hbvedu_kernel(
             // gives the product a register of its own and pays a v_mov_b64
             // on every day WITHOUT the power to join the two)
             asm("v_mul_f64 %0, %0, %1" : "+v"(prec_eff) : "v"(pw));
-#if RR_HBV_CONTRACT
             if constexpr (split_tail) {
                 // (the tame copy: the rest of the day inside the branch's
                 // arm, see below)
                 independent_of_the_power();
-                if constexpr (mid_in_arms) mid();
+                mid();
                 soil_n = __builtin_fma(-pe, dry, soil_lw - prec_eff);
                 s1_n = __builtin_fma(s1, keep_1, prec_eff - over);
                 asm("" : "+v"(soil_n), "+v"(s1_n));
             }
-#endif
         }
-#if RR_HBV_CONTRACT
         else if constexpr (split_tail) {
             // (a day without the power, see below)
             independent_of_the_power();
-            if constexpr (mid_in_arms) mid();
+            mid();
             soil_n = __builtin_fma(-pe, dry, soil);
             s1_n = __builtin_fma(s1, keep_1, -over);
             asm("" : "+v"(soil_n), "+v"(s1_n));
         }
-        if constexpr (split_tail && !mid_in_arms) mid();
         // The reservoir updates with their multiply-adds CONTRACTED -- each
         // product fused into the sum that takes it, one rounding instead of
         // two -- and the two linear stores regrouped around their
         // loop-invariant retention factors: 12 instructions instead of 23 a
         // day, every result within an ulp or two of the reference's.
-        // -DRR_HBV_CONTRACT=0 builds the reference's own sequence below.
+        // (The reference's own sequence: hbv_reference_day.)
         // soil moisture (:111); near-surface reservoir (:114-118): s1 - s1
         // K_1 - s1 K_p as s1 (1 - K_1 - K_p), the factor a loop invariant
         //
@@ -848,32 +683,6 @@ hbvedu_kernel(
         // discharge mixes old and new states (:125-127)
         const double q =
             __builtin_fma(s2_n, K_2, __builtin_fma(s1_n, K_1, over));
-#else
-        mid();
-        // potential / actual evapotranspiration (:102-108)
-        const double pe = (1 + C * f.dtemp) * f.pe_m;
-#if RR_FAITHFUL_QUOTIENTS
-        const double ea = (soil > PWP)
-            ? pe : pe * mul_by_inverse_m(soil, inv_PWP, pwp_m);
-#else
-        const double ea = (soil > PWP)
-            ? pe : pe * div_by_invariant_m(soil, soil_m, inv_PWP, pwp_m);
-#endif
-
-        // soil moisture (:111)
-        const double soil_n = soil_lw - prec_eff - ea;
-
-        // near-surface reservoir (:114-118)
-        const double over = nb_max(0.0, s1 - L) * K_0;
-        const double s1_n = s1 + prec_eff - over - s1 * K_1 - s1 * K_p;
-
-        // base-flow reservoir (:121-123)
-        const double s2_n = s2 + s1 * K_p - s2 * K_2;
-
-        // discharge mixes old and new states (:125-127)
-        const double q = over + s1_n * K_1 + s2_n * K_2;
-
-#endif
 
         double q_c = q;
         if constexpr (REFERENCE) {
@@ -891,7 +700,7 @@ hbvedu_kernel(
             snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
         }
 
-        if (WRITE_Q) rr_store_row_at(qsim + row, row_bytes, lane_off, soff, q_c, HBV_Q_NT != 0);
+        if (WRITE_Q) rr_store_row_at(qsim + row, row_bytes, lane_off, soff, q_c);
         if (WRITE_S) {
             rr_store_row_at(snow_out + row, row_bytes, lane_off, soff, snow);
             rr_store_row_at(soil_out + row, row_bytes, lane_off, soff, soil);
@@ -908,65 +717,13 @@ hbvedu_kernel(
     // (hbv_launch rejects 3 * ld * 8 >= 2^32)
     const unsigned ld8 = (unsigned)ld * 8u, ld16 = 2u * ld8, ld24 = 3u * ld8;
     (void)ld16; (void)ld24;
-    __shared__ HbvDay tile[FORCING == 1 ? RR_BLOCK : 1];
-    (void)tile;
     auto time_loop = [&](auto tame) {
-        if constexpr (FORCING == 1) {
-            for (int t0 = 1; t0 < Ti; t0 += RR_BLOCK) {
-                const int tt = t0 + threadIdx.x;
-                tile[threadIdx.x] = days[tt < Ti ? tt : Ti - 1];
-                __syncthreads();
-                const int n = (Ti - t0 < RR_BLOCK) ? (Ti - t0) : RR_BLOCK;
-                for (int k = 0; k < n; ++k) {
-                    const HbvDay f = tile[k];  // uniform address: LDS broadcast
-                    row += ld;
-                    day_step(f, t0 + k, [] {}, tame, 0u);
-                }
-                __syncthreads();
-            }
-        } else if constexpr (FORCING == 2) {
-            // small sweeps (at most two waves per SIMD): nothing hides the
-            // scalar load's latency, so the next day's record is requested in
-            // the middle of this day's arithmetic -- after the power block, whose
-            // wait for its table entry (lgkmcnt counts LDS and scalar loads
-            // alike) would otherwise wait for the record as well.  Two records
-            // alternate (loop unrolled by two: no register copies); the fetch
-            // runs one record ahead, so it may touch record T -- the workspace
-            // holds one spare record for that, its content is never used.
-            // (constant address space: the records are read-only for this
-            // kernel, which is what lets the load stay scalar once its address
-            // has gone through the asm that pins it in place)
-            typedef const HbvDay __attribute__((address_space(4))) *cp_t;
-            cp_t pn = (cp_t)(days + 2);
-            auto fetch = [&](HbvDay &dst) {
-                asm volatile("" : "+s"(pn));
-                dst.temp = pn->temp; dst.prec = pn->prec;     // one load burst
-                dst.dtemp = pn->dtemp; dst.pe_m = pn->pe_m; dst.qobs = pn->qobs;
-                pn += 1;
-            };
-            HbvDay a = hbv_load_day(days, 1), b;
-            // (a "use" of the first record ahead of the loop: otherwise hipcc
-            // leaves half of its load in flight across the loop entry and then
-            // waits for ALL scalar loads -- the prefetch included -- at that
-            // half's first use in every iteration)
-            asm volatile("" : : "s"(a.temp), "s"(a.prec), "s"(a.dtemp),
-                         "s"(a.pe_m), "s"(a.qobs));
-            int t = 1;
-            for (; t + 1 < Ti; t += 2) {
-                day_step(a, t, [&] { fetch(b); }, tame, ld8);
-                day_step(b, t + 1, [&] { fetch(a); }, tame, ld16);
-                row += 2 * ld;
-            }
-            if (t < Ti) day_step(a, t, [] {}, tame, ld8);
-        } else if constexpr (FORCING == 3) {
+        if constexpr (FORCING == 3) {
             // sweeps of at most two waves per SIMD, round 4: a lone wave's
             // day is a latency chain (a day takes as long with one wave on
             // the SIMD as with two), and the longest link that nothing covers
             // is the record's scalar load, requested and waited for in the
-            // same day by the two loops above (FORCING == 2 asks in the
-            // middle of the day before, and hipcc schedules the next day's
-            // first instructions -- the record's first use -- right behind
-            // that).  Here THREE records rotate (loop unrolled by three: no
+            // same day by the plain loop below.  Here THREE records rotate (loop unrolled by three: no
             // copies) and the middle of day t requests the record of day
             // t + 2: by the time it is used a whole day has passed.  Scalar
             // loads return out of order, so every wait is for all of them:
@@ -981,11 +738,7 @@ hbvedu_kernel(
                 asm volatile("" : "+s"(pn));
                 dst.temp = pn->temp; dst.prec = pn->prec;     // one load burst
                 dst.dtemp = pn->dtemp; dst.pe_m = pn->pe_m; dst.qobs = pn->qobs;
-#ifdef HBV_EXP_CONST_RECORD
-                // timing experiment only (wrong results): no new record
-#else
                 pn += 1;
-#endif
             };
             auto use = [](const HbvDay &r) {
                 asm volatile("" : : "s"(r.temp), "s"(r.prec), "s"(r.dtemp),
@@ -1011,22 +764,10 @@ hbvedu_kernel(
             // remainder on its own: one taken branch per two days)
             int t = t_begin;
             for (; t + 1 < t_end; t += 2) {
-#ifdef HBV_EXP_CONST_RECORD
-                // timing experiment only (wrong results): every day reads
-                // the same two records -- no scalar-cache misses
-                int tt = 1;
-                asm volatile("" : "+s"(tt));
-                const HbvDay f0 = hbv_load_day(days, tt);
-                day_step(f0, t, [] {}, tame, ld8);
-                asm volatile("" : "+s"(tt));
-                const HbvDay f1 = hbv_load_day(days, tt + 1);
-                day_step(f1, t + 1, [] {}, tame, ld16);
-#else
                 const HbvDay f0 = hbv_load_day(days, t);   // s_load_dwordx8 + x2
                 day_step(f0, t, [] {}, tame, ld8);
                 const HbvDay f1 = hbv_load_day(days, t + 1);
                 day_step(f1, t + 1, [] {}, tame, ld16);
-#endif
                 row += 2 * ld;
             }
             if (t < t_end) {
@@ -1047,13 +788,11 @@ hbvedu_kernel(
         tame_wave = odd == 0 && snow_init >= 0.0 &&
                     !__builtin_signbit(snow_init) &&
                     (rr_exec() & ~lanes_of_class(DD, 0x3c3)) == 0;
-#if RR_HBV_CONTRACT && RR_FAITHFUL_QUOTIENTS
         // ... and both divisors usable, PWP positive; K_0 +0 or a positive
         // number, L finite (day_step)
         tame_wave = tame_wave &&
                     (rr_exec() & ~(fc_m & RR_LANES(pwp_pos) &
                                    k0_folds_m)) == 0;
-#endif
     }
     if constexpr (TAME) {
         if (tame_wave) time_loop(std::true_type{});
@@ -1111,30 +850,11 @@ static size_t hbv_tile_bytes(int64_t N, int64_t C)
 extern "C" size_t rr_hbvedu_workspace_bytes(int64_t T, int64_t N)
 {
     if (T < 0) T = 0;
-    // + 1: the spare record the prefetching kernel variant may touch; + the
+    // + 2: the spare records the three-record loop may touch; + the
     // pre-pass's flags of odd precipitation values (one int per 256 days)
     // behind it
     if (T < 1) T = 1;
     return hbv_forcing_bytes(T, 1) + hbv_tile_bytes(N, 1);
-}
-
-// Pieces for a sweep of `waves` equal jobs on `slots` persistent waves
-// (slots / 2 < waves <= slots): with p pieces the p * waves items take
-// ceil(p * waves / slots) rounds of 1 / p of a job each; the smallest p (from
-// 4 to 48, pieces of at least 128 days) whose rounds come within 1 % of the
-// work itself, waves / slots -- or the best there is.  0: nothing to gain.
-static int hbv_small_pieces(int64_t waves, int64_t slots, int64_t T)
-{
-    if (waves <= 0 || waves >= slots) return 0;
-    const double ideal = (double)waves / (double)slots;
-    int best = 0;
-    double best_cost = 1.0;
-    for (int p = 4; p <= 48 && T / p >= 128; ++p) {
-        const double cost = (double)rr_ceil_div((int64_t)p * waves, slots) / p;
-        if (cost < best_cost - 1e-12) { best_cost = cost; best = p; }
-        if (cost <= ideal * 1.01) break;
-    }
-    return best_cost < 0.985 ? best : 0;
 }
 
 // Shared by the single- and multi-catchment entry points.
@@ -1172,82 +892,47 @@ static int hbv_launch(const double *temp, const double *prec,
                        dtemp_raw);
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK), (unsigned)C);
     const bool any_s = snow != nullptr;
-    // forcing variant: 0 one scalar load at the top of each day; 1 LDS
-    // staging (measurement only); 2 the next day's record requested in the
-    // middle of the day, two records alternating (125 instead of 87 VGPRs).
-    // Measured (profiles/README.md, round 2, kernel ms for 0 / 2): 65k sets
-    // 4.03 / 3.35, 125k 3.98 / 4.07, 250k 8.09 / 7.75, 375k 12.85 / 11.21,
-    // 500k 14.76 / 14.63, 1M 28.07 / 28.07 -- the prefetch wins wherever a
-    // SIMD holds one or three to eight waves, loses 2 % at exactly two and
-    // ties from about twelve on, where the plain loop (one wave per SIMD
-    // more) is kept.  rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one.
     const int64_t waves = rr_ceil_div(N, RR_BLOCK) * C;
     // (waves per SIMD of the device the process sees: 1024 SIMDs on a whole
     // MI355X)
     const int64_t simds = rr_simd_count();
-    const bool two_per_simd = waves > simds && waves <= 2 * simds;
-    // loop variant by sweep size: up to two waves per SIMD a day is a
-    // latency chain per wave, and the loop that asks for its record two days
-    // ahead (3) wins (round 4, kernel ms 0 / 3: 65k sets 3.04 / 2.48, 100k
-    // 3.01 / 2.59, 125k 3.08 / 2.88, 250k 6.00 / 5.87); the mid-day prefetch
-    // (2) up to six; the plain loop in time tiles beyond, where a SIMD
-    // always has a wave ready (kernel ms 2 untiled / 0 in four pieces: 375k
-    // sets 7.99 / 8.20, 400k 9.21 / 8.60, 500k 10.71 / 10.00, 750k 15.53 /
-    // 14.85: profiles/r04_mid_sizes.txt; the launch of
-    // equal-length waves moves in rounds of four waves per SIMD, which tiles
-    // smooth).  rr_debug_set_option(RR_OPT_HBV_VARIANT, v) pins one.
-    // the records' lines fetched into every XCD's L2 by the waves themselves
-    // when they start (the kernel's prologue): where a SIMD holds one wave,
-    // and in the score-only mode at any size.  Measured, kernel ms without /
-    // with (profiles/r05_hbv_warm_ab.txt): 32k sets 2.11 / 1.60, 65,536 2.20 /
-    // 1.51; scores only 125k 2.16 / 1.98, 1M 11.59 / 11.43 -- but with qsim
-    // written 100k 2.19 / 2.27, 125k 2.38 / 2.39, 250k 4.85 / 5.12: at two
-    // to four waves per SIMD the store stream (4 to 4.6 TB/s) is what the
-    // sweep waits for, and waves that queue behind their XCD's leading wave
-    // write the same rows at the same time, which the memory system likes
-    // better than 2,000 waves each at a row of its own.
+    // Loop form by sweep size.  Up to six waves per SIMD a day is a latency
+    // chain per wave, and the loop that asks for its record two days ahead
+    // (3) wins (kernel ms, plain loop / three records, with qsim: 65k sets
+    // 3.04 / 2.48, 125k 3.08 / 2.88, 250k 4.96 / 4.76, 375k 7.83 / 6.97);
+    // beyond, where a SIMD always has a wave ready, the plain loop in time
+    // tiles (400k 7.02 / 8.01, 750k 12.84 / 13.61; profiles/r05_mid_sizes.txt).
+    // RR_OPT_HBV_VARIANT pins 0 or 3 (tests: the two must agree bit for bit).
+    // The records' lines are fetched into every XCD's L2 by the waves
+    // themselves when they start (the kernel's prologue) where a SIMD holds
+    // one wave, and in the score-only mode at any size (kernel ms without /
+    // with, profiles/r05_hbv_warm_ab.txt: 65,536 sets 2.20 / 1.51; scores only
+    // 125k 2.16 / 1.98) -- but not with qsim written at two to four waves per
+    // SIMD (100k 2.19 / 2.27, 250k 4.85 / 5.12): there the store stream is
+    // what the sweep waits for, and waves that queue behind their XCD's
+    // leading wave write the same rows at the same time, which the memory
+    // system likes better than 2,000 waves each at a row of its own.
     const bool score_only = qsim == nullptr && snow == nullptr;
     const int warm = rr_warm_choice(waves, simds, score_only);
     const int64_t many_waves = 6 * simds;
-    // (round 5, with the shorter power and the trip-wise row addressing:
-    // the three-record loop wins up to six waves per SIMD -- kernel ms 0 / 2 /
-    // 3 with qsim: 250k sets 4.96 / 4.98 / 4.76, 375k 7.83 / 7.02 / 6.97;
-    // scores only 250k 3.78 / 3.80 / 3.55, 375k 5.26 / 5.22 / 4.94 -- and
-    // the tiled plain loop beyond: 400k 7.02 / 8.02 / 8.01, 500k 8.80 / 9.48 /
-    // 9.14, 750k 12.84 / 14.00 / 13.61; profiles/r05_mid_sizes.txt.  Variant
-    // 2 is no longer chosen.)
     int variant = waves > many_waves ? 0 : 3;
     const int64_t pinned = rr_option(RR_OPT_HBV_VARIANT);
-    if (pinned >= 0) variant = (int)pinned;
-    // time-tiled persistent form (hbvedu_kernel's TILED), variants 0 and 3:
-    //  * sweeps of many rounds of waves, where equal-length waves quantise
-    //    the kernel time to whole wave slots (1M sets: 16 slots for 15.26
-    //    slots of work): four pieces, as many waves as are resident;
-    //  * sweeps of between one and two waves per SIMD (one GPU's shard of a
-    //    million sets over eight: 1,954 waves on 1,024 SIMDs, 2 slots for
-    //    1.91 slots of work): exactly two waves per SIMD and as many pieces
-    //    as make the items fill whole rounds of those slots
-    //    (hbv_small_pieces) -- MEASURED AND NOT USED (HBV_SMALL_TILES = 0):
-    //    with two waves on a SIMD nobody covers an item's own latencies
-    //    (ticket, flag, acquire, five state loads, parameters; at its end
-    //    the release that drains its stores): 125k sets 2.82 ms untiled,
-    //    3.31 with 11 pieces, 3.85 with 22, 5.24 with 44 -- about 50 us per
-    //    round of items, against the 0.13 ms the quantisation costs.  An
-    //    explicit RR_OPT_TIME_TILES = k still runs it.
-    // RR_OPT_TIME_TILES: -1 by sweep size, 0 never, k > 1 pieces.
+    if (pinned == 0 || pinned == 3) variant = (int)pinned;   // (the setters
+                                                // accept -1, 0 and 3 only)
+    // Time-tiled persistent form (hbvedu_kernel's TILED) of the plain loop:
+    // sweeps of many rounds of waves, where equal-length waves quantise the
+    // kernel time to whole wave slots (1M sets: 16 slots for 15.26 slots of
+    // work): four pieces, as many waves as are resident.  (At two waves per
+    // SIMD tiles lose -- nobody covers an item's own latencies: 125k sets 2.82
+    // ms untiled, 3.31 with 11 pieces.)  RR_OPT_TIME_TILES: -1 by sweep size,
+    // 0 never, k > 1 pieces.
     int pieces = 0;
-    int64_t resident_cap = 0;           // 0: what the occupancy query says
     {
         const int64_t opt = rr_option(RR_OPT_TIME_TILES);
-        if ((variant == 0 || variant == 3) && T > 16 &&
+        if (variant == 0 && T > 16 &&
             waves * (opt > 1 ? opt : 64) < 0x7fffffff) {
             if (opt > 1) pieces = (int)opt;
-            else if (opt < 0 && variant == 0 && waves > many_waves) pieces = 4;
-#if HBV_SMALL_TILES
-            else if (opt < 0 && variant == 3 && two_per_simd)
-                pieces = hbv_small_pieces(waves, 2 * simds, T);
-#endif
-            if (pieces > 1 && waves <= 2 * simds) resident_cap = 2 * simds;
+            else if (opt < 0 && waves > many_waves) pieces = 4;
         }
     }
     int *queue = nullptr;
@@ -1259,13 +944,13 @@ static int hbv_launch(const double *temp, const double *prec,
     }
     rr_dispatch3(qsim != nullptr, any_s, qobs && sse,
                  [&](auto Q, auto S, auto E) {
-        auto go = [&](auto V, auto tame) {
-            if constexpr ((V.value == 0 || V.value == 3) && tame.value) {
+        auto go = [&](auto V) {
+            if constexpr (V.value == 0) {
                 if (pieces > 1) {
                     auto kern = C == 1 ? hbvedu_kernel<Q.value, S.value,
-                                                       E.value, V.value, true, 1>
+                                                       E.value, 0, true, 1>
                                        : hbvedu_kernel<Q.value, S.value,
-                                                       E.value, V.value, true, 2>;
+                                                       E.value, 0, true, 2>;
                     // as many waves as are resident at once, no more
                     int per_cu = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
@@ -1275,8 +960,6 @@ static int hbv_launch(const double *temp, const double *prec,
                         per_cu = 16;
                     }
                     int64_t resident = (int64_t)per_cu * (simds / 4);
-                    if (resident_cap > 0 && resident > resident_cap)
-                        resident = resident_cap;
                     const int64_t items = (int64_t)pieces * waves;
                     if (resident > items) resident = items;
                     kern<<<dim3((unsigned)resident), dim3(RR_BLOCK), 0, st>>>(
@@ -1287,21 +970,14 @@ static int hbv_launch(const double *temp, const double *prec,
                     return;
                 }
             }
-            hbvedu_kernel<Q.value, S.value, E.value, V.value, tame.value>
+            hbvedu_kernel<Q.value, S.value, E.value, V.value, true>
                 <<<grid, dim3(RR_BLOCK), 0, st>>>(
                     days, T, snow_init, soil_init, s1_init, s2_init, inits,
                     params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
                     day_flags, dtemp_raw, nullptr, nullptr, 0, (int)C, warm);
         };
-        if (variant == 1) go(std::integral_constant<int, 1>{}, std::false_type{});
-        else if (variant == 2) go(std::integral_constant<int, 2>{}, std::true_type{});
-        else if (variant == 3) go(std::integral_constant<int, 3>{}, std::true_type{});
-#if HBV_TWO_PER_SIMD_TAME
-        else if (two_per_simd) go(std::integral_constant<int, 0>{}, std::true_type{});
-#else
-        else if (two_per_simd) go(std::integral_constant<int, 0>{}, std::false_type{});
-#endif
-        else go(std::integral_constant<int, 0>{}, std::true_type{});
+        if (variant == 3) go(std::integral_constant<int, 3>{});
+        else go(std::integral_constant<int, 0>{});
         // ... and, right behind it, the kernel of the waves that hold a set
         // which is not civil (hbv_civil_lane): every other wave returns at
         // once (30 us of a million-set sweep)

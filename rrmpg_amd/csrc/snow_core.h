@@ -60,7 +60,8 @@ int rr_cema_prepass(const double *prec, const double *mean_temp,
                     const double *frac, const double *etp, const double *qobs,
                     int64_t T, int L, void *workspace, hipStream_t st,
                     double **days_out, double **gt_out, double **state_out,
-                    int *uncivil = nullptr);
+                    int *uncivil = nullptr,
+                    int reg_layers = RR_CEMANEIGE_MAX_LAYERS);
 
 static inline size_t cema_days_bytes(int64_t T, int64_t L, bool with_etp)
 {
@@ -92,11 +93,15 @@ static inline size_t cema_tile_offset(int64_t T, int64_t L, bool with_etp)
 {
     return 512 + cema_gt_bytes(L) + cema_days_bytes(T, L, with_etp);
 }
+// reg_layers: up to this many layers the model's kernels keep the snow states
+// in registers (RR_CEMANEIGE_MAX_LAYERS; the hysteresis / ice couplings:
+// RR_SNOWNEXT_REG_LAYERS)
 static inline size_t cema_ws_bytes(int64_t T, int64_t L, bool with_etp,
-                                   int64_t N, int nstate = 2)
+                                   int64_t N, int nstate = 2,
+                                   int reg_layers = RR_CEMANEIGE_MAX_LAYERS)
 {
     size_t b = cema_tile_offset(T, L, with_etp);
-    if (L > RR_CEMANEIGE_MAX_LAYERS && N > 0)
+    if (L > reg_layers && N > 0)
         b += rr_align256((size_t)nstate * (size_t)L * (size_t)N * 8);
     else if (N > 0)
         b += rr_tile_bytes(N, cema_tile_states(L));
@@ -121,9 +126,6 @@ struct CemaGt { double gt, rgt; };
 // ms, scores 33.4 -> 27.9; fused 83.1 -> 77.6, its 125k shard 12.9 -> 11.7.
 // -DRR_SNOW_FAITHFUL=0 builds the correctly rounded forms (bit-identical
 // snow pack).
-#ifndef RR_SNOW_FAITHFUL
-#define RR_SNOW_FAITHFUL 1
-#endif
 typedef const CemaGt __attribute__((address_space(4))) *cema_gt_ptr_t;
 
 // c / L (the layer mean, np.mean's division by the size): L is a constant --
@@ -133,12 +135,7 @@ template <int L, class V = CarefulVotes>
 __device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 {
     const InvDivisor inv_L = {(double)L, 1.0 / (double)L, true};
-#if RR_SNOW_FAITHFUL
     return inv_mul_core(c, inv_L);
-#else
-    return div_by_invariant_m(c, gr4j_num_mask(c), inv_L, ~0ull, 0x1p900,
-                              votes);
-#endif
 }
 
 // One day of the snow routine for all L layers of one parameter set
@@ -157,18 +154,6 @@ __device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 // left off: two vector instructions fewer on a layer's idle days bought
 // Cemaneige 1M sets 28.92 -> 28.68 ms and cost the small sweeps (125k sets
 // 6.49 -> 6.60, fused 10.75 -> 11.0; profiles/r04_lazy_sums_ab.txt).
-#ifndef CEMA_LAZY_SUMS
-#define CEMA_LAZY_SUMS 0
-#endif
-#ifndef CEMA_GT_SELECT_FORM
-#define CEMA_GT_SELECT_FORM 1
-#endif
-#ifndef CEMA_FROST_DAYS
-#define CEMA_FROST_DAYS 1
-#endif
-#ifndef CEMA_SCALAR_WARM
-#define CEMA_SCALAR_WARM 1
-#endif
 template <int L>
 struct CemaGtRegs { double gt[L], rgt[L]; };
 
@@ -233,7 +218,7 @@ __device__ __forceinline__ double cema_day_io(
     const CemaGtRegs<L> *gt_regs = nullptr, V &&votes = V())
 {
     double c = 0.0;
-    if constexpr (CEMA_FROST_DAYS && SANE && !FIRST) {
+    if constexpr (SANE && !FIRST) {
         // Frost in every layer (a third of the days of a temperate year): no
         // lane melts anything, whatever its thermal state -- `temp > 0` is
         // false (:99) --, so melt = pot_melt = 0, the pack keeps g = G + snow
@@ -297,9 +282,9 @@ __device__ __forceinline__ double cema_day_io(
         // (COUPLED -- the kernels with a GR4J day behind the snow routine --
         // only: they gain 1 % from it, 125k and 1M sets alike, the plain
         // Cemaneige kernel loses 2 %; profiles/r05_hyst_days_ab.txt)
-        const bool warm = (CEMA_SCALAR_WARM && COUPLED && SANE && !FIRST)
+        const bool warm = (COUPLED && SANE && !FIRST)
                               ? __double2hiint(temp) > 0 : temp > 0;
-        if (SANE && !FIRST && GT_REGS && CEMA_GT_SELECT_FORM) {
+        if (SANE && !FIRST && GT_REGS) {
             // (the small-sweep kernels evaluate it for every lane and select:
             // no exec-masked block, no branch over it -- at two waves per
             // SIMD the scalar work of a branch is not hidden: 125k sets
@@ -324,21 +309,6 @@ __device__ __forceinline__ double cema_day_io(
             SANE ? RR_LANES(pot_melt == 0.0)
                  : (RR_LANES(pot_melt == 0.0) & RR_LANES(g >= 0.0));
         double melt = pot_melt;
-#if CEMA_LAZY_SUMS
-        // On the idle days -- melt a zero in every lane -- g - melt is g and
-        // the layer adds its (wave-uniform) rain to the running sum: ONE
-        // vector instruction, issued before the branch; a wave that melts
-        // overwrites the sum with c + (rain + melt) and takes the melt off
-        // the pack inside the block.  (x - 0 = x and x + 0 = x for every x a
-        // pack or a rain can be: neither is ever -0.)
-        double c_next = 0.0;
-        if (l > 0) {
-            c_next = c + rain;
-            // (pinned: hipcc otherwise carries the ADDEND through the branch
-            // -- a v_mov_b64 of the rain on the idle side -- and adds behind)
-            asm("" : "+v"(c_next));
-        }
-#endif
         if (rr_exec() & ~idle) {
             // G / G_tresh: the threshold is fixed for the whole run, so the
             // quotient is the 3-instruction correctly rounded form of
@@ -364,7 +334,6 @@ __device__ __forceinline__ double cema_day_io(
             // (the quotient -- and its vote -- for every lane: a vote inside
             // a per-lane conditional would make the vote mask a per-lane
             // value)
-#if RR_SNOW_FAITHFUL
             const double gq = mul_by_inverse_m(g, inv_gt, gt_ok, votes);
             // (the faithful quotient of a pack a few ulp below its threshold
             // can round to 1 + ulp, and a ratio above 1 would melt more than
@@ -386,28 +355,11 @@ __device__ __forceinline__ double cema_day_io(
                 asm("v_fma_f64 %0, %1, %2, %3"
                     : "=v"(factor) : "v"(ratio), "s"(0.9), "v"(0.1));
             melt = factor * pot_melt;                      // :115
-#if CEMA_LAZY_SUMS
-            g = g - melt;                                  // :118
-            if (l > 0) c_next = c + (rain + melt);         // :121, :125
-#endif
-#else
-            const double gq = div_by_invariant_m(g, gr4j_num_mask(g), inv_gt,
-                                                 gt_ok, 0x1p900, votes);
-            const double ratio =                           // :109-112
-                SANE ? rr_hw_min(gq, 1.0) : ((g < inv_gt.b) ? gq : 1.0);
-            melt = (0.9 * ratio + 0.1) * pot_melt;         // :115
-#endif
         }
-#if CEMA_LAZY_SUMS
-        G[l] = g;
-        eTG[l] = e;
-        c = (l == 0) ? rain + melt : c_next;
-#else
         g = g - melt;                                      // :118
         G[l] = g;
         eTG[l] = e;
         c = (l == 0) ? rain + melt : c + (rain + melt);    // :121, :125
-#endif
     }
     return cema_layer_mean<L>(c, votes);
 }
@@ -492,19 +444,29 @@ __device__ __forceinline__ bool cema_wave_is_sane(const double *gtresh, int L,
            fabs(thermal_state_init) <= 1e300 && (rr_exec() & ~ctg_ok) == 0;
 }
 
-// calls f(std::integral_constant<int, L>) for the runtime L in 1..8
-template <class F>
+// calls f(std::integral_constant<int, L>) for the runtime L in 1..MAXL
+// (MAXL: RR_CEMANEIGE_MAX_LAYERS = 8, or RR_SNOWNEXT_REG_LAYERS = 5)
+template <int MAXL = RR_CEMANEIGE_MAX_LAYERS, class F>
 static inline void dispatch_layers(int L, F &&f)
 {
+    static_assert(MAXL == 5 || MAXL == 8, "dispatch_layers");
     switch (L) {
     case 1: f(std::integral_constant<int, 1>{}); break;
     case 2: f(std::integral_constant<int, 2>{}); break;
     case 3: f(std::integral_constant<int, 3>{}); break;
     case 4: f(std::integral_constant<int, 4>{}); break;
-    case 5: f(std::integral_constant<int, 5>{}); break;
-    case 6: f(std::integral_constant<int, 6>{}); break;
-    case 7: f(std::integral_constant<int, 7>{}); break;
-    default: f(std::integral_constant<int, 8>{}); break;
+    default:
+        if constexpr (MAXL == 5) {
+            f(std::integral_constant<int, 5>{});
+        } else {
+            switch (L) {
+            case 5: f(std::integral_constant<int, 5>{}); break;
+            case 6: f(std::integral_constant<int, 6>{}); break;
+            case 7: f(std::integral_constant<int, 7>{}); break;
+            default: f(std::integral_constant<int, 8>{}); break;
+            }
+        }
+        break;
     }
 }
 

@@ -63,21 +63,9 @@
 // day decided from the record alone in front of the layers' first step (what
 // snow_core.h cema_day_io gains from, 25.9 -> 23.8 ms): 135 -> 197 ms.
 // profiles/r05_hyst_days_ab.txt)
-#ifndef HYST_IDLE_DAYS
-#define HYST_IDLE_DAYS 1
-#endif
-#ifndef HYST_SCALAR_WARM
-#define HYST_SCALAR_WARM 1
-#endif
 // (measured, off: 135.0 -> 140.0 ms -- these kernels wait, at two or three
 // waves per SIMD, for their dependent chains, not for issue slots, and the
 // masked move sits on the chain)
-#ifndef HYST_POT_BY_EXEC
-#define HYST_POT_BY_EXEC 0
-#endif
-#ifndef SNOW_ICE_FROST_DAYS
-#define SNOW_ICE_FROST_DAYS 1
-#endif
 template <int L, bool FIRST, bool SANE = false, bool REF = false>
 __device__ __forceinline__ double cema_hyst_day(
     const double *__restrict__ day, const double *__restrict__ psol,
@@ -87,7 +75,7 @@ __device__ __forceinline__ double cema_hyst_day(
     double (&G)[L], double (&eTG)[L],
     double (&sca)[L], double (&swe_max)[L])
 {
-    constexpr bool TWO_STEPS = HYST_IDLE_DAYS && SANE && !FIRST && !REF;
+    constexpr bool TWO_STEPS = SANE && !FIRST && !REF;
     double g_[L], e_[L], pot_[L];
     if constexpr (TWO_STEPS) {
         lanemask_t busy = 0;
@@ -106,25 +94,8 @@ __device__ __forceinline__ double cema_hyst_day(
             // temperatures are finite and not positive subnormals, snow_core.h
             // cema_frost_everywhere --: a scalar compare instead of a vector
             // one per layer and day)
-            const bool warm = HYST_SCALAR_WARM ? __double2hiint(temp) > 0
-                                               : temp > 0;
-#if HYST_POT_BY_EXEC
-            // (the lanes without melt get their +0 by ONE v_mov_b64 under an
-            // exec mask, where a 64-bit select is two v_cndmask_b32 --
-            // hbvedu.hip's snow routine does the same)
-            {
-                double pot = pm;
-                const lanemask_t melts = RR_LANES(e == 0 && warm);
-                lanemask_t saved;
-                asm("s_andn1_saveexec_b64 %1, %2\n\t"
-                    "v_mov_b64 %0, 0\n\t"
-                    "s_mov_b64 exec, %1"
-                    : "+v"(pot), "=&s"(saved) : "s"(melts) : "scc");
-                pot_[l] = pot;
-            }
-#else
+            const bool warm = __double2hiint(temp) > 0;
             pot_[l] = (e == 0 && warm) ? pm : 0.0;
-#endif
             busy |= RR_LANES(pot_[l] != 0.0);
         }
         if (snowfall == 0 && busy == 0) {
@@ -369,7 +340,7 @@ snow_gr4j_kernel(
             // snow routine's outflow, the layers' rain, never -0, keeps its
             // bits: the loop is skipped)
             bool frost = false;
-            if constexpr (SNOW_ICE_FROST_DAYS && SANE && !FIRST)
+            if constexpr (SANE && !FIRST)
                 frost = ice_tame && cema_frost_everywhere<L>(day);
             if (!frost) {
 #pragma unroll
@@ -538,7 +509,7 @@ __global__ __launch_bounds__(RR_BLOCK) void snow_gr4j_reference_kernel(
     if (sse) sse[i] = acc;
 }
 
-// ---- more than RR_CEMANEIGE_MAX_LAYERS elevation layers ----------------------
+// ---- more than RR_SNOWNEXT_REG_LAYERS elevation layers ----------------------
 // The same day step with a run-time layer count (as cemaneige_dyn_kernel does
 // for the plain snow routine): the per-layer states -- G, eTG and, with the
 // hysteresis, sca and the pre-melt SWE maximum -- live in an HBM scratch
@@ -713,7 +684,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
         rr_set_error("%s: pass all %d storage outputs or none", who, want);
         return RR_E_NULL;
     }
-    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true, N, 4)) {
+    if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true, N, 4, RR_SNOWNEXT_REG_LAYERS)) {
         rr_set_error("%s: workspace too small", who);
         return RR_E_WORKSPACE;
     }
@@ -724,7 +695,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     lay.i_ddf = lay.npar - 1;
     const int *d_plan = (const int *)workspace;
     // whatever lies behind the base workspace is unit-hydrograph scratch
-    const size_t base_ws = cema_ws_bytes(T, L, true, N, 4);
+    const size_t base_ws = cema_ws_bytes(T, L, true, N, 4, RR_SNOWNEXT_REG_LAYERS);
     double *uh_mem = (double *)((char *)workspace + base_ws);
     const int mem_cap = gr4j_mem_cap(workspace_bytes - base_ws, N);
     rc = rr_gr4j_plan_async(params, N, lay.npar, lay.i_x1 + 3,
@@ -738,7 +709,8 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     double *days, *gt, *state;
     rc = rr_cema_prepass(prec, mean_temp, frac_solid_prec, etp,
                          (qobs && sse) ? qobs : nullptr, T, (int)L, workspace,
-                         st, &days, &gt, &state, (int *)workspace + 3);
+                         st, &days, &gt, &state, (int *)workspace + 3,
+                         RR_SNOWNEXT_REG_LAYERS);
     if (rc != RR_OK) return rc;
     const dim3 grid((unsigned)rr_ceil_div(N, RR_BLOCK)), block(RR_BLOCK);
     const double *qo = (qobs && sse) ? qobs : nullptr;
@@ -747,7 +719,12 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     const size_t lds_bytes = GR4J_LDS_BYTES;
     const SnowOut out = {qsim, G, eTG, s_store, r_store, sca, icemelt,
                          snowmelt, ld};
-    if (L > RR_CEMANEIGE_MAX_LAYERS) {
+    // (the couplings of this file keep up to RR_SNOWNEXT_REG_LAYERS = 5
+    // layers -- Cemaneige's own five equal-area zones -- in registers; more
+    // run from the HBM state scratch: per-layer kernels for L = 6..8 were 45
+    // of the library's 525 kernels and 3.5 MB of its code for configurations
+    // nobody has asked for; removed in round 6)
+    if (L > RR_SNOWNEXT_REG_LAYERS) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
             snow_gr4j_dyn_kernel<UH, HYST, ICE>
@@ -790,7 +767,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
         if (rc != RR_OK) return rc;
     }
     // (no early return between the fork and the join inside dispatch_layers)
-    dispatch_layers((int)L, [&](auto LL) {
+    dispatch_layers<RR_SNOWNEXT_REG_LAYERS>((int)L, [&](auto LL) {
         gr4j_for_each_tier([&](auto uh) {
             using UH = decltype(uh);
             hipStream_t ts = st;
@@ -821,13 +798,13 @@ static int snow_gr4j_dev(const char *who, const double *prec,
 
 extern "C" size_t rr_snowgr4j_workspace_bytes(int64_t T, int64_t L, int64_t N)
 {
-    return cema_ws_bytes(T, L, true, N, 4);   // N only matters for L > 8
+    return cema_ws_bytes(T, L, true, N, 4, RR_SNOWNEXT_REG_LAYERS);   // N only matters for L > 5
 }
 
 extern "C" size_t rr_snowgr4j_workspace_bytes_x4(int64_t T, int64_t L,
                                                  int64_t N, double max_x4)
 {
-    return cema_ws_bytes(T, L, true, N, 4) +
+    return cema_ws_bytes(T, L, true, N, 4, RR_SNOWNEXT_REG_LAYERS) +
            rr_gr4j_uh_scratch_bytes(N, max_x4);
 }
 

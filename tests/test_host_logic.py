@@ -403,8 +403,8 @@ def test_debug_options_and_cache_release_need_no_gpu():
     assert lib.rr_debug_get_option(opt["hbv_variant"]) == -1
     assert lib.rr_debug_get_option(opt["gr4j_force_lds"]) == 0
     assert lib.rr_debug_get_option(opt["max_block_cols"]) == 0
-    with _lib.debug_option("hbv_variant", 2):
-        assert lib.rr_debug_get_option(opt["hbv_variant"]) == 2
+    with _lib.debug_option("hbv_variant", 3):
+        assert lib.rr_debug_get_option(opt["hbv_variant"]) == 3
         with _lib.debug_option("max_block_cols", 512):
             assert lib.rr_debug_get_option(opt["max_block_cols"]) == 512
         assert lib.rr_debug_get_option(opt["max_block_cols"]) == 0
@@ -415,7 +415,11 @@ def test_debug_options_and_cache_release_need_no_gpu():
     assert lib.rr_debug_get_option(opt["time_tiles"]) == -1
     assert lib.rr_debug_set_option(opt["time_tiles"], 1) == -4
     assert lib.rr_debug_get_option(opt["gr4j_variant"]) == 0
-    assert lib.rr_debug_set_option(opt["gr4j_variant"], 5) == -4
+    assert lib.rr_debug_set_option(opt["gr4j_variant"], 2) == -4
+    # the variants removed in round 6 are refused, not silently remapped
+    assert lib.rr_debug_set_option(opt["hbv_variant"], 1) == -4
+    assert lib.rr_debug_set_option(opt["hbv_variant"], 2) == -4
+    assert lib.rr_debug_set_option(opt["fused_variant"], 4) == -4
     assert b"does not take" in lib.rr_last_error()
     assert lib.rr_debug_get_option(opt["warm_records"]) == -1
     assert lib.rr_debug_set_option(opt["warm_records"], 2) == -4
