@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Driver of profiles/ubench/energy.hip: builds it, runs every mode for a few
+seconds and reads the GPU's socket power and shader clock from hwmon (bench.py's
+SocketSampler) over the second half of each run.
+
+    python profiles/ubench/energy.py [seconds] > profiles/r06_energy.txt
+"""
+import os
+import subprocess
+import sys
+import threading
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+MODES = {0: "32 v_fma_f64 per trip",
+         1: "+ scalar mix (64-B s_load burst, 12 SALU)",
+         2: "+ one nt sc1 8-B store per lane and trip",
+         3: "+ two LDS table reads per trip",
+         4: "the stores alone (no arithmetic)",
+         5: "24 FMAs + scalar mix + stores"}
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+    exe = os.path.join("/tmp", "rr_energy")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-o", exe,
+                           os.path.join(HERE, "energy.hip")])
+    idle = bench.SocketSampler(0)
+    with idle:
+        time.sleep(1.5)
+    rec = idle.record()
+    print("# idle: %s" % (rec and {k: round(v, 1) for k, v in rec.items()
+                                   if isinstance(v, float)}))
+    print("# mode | what | socket W | sclk MHz | wave-trips/s | stored GB/s |"
+          " cycles per trip per SIMD")
+    for mode, what in MODES.items():
+        s = bench.SocketSampler(0)
+        out = {}
+
+        def work():
+            out["txt"] = subprocess.run([exe, str(mode), str(seconds)],
+                                        capture_output=True,
+                                        text=True).stdout.strip()
+        th = threading.Thread(target=work)
+        with s:
+            th.start()
+            time.sleep(seconds * 0.5)
+            half = (len(s.power), len(s.clock))
+            th.join()
+        s.power, s.clock = s.power[half[0]:], s.clock[half[1]:]
+        r = s.record() or {}
+        f = dict(zip(out["txt"].split()[0::2], out["txt"].split()[1::2]))
+        wt = float(f.get("wave_trips_per_s", "nan"))
+        mhz = r.get("sclk_mhz") or float("nan")
+        # 1024 SIMDs: cycles a SIMD spends per wave-trip
+        cyc = mhz * 1e6 * 1024 / wt if wt else float("nan")
+        print("%d | %-44s | %7.1f | %7.1f | %.4e | %7.1f | %6.1f"
+              % (mode, what, r.get("socket_w", float("nan")), mhz, wt,
+                 float(f.get("stored_GBps", "nan")), cyc), flush=True)
+        time.sleep(1.0)
+
+
+if __name__ == "__main__":
+    main()
