@@ -742,6 +742,23 @@ class SocketSampler:
                 "source": "hwmon power1_input / freq1_input of this GPU"}
 
 
+# What the headline's ingredients cost at the socket (profiles/r06_energy.txt,
+# profiles/ubench/energy.hip): picojoules per fp64 lane-operation and per
+# byte stored with `nt sc1`, measured with each ingredient alone
+ENERGY_PJ = {"fp64_lane_op": 33.0, "stored_byte": 140.0}
+
+
+def energy_budget(valu_per_unit, bytes_per_unit):
+    """Dynamic energy of one model-timestep by component (nJ) at the
+    measured prices: which ingredient the power cap is spent on."""
+    if not valu_per_unit:
+        return None
+    v = valu_per_unit * ENERGY_PJ["fp64_lane_op"] * 1e-3
+    b = bytes_per_unit * ENERGY_PJ["stored_byte"] * 1e-3
+    return {"valu_nj": v, "store_nj": b, "valu_share": v / (v + b),
+            "source": "profiles/r06_energy.txt"}
+
+
 # what a SIMD with four or more waves needs per fp64 vector instruction
 # (profiles/ubench/valu_cost.hip, DESIGN.md 3.1): 4 is the hardware's rate,
 # 4.3 what a stream of dependent-free fp64 instructions is measured at
@@ -1045,6 +1062,10 @@ def compact_line(d):
     if r.get("power"):
         roof["power"] = _sig({k: r["power"].get(k) for k in
                               ("socket_w", "sclk_mhz", "cap_w")})
+        bud = r["power"].get("budget")
+        if bud:
+            roof["power"]["budget_nj"] = _sig(
+                {"valu": bud["valu_nj"], "store": bud["store_nj"]}, 4)
     if "binding_roof" in r:
         roof["binding_roof"] = r["binding_roof"]
     out["roofline"] = roof
@@ -1233,6 +1254,9 @@ def main():
                 # kernel once the socket's power cap has been paid
                 f_ms = floor_ms * CLOCK_GHZ_NOMINAL * 1e3 / pw["sclk_mhz"]
                 roof["valu"].update(valu_at_clock(f_ms, kernel_ms))
+        if r["power"] and valu:
+            # per-component budget of a model-timestep's dynamic energy
+            roof["power"]["budget"] = energy_budget(valu, r["bytes_per_step"])
         pw = r["power"] or {}
         if pw.get("socket_w") and pw.get("cap_w"):
             # `bound` stays what the contract asks for (the HBM roof the
