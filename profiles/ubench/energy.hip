@@ -19,7 +19,11 @@
 //           in the kernel, two on the days that take the power);
 //   mode 4  mode 2's stores with NO arithmetic (the store stream alone);
 //   mode 5  mode 0 with 24 instead of 32 FMAs per trip plus mode 2's stores
-//           (what removing a quarter of the arithmetic buys at the cap).
+//           (what removing a quarter of the arithmetic buys at the cap);
+//   mode 6  the stores alone, TWO adjacent columns per lane: one 16-byte
+//           store per lane and trip, 1 KiB per wave and row (2,048 waves);
+//   mode 7  two sets per lane: 64 FMAs + scalar mix + one 16-byte store per
+//           lane and trip (2,048 waves: the same sets as mode 2).
 //
 //   hipcc --offload-arch=gfx950 -O2 -o energy energy.hip
 //   ./energy <mode> <seconds>     -> prints trips/s per wave and GB/s stored
@@ -32,6 +36,7 @@
 #define TRIPS 4096
 
 typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 template <int MODE>
 __global__ __launch_bounds__(64) void soak(double *out, const double *rec,
@@ -43,15 +48,18 @@ __global__ __launch_bounds__(64) void soak(double *out, const double *rec,
     __syncthreads();
     double a[8];
     for (int k = 0; k < 8; ++k) a[k] = 1.0 + 0.001 * (threadIdx.x + k);
-    const long first = (long)blockIdx.x * 64;
+    constexpr bool WIDE = MODE == 6 || MODE == 7;
+    const long first = (long)blockIdx.x * (WIDE ? 128 : 64);
     double *row = out + first;
-    const int lane_off = threadIdx.x * 8;
+    const int lane_off = threadIdx.x * (WIDE ? 16 : 8);
     typedef const double __attribute__((address_space(4))) *cp_t;
     cp_t rp = (cp_t)rec;
     unsigned sx = blockIdx.x;
-    constexpr bool STORES = MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5;
-    constexpr bool SCALAR = MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5;
-    constexpr int FMAS = MODE == 4 ? 0 : (MODE == 5 ? 24 : 32);
+    constexpr bool STORES = MODE >= 2;
+    constexpr bool SCALAR = MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5 ||
+                            MODE == 7;
+    constexpr int FMAS = (MODE == 4 || MODE == 6) ? 0
+                         : (MODE == 5 ? 24 : (MODE == 7 ? 64 : 32));
     for (int t = 0; t < trips; ++t) {
         double r0 = 0, r1 = 0;
         if (SCALAR) {
@@ -82,13 +90,24 @@ __global__ __launch_bounds__(64) void soak(double *out, const double *rec,
             a[2] += tab[j];
             a[3] += tab[(j + 517) & 1023];
         }
-        if (STORES) {
+        if (STORES && !WIDE) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)row, (short)0, 512, 0x00020000);
             v2i d;
             d.x = __double2loint(a[t & 7]);
             d.y = __double2hiint(a[t & 7]);
             __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_off, 0, 18);
+            row += ld;
+        }
+        if (STORES && WIDE) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)row, (short)0, 1024, 0x00020000);
+            v4i d;
+            d.x = __double2loint(a[t & 7]);
+            d.y = __double2hiint(a[t & 7]);
+            d.z = __double2loint(a[(t + 1) & 7]);
+            d.w = __double2hiint(a[(t + 1) & 7]);
+            __builtin_amdgcn_raw_buffer_store_b128(d, rs, lane_off, 0, 18);
             row += ld;
         }
     }
@@ -103,8 +122,9 @@ int main(int argc, char **argv)
     const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
     hipDeviceProp_t pr;
     if (hipGetDeviceProperties(&pr, 0) != hipSuccess) return 1;
-    const int waves = pr.multiProcessorCount * 4 * WAVES_PER_SIMD;
-    const long ld = (long)waves * 64;
+    const bool wide = mode == 6 || mode == 7;
+    const int waves = pr.multiProcessorCount * 4 * WAVES_PER_SIMD / (wide ? 2 : 1);
+    const long ld = (long)waves * (wide ? 128 : 64);
     double *out = nullptr, *rec = nullptr;
     const size_t bytes = (size_t)ld * 8 * (TRIPS + 1);
     if (hipMalloc(&out, bytes) != hipSuccess) { printf("hipMalloc\n"); return 1; }
@@ -117,7 +137,9 @@ int main(int argc, char **argv)
         case 2: soak<2><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
         case 3: soak<3><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
         case 4: soak<4><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
-        default: soak<5><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        case 5: soak<5><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        case 6: soak<6><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        default: soak<7><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
         }
     };
     launch();
@@ -135,7 +157,7 @@ int main(int argc, char **argv)
     const bool stores = mode >= 2;
     printf("mode %d waves %d seconds %.2f trips_per_wave_per_s %.4e "
            "stored_GBps %.1f wave_trips_per_s %.4e\n", mode, waves, el,
-           trips_per_s, stores ? trips_per_s * waves * 512 / 1e9 : 0.0,
+           trips_per_s, stores ? trips_per_s * waves * (wide ? 1024 : 512) / 1e9 : 0.0,
            trips_per_s * waves);
     return 0;
 }

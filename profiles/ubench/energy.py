@@ -21,7 +21,9 @@ MODES = {0: "32 v_fma_f64 per trip",
          2: "+ one nt sc1 8-B store per lane and trip",
          3: "+ two LDS table reads per trip",
          4: "the stores alone (no arithmetic)",
-         5: "24 FMAs + scalar mix + stores"}
+         5: "24 FMAs + scalar mix + stores",
+         6: "stores alone, 16 B per lane (1 KiB per wave-row)",
+         7: "two sets per lane: 64 FMAs + scalar + 16-B store"}
 
 
 def main():
