@@ -76,6 +76,40 @@ def loop_lane_moves(body):
     return total, hot
 
 
+def outer_loop_moves(body):
+    """Lane moves of every OUTERMOST loop of more than 200 instructions --
+    the copies of a kernel's time loop (a kernel carries two: the one its
+    sane / tame waves run, and the general one) --, in code order: which copy
+    the moves of `in day loops` sit in."""
+    lines = body.split("\n")
+    labels = {}
+    for i, l in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = i
+    spans = []
+    for i, l in enumerate(lines):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            spans.append((labels[m.group(1)], i))
+    spans.sort(key=lambda ab: (ab[0], -ab[1]))
+    outer, end = [], -1
+    for a, b in spans:
+        if a > end:
+            outer.append([a, b])
+            end = b
+        elif b > end:               # overlapping back edges: one region
+            outer[-1][1] = b
+            end = b
+    out = []
+    for a, b in outer:
+        seg = lines[a:b + 1]
+        if sum(1 for l in seg if re.match(r"\s+[vs]_", l)) > 200:
+            out.append(sum(1 for l in seg
+                           if re.search(r"v_(?:read|write)lane_b32", l)))
+    return out
+
+
 def kernels_of(path):
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "k.s")
@@ -102,6 +136,8 @@ def kernels_of(path):
             occupancy=num(r"; Occupancy: (\d+)", info),
             lane_moves=len(re.findall(r"v_(?:read|write)lane_b32", body)),
             loop_moves=loop_lane_moves(body),
+            outer_moves=outer_loop_moves(body),
+            scratch_instrs=len(re.findall(r"\bscratch_(?:load|store)", body)),
             code=num(r"; codeLenInByte = (\d+)", info)))
     return rows
 
@@ -118,11 +154,19 @@ def main():
              "/ the blocks on the loops' straight path only (the unlikely "
              "slow blocks lie behind the back edge): what a wave executes "
              "per day, against what it executes once per launch or work "
-             "item." %
+             "item.  `scratch B (instr)`: the private segment the kernel "
+             "reserves and the scratch_load / scratch_store instructions in "
+             "its code (a reservation nobody touches costs nothing).  `per "
+             "time-loop copy`: lane moves inside each outermost loop of more "
+             "than 200 instructions, in code order -- a kernel with a sane / "
+             "tame copy of its time loop runs the first one for every wave "
+             "whose sets and forcing are civil." %
              " ".join(FLAGS[:-2]), "",
-             "| file | kernel | VGPRs | SGPRs | LDS B | scratch B | waves/SIMD "
-             "| lane moves | in day loops (all / straight path) | code B |",
-             "|---|---|---|---|---|---|---|---|---|---|"]
+             "| file | kernel | VGPRs | SGPRs | LDS B | scratch B (instr) | "
+             "waves/SIMD | lane moves | in day loops (all / straight path) | "
+             "per time-loop copy | code B |",
+             "|---|---|---|---|---|---|---|---|---|---|---|"]
+    count, code_total = 0, 0
     for f in sorted(os.listdir(CSRC)):
         if not f.endswith(".hip"):
             continue
@@ -133,11 +177,26 @@ def main():
             nice = re.sub(r"\(.*", "", nice).replace("void ", "")
             if wanted and not wanted.search(nice):
                 continue
-            lines.append("| %s | `%s` | %s | %s | %s | %s | %s | %s | %d / %d "
-                         "| %s |" % (
+            count += 1
+            code_total += r["code"] or 0
+            lines.append("| %s | `%s` | %s | %s | %s | %s (%d) | %s | %s | "
+                         "%d / %d | %s | %s |" % (
                 f, nice, r["vgpr"], r["sgpr"], r["lds"], r["scratch"],
-                r["occupancy"], r["lane_moves"], r["loop_moves"][0],
-                r["loop_moves"][1], r["code"]))
+                r["scratch_instrs"], r["occupancy"], r["lane_moves"],
+                r["loop_moves"][0], r["loop_moves"][1],
+                " / ".join(str(n) for n in r["outer_moves"]) or "-",
+                r["code"]))
+    cond = 0
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(CSRC, f)) as fh:
+                cond += len(re.findall(r"^\s*#\s*(?:if|ifdef|ifndef|elif)\b",
+                                       fh.read(), flags=re.M))
+    lines += ["", "%d kernel instantiations, %d bytes of code; %d preprocessor "
+              "conditionals (#if / #ifdef / #ifndef / #elif) in "
+              "rrmpg_amd/csrc (include guards and the host / device "
+              "branches of fastmath.h and invdiv.h among them)."
+              % (count, code_total, cond)]
     out = os.path.join(REPO, "profiles", "%s_isa_metadata.md" % tag)
     with open(out, "w") as fh:
         fh.write("\n".join(lines) + "\n")

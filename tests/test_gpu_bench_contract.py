@@ -76,7 +76,8 @@ def test_default_line_carries_every_config_and_the_valu_roof():
     stdout the driver keeps (numbers and short keys, profiles/BENCH_KEYS.md;
     the prose is in the side file the line names)."""
     d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3",
-              "--warmup", "1", "--extra-steps", "2", "--no-cpu-baseline"])
+              "--warmup", "1", "--extra-steps", "2", "--no-cpu-baseline",
+              "--soak-scale", "0.3"])
     assert d["_line_chars"] <= 7500, d["_line_chars"]
     assert d["config"]["sets_total"] == 1_000_000
     assert d["config"]["timesteps"] == 10957 and d["config"]["mode"] == "qsim"
