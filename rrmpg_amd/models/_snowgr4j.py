@@ -112,6 +112,19 @@ def run(hyst, ice, layers, frac_ice, inits, params, want_qsim, want_storages,
     return out, sse
 
 
+def resident(hyst, ice, layers, frac_ice, inits, device=None):
+    """simulate()'s forcing -- after its own checks and layer preprocessing
+    (`prepare`) -- as an HBM-resident ensemble
+    (rrmpg_amd.device.SnowGR4JEnsemble): what
+    ``monte_carlo(..., sampler='device')`` sweeps."""
+    from .. import device as rrdev
+    return rrdev.SnowGR4JEnsemble(
+        hyst, ice, layers[0], layers[1], layers[2], layers[3],
+        frac_ice=frac_ice if ice else None, snow_pack_init=inits[0],
+        thermal_state_init=inits[1], sca_init=inits[2], s_init=inits[3],
+        r_init=inits[4], **({} if device is None else {"device": device}))
+
+
 def check_loss_metric(loss_metric):
     if loss_metric not in ("mse", "kge"):
         raise ValueError("Invalid loss_metric. Choose 'mse' or 'kge'.")

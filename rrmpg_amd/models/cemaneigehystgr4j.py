@@ -97,6 +97,15 @@ class CemaneigeHystGR4J(BaseModel):
                             want_qsim, False, qobs)
         return out["qsim"], sse
 
+    def _resident(self, prec, mean_temp, min_temp, max_temp, etp,
+                  met_station_height, snow_pack_init=0, thermal_state_init=0,
+                  sca_init=0, s_init=0, r_init=0, altitudes=[], device=None):
+        layers, frac_ice, inits = core.prepare(
+            True, False, prec, mean_temp, min_temp, max_temp, etp, None,
+            met_station_height, snow_pack_init, thermal_state_init, sca_init,
+            s_init, r_init, altitudes)
+        return core.resident(True, False, layers, None, inits, device)
+
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp,
             met_station_height, loss_metric="mse", snow_pack_init=0,
             thermal_state_init=0, sca_init=0, s_init=0, r_init=0,

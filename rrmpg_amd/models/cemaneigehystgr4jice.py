@@ -84,6 +84,15 @@ class CemaneigeHystGR4JIce(BaseModel):
                             want_qsim, False, qobs)
         return out["qsim"], sse
 
+    def _resident(self, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
+                  met_station_height, snow_pack_init=0, thermal_state_init=0,
+                  sca_init=0, s_init=0, r_init=0, altitudes=[], device=None):
+        layers, fice, inits = core.prepare(
+            True, True, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
+            met_station_height, snow_pack_init, thermal_state_init, sca_init,
+            s_init, r_init, altitudes)
+        return core.resident(True, True, layers, fice, inits, device)
+
     def fit(self, obs, prec, mean_temp, min_temp, max_temp, etp, frac_ice,
             met_station_height, loss_metric="mse", snow_pack_init=0,
             thermal_state_init=0, sca_init=0, s_init=0, r_init=0,

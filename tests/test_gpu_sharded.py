@@ -242,6 +242,51 @@ def test_monte_carlo_device_sampler_over_eight_gpus_in_one_call(env,
                     sampler="device", **kw)
 
 
+@pytest.mark.parametrize("model_name", ["ABCModel", "GR4J", "Cemaneige",
+                                        "CemaneigeHystGR4J",
+                                        "CemaneigeGR4JIce",
+                                        "CemaneigeHystGR4JIce"])
+def test_every_model_sweeps_resident_over_shards(env, model_name):
+    """sampler='device' (and with it gpus=G) for every model class: the
+    couplings of the next tier included, whose single sweep of 300,007 sets
+    sorts its sets by hydrograph tier and runs the tiers' kernels side by
+    side, while its eight shards of 37,501 keep their order -- the same
+    scores, bit for bit."""
+    from rrmpg_amd.tools import monte_carlo
+    m, f, syn = env["models"], env["f"], env["syn"]
+    model = getattr(m, model_name)()
+    snow = dict(prec=f["prec"], mean_temp=f["temp"] - 3,
+                min_temp=f["tmin"] - 3, max_temp=f["tmax"] - 3,
+                met_station_height=syn.STATION_HEIGHT,
+                altitudes=list(syn.ALTITUDES))
+    if model_name == "ABCModel":
+        kw = dict(prec=f["prec"], initial_state=2.0)
+    elif model_name == "GR4J":
+        kw = dict(prec=f["prec"], etp=f["etp"], s_init=0.6, r_init=0.7)
+    elif model_name == "Cemaneige":
+        kw = snow
+    else:
+        kw = dict(snow, etp=f["etp"], s_init=0.6, r_init=0.7)
+        if "Ice" in model_name:
+            kw["frac_ice"] = np.array([0.02, 0.04, 0.25, 0.51, 0.71])
+    rec = model.get_random_params(3)
+    base = model.simulate(params=rec, **kw)
+    qobs = np.asarray(base[0] if isinstance(base, tuple) else base)[:, 1] \
+        * 0.9 + 0.05
+    n = 300_007
+    call = dict(qobs=qobs, return_qsim=False, score="nse", sampler="device",
+                seed=77)
+    one = monte_carlo(model, n, **call, **kw)
+    eight = monte_carlo(model, n, gpus=8, **call, **kw)
+    assert np.isfinite(one["mse"]).all()
+    assert np.array_equal(one["mse"], eight["mse"])
+    assert np.array_equal(one["nse"], eight["nse"])
+    # ... and they are the scores of the host path on the same population
+    some = np.asarray(one["params"])[:500]
+    _, sse = model._sweep(some, qobs, False, **kw)
+    assert np.array_equal(sse / len(qobs), one["mse"][:500])
+
+
 def test_ensemble_replica_shares_forcing_not_workspace(env):
     dev, f, torch = env["device"], env["f"], env["torch"]
     ens = dev.GR4JEnsemble(f["prec"], f["etp"], s_init=0.6, r_init=0.7)
