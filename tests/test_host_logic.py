@@ -630,3 +630,38 @@ def test_shard_bounds_and_the_collectives_argument_checks():
     assert lib.rr_allgather_metric(None, None, 0, None, 0, None) == -1
     assert b"NULL" in lib.rr_last_error()
     assert lib.rr_comm_destroy(None) == 0
+
+
+def test_bench_line_fits_the_drivers_tail():
+    """bench.compact_line on the round's full record (and on its worst case:
+    eight ranks' shards, every float at full precision, every extra
+    configuration with every field): at most bench.LINE_LIMIT characters, the
+    contract's fields and every BASELINE configuration's kernel_ms / frac /
+    valu.frac / parity_spot present."""
+    import json
+    import bench
+    with open(os.path.join(REPO, "profiles", "r06_bench_detail.json")) as fh:
+        full = json.load(fh)
+    line = bench.compact_line(full)
+    assert len(json.dumps(line, separators=(",", ":"))) <= bench.LINE_LIMIT
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"], key
+    ids = [e["id"] for e in line["extra_configs"]]
+    assert ids[:4] == ["cfg1", "cfg2", "cfg3", "cfg4"]
+    for e in line["extra_configs"][:4]:
+        assert e["kernel_ms"] > 0 and "frac" in e and "parity_spot" in e
+        assert e["valu"]["frac"] > 0
+    worst = json.loads(json.dumps(full))
+    worst["n_gpus"] = 8
+    worst["config"]["shards"] = [[k * 125000 + 1, (k + 1) * 125000 + 1]
+                                 for k in range(8)]
+    worst["value"] = 6.123456789012345e11
+    for e in worst["extra_configs"]:
+        e["kernel_ms"] = 123.45678901234567
+        e["parity_spot"] = 2.123456789012345e-13
+    assert len(json.dumps(bench.compact_line(worst),
+                          separators=(",", ":"))) <= bench.LINE_LIMIT
