@@ -20,6 +20,15 @@ class CemaneigeHystGR4J(BaseModel):
     model parameters are passed upon initialization, a random parameter set
     is generated.
 
+    Beyond the reference's interface (every default is the reference's
+    behaviour): ``simulate(params=...)`` runs any number of parameter sets in
+    ONE GPU call; ``fit(batched=True)`` evaluates a whole
+    differential-evolution generation per GPU sweep (about 100 times faster,
+    another optimiser trajectory than the reference's sequential search, which
+    stays the default); ``rrmpg_amd.tools.monte_carlo(model, num, qobs,
+    return_qsim=False, sampler='device', gpus=G)`` draws, sweeps and scores
+    the sets in the GPUs' memory.
+
     Args:
         params: (optional) Dictionary containing all model parameters as
             separate key/value pairs.
