@@ -140,7 +140,11 @@ def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs):
         raise ValueError("sampler='device' is not available for %s"
                          % type(model).__name__)
     devices = _shard_devices(gpus)
-    ens = model._resident(**kwargs)
+    # on the CURRENT device (a rank of a torchrun job has selected its GPU
+    # with torch.cuda.set_device / rrmpg_amd._lib.set_device), not on the
+    # ensembles' default "cuda:0"
+    ens = model._resident(
+        device=torch.device("cuda", torch.cuda.current_device()), **kwargs)
     if seed is None:
         # no key given: one draw from numpy's global generator, so that
         # np.random.seed(s) in front of the call still fixes the sweep
