@@ -223,7 +223,7 @@ __device__ __forceinline__ double mul_by_inverse_m(double a,
 // stores are NON-TEMPORAL (streamed past the L2's write-back lines).  With
 // plain stores the million-set sweeps that write qsim are a third slower
 // (HBV-Edu 19.2 -> 29.5 ms, 125k sets 2.78 -> 4.3: profiles/
-// r04_streaming_stores.txt); -DRR_OUT_NT=0 restores them.
+// r04_streaming_stores.txt).
 // cache-policy bits of the row stores (gfx94x / gfx950: 1 = sc0, 2 = nt,
 // 16 = sc1).  nt + sc1 measured against nt alone: HBV-Edu headline 19.55 ->
 // 19.18 ms, 125k sets 2.86 -> 2.82; nt + sc0 no different from nt

@@ -31,8 +31,8 @@
 // product that goes straight into a sum is contracted into it (one rounding
 // instead of two), the unit hydrographs' ordinates carry the 0.9 / 0.1 split
 // of the routed amount (gr4j_model.py:126-127), and the two store updates
-// x - x (1 - y) are taken as x y.  -DRR_GR4J_CONTRACT=0 builds the
-// reference's own sequence.
+// x - x (1 - y) are taken as x y.  (The reference's own sequence:
+// gr4j_reference.h, the kernel of the sets that are not civil.)
 #define GR4J_UH1_SHARE 0.9
 #define GR4J_UH2_SHARE 0.1
 
@@ -79,7 +79,7 @@ __device__ __forceinline__ lanemask_t gr4j_num_mask(double a)
 // from the reference semantics did not move (1.7e-13 over 30 years), and the two FMAs and
 // the numerator vote of the correctly rounded form were a tenth of the day's
 // vector work (GR4J 1M sets 53.6 -> 48.1 ms, scores 44.6 -> 40.4, 125k 6.7 ->
-// 6.1; fused 90.2 -> 84.7; -DRR_FAITHFUL_QUOTIENTS=0 builds the old form).
+// 6.1; fused 90.2 -> 84.7).
 // The only vote left is on the divisor, a loop invariant.  One numerator
 // test survives, on the production store (gr4j_production: the folded store
 // update must not overflow early), and it is the relaxed one: a is +0 or
@@ -653,11 +653,10 @@ struct Gr4jNoHook {
 // The day is cut where its data flow is feed-forward: the PRODUCTION half
 // (net rainfall, production store, percolation, :89-123) only ever hands the
 // routed amount p_r to the ROUTING half (hydrographs, exchange, routing
-// store, discharge, :126-154), which never feeds anything back.  The
-// wave-specialised kernels (gr4j.hip gr4j_pipe_kernel, cemaneige.hip) run
-// the halves in different waves of a workgroup, a few days apart; everybody
-// else calls them back to back through gr4j_step_net.  Same instruction
-// sequence either way, so the results are bit-identical.
+// store, discharge, :126-154), which never feeds anything back.  (Rounds 3-5
+// carried wave-specialised kernels that ran the halves in different waves of
+// a workgroup; they lost and were removed in round 6.)  The kernels call the
+// halves back to back through gr4j_step_net.
 // `wet` as a Gr4jUniformWet (the plain GR4J kernel, whose pre-pass decides it
 // once per day for every set -- the forcing is shared): the day record's 0 / 1
 // in a scalar register.  The branch's two outcomes are then formed with that

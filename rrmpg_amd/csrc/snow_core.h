@@ -124,13 +124,10 @@ struct CemaGt { double gt, rgt; };
 // bit-identical to it; snow pack and outflow are within 1e-14 of it over 30
 // years (tests/conftest.py SNOW_TOL = 1e-12).  Cemaneige 1M sets 38.9 -> 35.0
 // ms, scores 33.4 -> 27.9; fused 83.1 -> 77.6, its 125k shard 12.9 -> 11.7.
-// -DRR_SNOW_FAITHFUL=0 builds the correctly rounded forms (bit-identical
-// snow pack).
 typedef const CemaGt __attribute__((address_space(4))) *cema_gt_ptr_t;
 
 // c / L (the layer mean, np.mean's division by the size): L is a constant --
-// one multiply by RN(1/L) (RR_SNOW_FAITHFUL), or the correctly rounded 3-FMA
-// quotient of invdiv.h under its numerator vote.
+// one multiply by RN(1/L).
 template <int L, class V = CarefulVotes>
 __device__ __forceinline__ double cema_layer_mean(double c, V &&votes = V())
 {
