@@ -118,6 +118,18 @@ def parse_args():
                     help="N = 1 only: skip the short timings of the other "
                          "BASELINE configurations after the headline")
     ap.add_argument("--extra-steps", type=int, default=3)
+    ap.add_argument("--live-counters", default="all",
+                    choices=["all", "headline", "none"],
+                    help="N = 1 only: three short rocprofv3 --pmc passes "
+                         "(FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU -- one pass "
+                         "each) of a child run of the workload, which measure "
+                         "roofline.traffic and the instruction count on THIS "
+                         "box: all = the headline and BASELINE configs[1]-[4] "
+                         "(default), headline, none (the committed "
+                         "profiles/traffic.json then stands in, as it does "
+                         "for the other extra configurations)")
+    ap.add_argument("--no-live-counters", dest="live_counters",
+                    action="store_const", const="none")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="N = 1 only: skip the PCIe-inclusive timing of the "
                          "host-pointer family (HBVEdu.simulate, 100k sets)")
@@ -679,6 +691,92 @@ def traffic_is_stale(model):
         return True
 
 
+def live_counters(args, n, t, per_pass_timeout=120):
+    """HBM traffic per launch and vector instructions per model-timestep of
+    THIS workload measured on THIS box: three rocprofv3 passes (--kernel-trace
+    --pmc, one counter group each: FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) over
+    a short child run of this script, corrected as MI355X_MICROARCH.md's HBM
+    section prescribes (KiB -> x1024; gfx950's FETCH_SIZE counts 64 B per
+    128-B request: x2) -- profiles/collect.sh's recipe, without the committed
+    file in between.  The sweep kernel is the one with the largest total
+    duration; only its launches at its largest grid count (the one-set helper
+    launch does not).  Returns a dict or None (no rocprofv3, a pass that
+    fails or runs into its timeout: the committed numbers then stand in)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1",
+             "--steps", "3", "--warmup", "1", "--model", args.model, "--mode",
+             args.mode, "--sets", str(args.sets), "--days", str(args.days),
+             "--catchments", str(args.catchments), "--score", args.score,
+             "--sampler", args.sampler, "--no-cpu-baseline",
+             "--no-extra-configs", "--no-power-soak", "--no-parity-spot",
+             "--no-end-to-end", "--live-counters", "none"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    t0 = time.perf_counter()
+    for group in (["FETCH_SIZE"], ["WRITE_SIZE"],
+                  ["SQ_INSTS_VALU", "SQ_WAVES"]):
+        out = tempfile.mkdtemp(prefix="rr_pmc_")
+        cmd = [exe, "--kernel-trace", "--pmc", *group, "--output-format",
+               "csv", "-d", out, "--"] + child
+        try:
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env,
+                                    stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=per_pass_timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)   # the group WE started
+                proc.wait()
+                return None
+            if rc != 0:
+                return None
+            rows = []
+            for f in glob.glob(os.path.join(out, "*",
+                                            "*_counter_collection.csv")):
+                with open(f) as fh:
+                    rows += list(csv.DictReader(fh))
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+        if not rows:
+            return None
+        total = {}
+        for r in rows:
+            if r["Counter_Name"] == group[0]:
+                total[r["Kernel_Name"]] = total.get(r["Kernel_Name"], 0) + (
+                    int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        if not total:
+            return None
+        kern = max(total, key=total.get)
+        grid = max(float(r["Grid_Size"]) for r in rows
+                   if r["Kernel_Name"] == kern)
+        for name in group:
+            vals = [float(r["Counter_Value"]) for r in rows
+                    if r["Kernel_Name"] == kern and r["Counter_Name"] == name
+                    and float(r["Grid_Size"]) == grid]
+            if not vals:
+                return None
+            got[name] = sum(vals) / len(vals)
+        got["kernel"] = kern.split("(")[0][:100]
+    jobs = -(-args.sets // 64) * max(1, args.catchments)
+    return {"traffic": got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024,
+            "read_bytes_corrected": got["FETCH_SIZE"] * 1024 * 2,
+            "write_bytes": got["WRITE_SIZE"] * 1024,
+            "valu_instr_per_unit": got["SQ_INSTS_VALU"] / (jobs * t),
+            "waves": got["SQ_WAVES"], "kernel": got["kernel"],
+            "seconds": time.perf_counter() - t0,
+            "source": "rocprofv3 --kernel-trace --pmc, three passes of a "
+                      "3-step child run on this box (FETCH_SIZE x 2048 + "
+                      "WRITE_SIZE x 1024 bytes per launch)"}
+
+
 class SocketSampler:
     """Socket power and shader clock of one GPU, read from its hwmon files
     (power1_input in microwatts, freq1_input in hertz, power1_cap) every few
@@ -982,6 +1080,17 @@ def extra_configs(args, device):
                                                r["qsim"], r["sweep"].sse,
                                                r["qobs"]))}
             traffic, valu = traffic_record(a, r["n"], r["t"])
+            rec["traffic_from"] = "profiles/traffic.json" if traffic else None
+            if args.live_counters == "all" and ident.startswith("cfg"):
+                # BASELINE configs[1]-[4]: this box's own counter passes
+                try:
+                    live = live_counters(a, r["n"], r["t"])
+                except Exception:
+                    live = None
+                if live:
+                    traffic, valu = live["traffic"], live["valu_instr_per_unit"]
+                    rec["traffic_from"] = "this run"
+                    rec["live_counters"] = live
             if traffic:
                 rec["traffic"] = traffic
             # clock and socket power under THIS sweep (a 1.2-s soak): the
@@ -1056,8 +1165,13 @@ def compact_line(d):
     r = d["roofline"]
     roof = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac",
                               "traffic", "kernel_ms")}
-    roof["traffic_from"] = ("stale" if "stale" in r["source"]
+    roof["traffic_from"] = ("this run (rocprofv3 --pmc passes)"
+                            if r.get("live_counters")
+                            else "stale" if "stale" in r["source"]
                             else "profiles/traffic.json")
+    if r.get("live_counters") and r.get("committed_counters", {}).get(
+            "traffic"):
+        roof["traffic_committed"] = r["committed_counters"]["traffic"]
     roof["valu_instr_per_unit"] = r.get("valu_instr_per_unit")
     if "valu" in r:
         roof["valu"] = _sig({k: r["valu"].get(k) for k in
@@ -1095,6 +1209,7 @@ def compact_line(d):
                "finite": e["scores_finite"], "parity_spot": e["parity_spot"]}
         if e.get("traffic"):
             rec["traffic"] = e["traffic"]
+            rec["live"] = e.get("traffic_from") == "this run"
         if e.get("power"):
             rec["w"] = e["power"].get("socket_w")
             rec["mhz"] = e["power"].get("sclk_mhz")
@@ -1201,6 +1316,18 @@ def main():
     if rank == 0:
         value = r["total_units"] * t * args.steps / r["elapsed"]
         traffic, valu = traffic_record(args, n, t)
+        committed = {"traffic": traffic, "valu_instr_per_unit": valu}
+        live = None
+        if world == 1 and args.live_counters != "none":
+            # this box's own counter passes (the GPU is ours: nothing else of
+            # this script runs meanwhile; the sweep's buffers stay allocated,
+            # the child's fit beside them)
+            try:
+                live = live_counters(args, n, t)
+            except Exception:
+                live = None
+            if live:
+                traffic, valu = live["traffic"], live["valu_instr_per_unit"]
         what = {"qsim": "qsim[T,N] written to HBM + fused per-set MSE",
                 "metric": "fused per-set MSE only",
                 "storages": "qsim and every state series written to HBM + "
@@ -1225,16 +1352,21 @@ def main():
             # traffic and instruction count: committed counter passes of this
             # workload, not measured in this run
             "source": {"achieved": "HIP events, this run",
-                       "traffic": "profiles/traffic.json (rocprofv3 --pmc "
-                                  "passes, profiles/collect.sh)",
-                       "valu.instr_per_unit": "profiles/traffic.json "
-                                              "(SQ_INSTS_VALU pass)"},
+                       "traffic": (live["source"] if live else
+                                   "profiles/traffic.json (rocprofv3 --pmc "
+                                   "passes, profiles/collect.sh)"),
+                       "valu.instr_per_unit": ("the same passes "
+                                               "(SQ_INSTS_VALU)" if live else
+                                               "profiles/traffic.json "
+                                               "(SQ_INSTS_VALU pass)")},
+            "live_counters": live,
+            "committed_counters": committed,
             "valu_instr_per_unit": valu,
             # socket power and shader clock of the same sweep in steady
             # state (rank 0's GPU): at the cap, the kernel is power-bound
             "power": r["power"],
         }
-        if traffic_is_stale(args.model):
+        if not live and traffic_is_stale(args.model):
             roof["source"]["stale"] = (
                 "profiles/traffic.json was collected on other kernel sources "
                 "than this tree's (rrmpg_amd/utils/buildid.py): traffic and "
