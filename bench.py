@@ -710,6 +710,12 @@ def live_counters(args, n, t, per_pass_timeout=120):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None
+    # not under a profiler ourselves (profiles/collect.sh, a driver's own
+    # rocprofv3 around this script): a profiler inside a profiled process is
+    # asking for trouble -- the committed numbers then stand in
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in
+           os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     child = [sys.executable, os.path.abspath(__file__), "--gpus", "1",
              "--steps", "3", "--warmup", "1", "--model", args.model, "--mode",
              args.mode, "--sets", str(args.sets), "--days", str(args.days),

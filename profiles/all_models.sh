@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.." || exit 1
 run() {
   tag=$1; shift
-  timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --no-power-soak --steps ${STEPS:-10} --warmup 2 "$@" 2>/dev/null | python -c "
+  timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --no-power-soak --live-counters none --steps ${STEPS:-10} --warmup 2 "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('%-28s kernel_ms=%8.3f ms_per_step=%8.3f value=%.3e frac=%.3f parity=%s' % ('$tag', d['roofline']['kernel_ms'], d['ms_per_step'], d['value'], d['roofline']['frac'] or 0, d.get('parity_spot')))"

@@ -4,7 +4,7 @@
 # samples every 0.7 s; the first seconds of each run are setup).
 cd "$(dirname "$0")/.." || exit 1
 for mode in qsim metric; do
-  timeout 120 python bench.py --no-cpu-baseline --no-parity-spot --no-extra-configs --no-power-soak \
+  timeout 120 python bench.py --no-cpu-baseline --no-parity-spot --no-extra-configs --no-power-soak --live-counters none \
       --steps 600 --warmup 3 --mode $mode > /tmp/cp_$mode.json 2>/dev/null &
   BP=$!
   sleep 6

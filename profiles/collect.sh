@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs --no-power-soak $EXTRA"
+CMD="python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs --no-power-soak --live-counters none $EXTRA"
 # 1) kernel trace + stats (own run, no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 # 2) HBM traffic counters, one pass each (FETCH_SIZE and WRITE_SIZE do not fit

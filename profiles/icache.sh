@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/icache_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-configs --no-power-soak $*"
+CMD="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-configs --no-power-soak --live-counters none $*"
 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc" -- $CMD > "$OUT/pmc.log" 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections
