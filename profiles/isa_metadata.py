@@ -110,11 +110,17 @@ def outer_loop_moves(body):
     return out
 
 
+# per-file flags of rrmpg_amd/csrc/Makefile (FLAGS_<file>)
+FILE_FLAGS = {"snownext_hyst.hip": ["-mllvm",
+                                    "-amdgpu-sched-strategy=iterative-ilp"]}
+
+
 def kernels_of(path):
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "k.s")
-        subprocess.run(["hipcc", *FLAGS, "-o", asm, path], check=True,
-                       capture_output=True)
+        subprocess.run(["hipcc", *FLAGS,
+                        *FILE_FLAGS.get(os.path.basename(path), []), "-o",
+                        asm, path], check=True, capture_output=True)
         text = open(asm).read()
     rows = []
     # one function body per .amdhsa_kernel; the "; Kernel info" comment block

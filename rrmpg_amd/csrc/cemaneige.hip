@@ -32,7 +32,7 @@
 //   [0,L) snow, [L,2L) rain, [2L,3L) mean_temp, [3L] etp, then the day's
 //   observation (cema_day_meta)
 // `insane`: counts the values that rule out the SANE form of the snow routine
-// (snow_core.h cema_day, snownext.hip cema_hyst_day): a snowfall that is not
+// (snow_core.h cema_day, snownext_kernels.h cema_hyst_day): a snowfall that is not
 // a number in [0, 1e290], a temperature that is not finite (or beyond 1e300),
 // a rain whose sign bit is set, a positive subnormal temperature.
 // Zeroed by rr_cema_prepass before the launch.
@@ -58,7 +58,7 @@ __global__ void cema_pack(const double *__restrict__ prec,
     d[2 * L + l] = temp;
     if (etp && l == 0) d[3 * L] = etp[t];
     // (... or a rain of -0 or below: on a day without melt the hysteresis
-    // routine's outflow is the rain itself, snownext.hip)
+    // routine's outflow is the rain itself, snownext_kernels.h)
     if (!(snow >= 0.0 && snow <= 1e290) || !(fabs(temp) <= 1e300) ||
         __builtin_signbit(rain) || (temp > 0.0 && temp < 0x1p-1022))
         atomicAdd(insane, 1ull);
@@ -349,7 +349,7 @@ cemaneigegr4j_kernel(
     // Requested at the top of the day, every wave would sit out the
     // scalar-load latency once per day, which a sweep of one or two waves per
     // SIMD cannot hide (measured: 65k sets 16.2 -> 14.0 ms, 125k 18.3 -> 17.9,
-    // a million unchanged; the hysteresis / ice kernels of snownext.hip,
+    // a million unchanged; the hysteresis / ice kernels of snownext_kernels.h,
     // shorter of SGPRs still, lose with it and keep the load at the top).
     CemaGtRegs<L> gt_regs;
     if constexpr (SMALL) cema_gt_to_regs<L>(gt_tab, gt_regs);

@@ -412,7 +412,7 @@ extern "C" size_t rr_gr4j_workspace_bytes_x4(int64_t T, int64_t N,
     return rr_gr4j_workspace_bytes(T, N) + rr_gr4j_uh_scratch_bytes(N, max_x4);
 }
 
-// Shared by gr4j.hip, cemaneige.hip and snownext.hip: enqueues the scan of
+// Shared by gr4j.hip, cemaneige.hip and snownext_kernels.h: enqueues the scan of
 // x4 that leaves the plan {max ceil(x4), #bad sets, scratch capacity} in
 // d_plan (gr4j_core.h).  Asynchronous: nothing is read back.
 int rr_gr4j_plan_async(const double *params, int64_t N, int stride,

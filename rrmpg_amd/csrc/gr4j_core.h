@@ -553,7 +553,7 @@ static inline void gr4j_for_each_tier(F &&f)
 // their small-sweep variants (at most two waves per SIMD) hold them in VGPRs.
 enum { GR4J_CONSTS_SGPR = 0, GR4J_CONSTS_VGPR = 1, GR4J_CONSTS_JIT = 2,
        // ... and the exponential tanh instead of the rational one: the ice
-       // kernels (snownext.hip), which spill already and lose 6-9 % to the
+       // kernels (snownext_kernels.h), which spill already and lose 6-9 % to the
        // approximant's live ranges (ice 86.4 -> 92.0 ms, hysteresis + ice
        // 165 -> 181) where every other kernel gains 3-11 %
        GR4J_CONSTS_JIT_EXP = 3 };

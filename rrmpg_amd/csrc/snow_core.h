@@ -1,5 +1,5 @@
 // snow_core.h -- pieces shared by cemaneige.hip (Cemaneige, CemaneigeGR4J) and
-// snownext.hip (hysteresis / ice-melt couplings): the per-day Cemaneige step,
+// snownext_kernels.h (hysteresis / ice-melt couplings): the per-day Cemaneige step,
 // the layer-count dispatch, workspace sizing and the forcing pre-pass.
 #pragma once
 

@@ -12,7 +12,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                      "csrc")
 _KERNEL_FILE = {"hbvedu": "hbvedu.hip", "abc": "abc.hip", "gr4j": "gr4j.hip",
                 "cemaneige": "cemaneige.hip", "cemaneigegr4j": "cemaneige.hip",
-                "cemaneigehystgr4j": "snownext.hip",
+                "cemaneigehystgr4j": "snownext_hyst.hip",
                 "cemaneigegr4jice": "snownext.hip",
                 "cemaneigehystgr4jice": "snownext.hip"}
 

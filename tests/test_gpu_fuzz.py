@@ -908,7 +908,7 @@ def test_reference_kernels_hand_gr4j_the_reference_snow_outflow(models,
     which numba's max(0, .) swallows together with the day's discharge -- 0
     where the reference has 9e302.  The one-lane kernels of the sets that are
     not civil therefore run the reference's own snow day (csrc/snow_core.h
-    cema_ref_day, csrc/snownext.hip cema_hyst_day<.., REF>): the routing
+    cema_ref_day, csrc/snownext_kernels.h cema_hyst_day<.., REF>): the routing
     store is empty on the very days the reference's is, and the discharge
     follows it.  No probes, no excuses: rtol 1e-9 on every day (pow / tanh
     of the device library against glibc's), zeros and non-finite values in

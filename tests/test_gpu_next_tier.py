@@ -347,7 +347,7 @@ def test_next_tier_resident_ensembles_match_host_path(models):
 
 def test_next_tier_days_decided_from_the_record(models, oracle):
     """The days the kernels decide for the whole wave from the day's record
-    (snow_core.h cema_day_io: frost in every layer; snownext.hip: the
+    (snow_core.h cema_day_io: frost in every layer; snownext_kernels.h: the
     hysteresis routine's idle days, the ice-melt loop skipped under frost):
     long frosts, dry spells, temperatures of exactly +0 and -0, layers that
     disagree -- and a wave that must NOT take the ice-melt shortcut, because
