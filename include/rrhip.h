@@ -144,7 +144,17 @@ int rr_release_cached_memory(void);
  *                       root of block r -- no padding, nothing
  *                       allocated.  Enqueued on `stream` (hipStream_t),
  *                       returns at once like the *_simulate_dev family.
- *   rr_comm_destroy                                                          */
+ *   rr_comm_destroy
+ * One process that drives several GPUs itself (the clique of SURVEY.md 8e's
+ * sketch) uses instead of the id exchange:
+ *   rr_comm_init_all    comms_out[ndev]: the rank-j communicator lives on
+ *                       devices[j] (NULL: devices 0..ndev-1; no device twice)
+ *                       (ncclCommInitAll); each is destroyed with
+ *                       rr_comm_destroy
+ *   rr_comm_group_start / rr_comm_group_end   bracket the ndev
+ *                       rr_allgather_metric calls the one thread issues, one
+ *                       per communicator, each with its device's buffers and
+ *                       stream (ncclGroupStart / ncclGroupEnd)                */
 #define RR_COMM_ID_BYTES 128
 int rr_shard_bounds(int64_t n_total, int world, int rank, int64_t *first,
                     int64_t *stop);
@@ -153,6 +163,9 @@ int rr_comm_init(void **comm_out, int world, int rank, const void *id);
 int rr_allgather_metric(void *comm, const double *local, int64_t n_local,
                         double *all, int64_t n_total, void *stream);
 int rr_comm_destroy(void *comm);
+int rr_comm_init_all(void **comms_out, int ndev, const int *devices);
+int rr_comm_group_start(void);
+int rr_comm_group_end(void);
 
 /* Options: which GPUs a host-pointer call spreads over, and which kernel
  * variant / blocking a call uses where the library's own choice (by sweep

@@ -57,6 +57,11 @@ _SIGNATURES = {
                                            _i64, ctypes.c_void_p, _i64,
                                            ctypes.c_void_p]),
     "rr_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "rr_comm_init_all": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_int)]),
+    "rr_comm_group_start": (ctypes.c_int, []),
+    "rr_comm_group_end": (ctypes.c_int, []),
     "rr_debug_set_option": (ctypes.c_int, [ctypes.c_int, _i64]),
     "rr_debug_get_option": (_i64, [ctypes.c_int]),
     "rr_call_options_init": (None, [_optp]),

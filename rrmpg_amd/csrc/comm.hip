@@ -14,6 +14,13 @@
 //   rr_allgather_metric(comm, local block, n_total scores out, stream)
 //   rr_comm_destroy
 //
+// ... or, for ONE process that drives several GPUs (SURVEY.md 8e's sketch:
+// ncclCommInitAll + ncclGroupStart / End):
+//
+//   rr_comm_init_all   (comms[ndev], one per device of `devices`)
+//   rr_comm_group_start; rr_allgather_metric(comms[j], ..., stream_j) for
+//   every j from the one thread; rr_comm_group_end
+//
 // The blocks are rrmpg_amd.sharding.shard_bounds' (contiguous, sizes differ
 // by at most one, the first n_total % world ranks hold the longer ones).
 // Equal blocks (n_total % world == 0 -- every BASELINE configuration) are ONE
@@ -48,6 +55,7 @@ struct Rccl {
     void *handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t,
                               int, ncclComm_t, hipStream_t) = nullptr;
@@ -79,6 +87,8 @@ const Rccl *rccl()
         g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
         g_rccl.CommInitRank =
             (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+        g_rccl.CommInitAll =
+            (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
         g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
         g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
         g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
@@ -88,7 +98,8 @@ const Rccl *rccl()
             (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
         g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank &&
                     g_rccl.CommDestroy && g_rccl.Broadcast &&
-                    g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd;
+                    g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd &&
+                    g_rccl.CommInitAll;
     });
     return g_rccl.ok ? &g_rccl : nullptr;
 }
@@ -118,10 +129,10 @@ const Rccl *need_rccl(const char *who)
 
 static_assert(sizeof(ncclUniqueId) == RR_COMM_ID_BYTES, "rrhip.h");
 
-// Test hook (not part of include/rrhip.h): table = seven function pointers in
+// Test hook (not part of include/rrhip.h): table = eight function pointers in
 // the order {GetUniqueId, CommInitRank, CommDestroy, Broadcast, AllGather,
-// GroupStart, GroupEnd} that answer instead of librccl from now on; NULL
-// restores the library.
+// GroupStart, GroupEnd, CommInitAll} that answer instead of librccl from now
+// on; NULL restores the library.
 extern "C" int rrdbg_comm_inject(void *const *table)
 {
     if (!table) {
@@ -136,6 +147,7 @@ extern "C" int rrdbg_comm_inject(void *const *table)
     g_injected.AllGather = (decltype(g_injected.AllGather))table[4];
     g_injected.GroupStart = (decltype(g_injected.GroupStart))table[5];
     g_injected.GroupEnd = (decltype(g_injected.GroupEnd))table[6];
+    g_injected.CommInitAll = (decltype(g_injected.CommInitAll))table[7];
     g_injected.ok = true;
     g_use_injected = true;
     return RR_OK;
@@ -180,6 +192,59 @@ extern "C" int rr_comm_init(void **comm_out, int world, int rank,
     }
     *comm_out = c;
     return RR_OK;
+}
+
+// One process, several GPUs: a clique of `ndev` communicators, comms_out[j]
+// the rank-j communicator on device devices[j] (NULL: devices 0..ndev-1).
+// RCCL refuses two ranks on one device, so the devices must differ.
+extern "C" int rr_comm_init_all(void **comms_out, int ndev, const int *devices)
+{
+    if (!comms_out) {
+        rr_set_error("rr_comm_init_all: comms_out is NULL");
+        return RR_E_NULL;
+    }
+    if (ndev < 1 || ndev > 1024) {
+        rr_set_error("rr_comm_init_all: %d devices", ndev);
+        return RR_E_SIZE;
+    }
+    for (int j = 0; j < ndev; ++j) comms_out[j] = nullptr;
+    if (devices)
+        for (int j = 0; j < ndev; ++j)
+            for (int k = 0; k < j; ++k)
+                if (devices[j] == devices[k]) {
+                    rr_set_error("rr_comm_init_all: device %d is listed twice "
+                                 "(one rank per GPU)", devices[j]);
+                    return RR_E_PARAM;
+                }
+    const Rccl *r = need_rccl("rr_comm_init_all");
+    if (!r) return RR_E_NODEVICE;
+    ncclComm_t *raw = new ncclComm_t[ndev];
+    const ncclResult_t rc = r->CommInitAll(raw, ndev, devices);
+    if (rc != ncclSuccess) {
+        delete[] raw;
+        return fail(r, "ncclCommInitAll", rc);
+    }
+    for (int j = 0; j < ndev; ++j) comms_out[j] = new RrComm{raw[j], ndev, j};
+    delete[] raw;
+    return RR_OK;
+}
+
+// Brackets the collectives one thread issues for several communicators of a
+// clique (ncclGroupStart / ncclGroupEnd); they nest with the group
+// rr_allgather_metric opens itself for ragged blocks.
+extern "C" int rr_comm_group_start(void)
+{
+    const Rccl *r = need_rccl("rr_comm_group_start");
+    if (!r) return RR_E_NODEVICE;
+    const ncclResult_t rc = r->GroupStart();
+    return rc == ncclSuccess ? RR_OK : fail(r, "ncclGroupStart", rc);
+}
+extern "C" int rr_comm_group_end(void)
+{
+    const Rccl *r = need_rccl("rr_comm_group_end");
+    if (!r) return RR_E_NODEVICE;
+    const ncclResult_t rc = r->GroupEnd();
+    return rc == ncclSuccess ? RR_OK : fail(r, "ncclGroupEnd", rc);
 }
 
 extern "C" int rr_comm_destroy(void *comm)

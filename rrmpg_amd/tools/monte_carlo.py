@@ -108,7 +108,26 @@ def _resident_scores(sse, qobs, score):
     return result
 
 
-def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs):
+_cliques = {}
+
+
+def _clique(devices):
+    """In-process RCCL communicators, one per device of `devices` (the C-ABI's
+    rr_comm_init_all), kept for the life of the process."""
+    import ctypes
+    key = tuple(devices)
+    if key not in _cliques:
+        lib = _lib.load()
+        comms = (ctypes.c_void_p * len(key))()
+        devs = (ctypes.c_int * len(key))(*key)
+        _lib.check(lib.rr_comm_init_all(comms, len(key), devs),
+                   "rr_comm_init_all")
+        _cliques[key] = [ctypes.c_void_p(c) for c in comms]
+    return _cliques[key]
+
+
+def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs,
+                          exchange="host"):
     """sampler='device': sets drawn in HBM (numpy's Philox stream under
     `seed`, rrmpg_amd.device.sample_params), swept against the resident
     forcing, only the scores come back.
@@ -124,8 +143,14 @@ def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs):
       its 8 B per set straight into its slice of ONE
       pinned host vector -- G copies of num/G x 8 B over G PCIe links beside
       each other, no GPU-to-GPU step: the scores' destination is the host
-      (the all-gather of rrmpg_amd.sharding / rr_allgather_metric is for
-      jobs whose ranks each need all scores in HBM).
+      (``exchange='host'``, the default).  ``exchange='rccl'``: the shards'
+      sums are all-gathered over RCCL / xGMI first -- one in-process
+      communicator per GPU (rr_comm_init_all), the G rr_allgather_metric
+      calls of the one thread inside a group -- so that EVERY GPU holds all
+      `num` sums (result['sse_device'], one tensor per GPU: a caller that
+      goes on working on the GPUs, resampling around the best sets, say);
+      the host's copy then comes from the first GPU alone.  One rank per
+      device: G may not exceed the number of GPUs.
     * inside an initialised ``torch.distributed`` group of several ranks (one
       process per GPU under torchrun): this rank draws and sweeps its block
       of rrmpg_amd.sharding.shard_bounds and the one collective of the job,
@@ -170,7 +195,10 @@ def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs):
         result['bounds'] = (first, stop)
         return result
 
-    if devices is None or len(devices) == 1 or num == 1:
+    if exchange == "rccl" and devices is None:
+        devices = [torch.cuda.current_device()]
+    if exchange != "rccl" and (devices is None or len(devices) == 1
+                               or num == 1):
         params = rrdev.sample_params(model, num, seed, device=ens.device)
         q = torch.as_tensor(qobs, dtype=torch.float64, device=ens.device)
         sse = ens.run(params, None, qobs=q)
@@ -182,6 +210,9 @@ def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs):
 
     devices = devices[:num]
     count = len(devices)
+    if exchange == "rccl" and len(set(devices)) != count:
+        raise ValueError("exchange='rccl' needs one GPU per shard: gpus=%r "
+                         "on %d device(s)" % (gpus, len(set(devices))))
     host = torch.empty(num, dtype=torch.float64).pin_memory()
     # one replica of the forcing and of the observations per GPU (the copies
     # are made here, behind the upload); shards sharing a GPU share both and
@@ -212,9 +243,35 @@ def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs):
                                              n_total=num, first=first,
                                              device=dev)
                 sse = mine.run(params, None, qobs=obs[d])
-                host[first:stop].copy_(sse, non_blocking=True)
+                if exchange != "rccl":
+                    host[first:stop].copy_(sse, non_blocking=True)
         blocks.append(params)
         work.append((dev, mine, stream, sse))
+    gathered = None
+    if exchange == "rccl":
+        # every GPU gets all sums: the G collectives of the clique, issued by
+        # this one thread inside a group, each on its shard's stream behind
+        # the shard's sweep; the host's copy comes from the first GPU
+        lib = _lib.load()
+        comms = _clique(devices)
+        gathered = []
+        for dev, _, stream, _ in work:
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                gathered.append(torch.empty(num, dtype=torch.float64,
+                                            device=dev))
+        _lib.check(lib.rr_comm_group_start(), "rr_comm_group_start")
+        try:
+            for j, (dev, _, stream, sse) in enumerate(work):
+                with torch.cuda.device(dev):
+                    _lib.check(lib.rr_allgather_metric(
+                        comms[j], sse.data_ptr(), sse.numel(),
+                        gathered[j].data_ptr(), num, stream.cuda_stream),
+                        "rr_allgather_metric")
+        finally:
+            _lib.check(lib.rr_comm_group_end(), "rr_comm_group_end")
+        dev, _, stream, _ = work[0]
+        with torch.cuda.device(dev), torch.cuda.stream(stream):
+            host.copy_(gathered[0], non_blocking=True)
     for dev, mine, stream, sse in work:
         with torch.cuda.device(dev), torch.cuda.stream(stream):
             if hasattr(mine, "check"):
@@ -222,11 +279,14 @@ def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs):
             stream.synchronize()
     result = _resident_scores(host.numpy(), qobs, score)
     result['params'] = DeviceParams(model, blocks)
+    if gathered is not None:
+        result['sse_device'] = gathered
     return result
 
 
 def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
-                score="mse", sampler="numpy", seed=None, **kwargs):
+                score="mse", sampler="numpy", seed=None, exchange="host",
+                **kwargs):
     """Perform Monte-Carlo-Simulation.
 
     Args:
@@ -265,6 +325,11 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
             ``torch.distributed`` group), each rank sweeps its block and the
             scores are all-gathered (RCCL for an nccl group).
         seed: (optional) the key of sampler='device'.
+        exchange: (optional, sampler='device' only) 'host' (default): every
+            GPU sends its 8 B per set straight to the host; 'rccl': the
+            per-set sums are first all-gathered over RCCL / xGMI between the
+            GPUs of the call (in-process communicators), 'sse_device' in the
+            result holds them on every GPU.
         **kwargs: Keyword arguments matching the inputs the model needs to
             perform a simulation; see help(model.simulate).
 
@@ -297,8 +362,12 @@ def monte_carlo(model, num, qobs=None, return_qsim=True, gpus=None,
         if qobs is None or return_qsim:
             raise ValueError("sampler='device' scores resident sets: it "
                              "needs qobs and return_qsim=False")
+        if exchange not in ("host", "rccl"):
+            raise ValueError("exchange must be 'host' or 'rccl'")
         return _monte_carlo_resident(model, num, qobs, score, seed, gpus,
-                                     kwargs)
+                                     kwargs, exchange)
+    if exchange != "host":
+        raise ValueError("exchange='rccl' needs sampler='device'")
     params = model.get_random_params(num=num)
     sweep = model._sweep
     accepted = inspect.signature(sweep).parameters

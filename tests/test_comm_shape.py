@@ -27,6 +27,8 @@ DESTROY = ctypes.CFUNCTYPE(_int, _vp)
 BCAST = ctypes.CFUNCTYPE(_int, _vp, _vp, _sz, _int, _int, _vp, _vp)
 GATHER = ctypes.CFUNCTYPE(_int, _vp, _vp, _sz, _int, _vp, _vp)
 GROUP = ctypes.CFUNCTYPE(_int)
+INIT_ALL = ctypes.CFUNCTYPE(_int, ctypes.POINTER(_vp), _int,
+                            ctypes.POINTER(_int))
 
 
 class FakeRccl:
@@ -65,10 +67,18 @@ class FakeRccl:
                 return 0
             return fn
 
+        def init_all(out, ndev, devs):
+            self.calls.append(("init_all", ndev,
+                               [devs[j] for j in range(ndev)] if devs
+                               else None))
+            for j in range(ndev):
+                out[j] = 0x2000 + j
+            return 0
+
         self.keep = [GET_ID(get_id), INIT(init), DESTROY(destroy),
                      BCAST(bcast), GATHER(gather), GROUP(group("start")),
-                     GROUP(group("end"))]
-        self.table = (_vp * 7)(*[ctypes.cast(f, _vp) for f in self.keep])
+                     GROUP(group("end")), INIT_ALL(init_all)]
+        self.table = (_vp * 8)(*[ctypes.cast(f, _vp) for f in self.keep])
 
 
 @pytest.fixture()
@@ -176,3 +186,60 @@ def test_fewer_sets_than_ranks_and_errors(fake):
     assert lib.rr_comm_init(ctypes.byref(bad), 4, 4, ident) == -2
     assert lib.rr_comm_init(ctypes.byref(bad), 0, 0, ident) == -2
     lib.rr_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_in_process_clique_one_thread_for_all_gpus(fake, world, ragged):
+    """One process driving `world` GPUs (SURVEY.md 8e's sketch, what
+    monte_carlo(sampler='device', gpus=G, exchange='rccl') does):
+    rr_comm_init_all hands out the rank-j communicator of device devices[j],
+    and the one thread issues the G collectives inside ONE group -- an
+    all-gather per rank for equal blocks, a nested group of per-root
+    broadcasts per rank for ragged ones, each with its own buffers."""
+    lib, f = fake
+    n = 1_000_000 + (3 if ragged and world > 1 else 0)
+    if ragged and world == 1:
+        pytest.skip("one rank has no ragged blocks")
+    devs = (_int * world)(*[(3 + j) % 8 for j in range(world)])
+    comms = (_vp * world)()
+    assert lib.rr_comm_init_all(comms, world, devs) == 0, lib.rr_last_error()
+    assert f.calls == [("init_all", world, [(3 + j) % 8 for j in range(world)])]
+    assert [comms[j] for j in range(world)] != [None] * world
+    f.calls.clear()
+    assert lib.rr_comm_group_start() == 0
+    for j in range(world):
+        a, b = shard_bounds(n, world, j)
+        assert lib.rr_allgather_metric(comms[j], LOCAL + 0x100000 * j, b - a,
+                                       ALL + 0x1000000 * j, n,
+                                       STREAM + j) == 0, lib.rr_last_error()
+    assert lib.rr_comm_group_end() == 0
+    assert f.calls[0] == ("start",) and f.calls[-1] == ("end",)
+    body = f.calls[1:-1]
+    if n % world == 0:
+        assert body == [("gather", LOCAL + 0x100000 * j,
+                         ALL + 0x1000000 * j, n // world, 8, 0x2000 + j,
+                         STREAM + j) for j in range(world)]
+    else:
+        per_rank = world + 2              # nested start, W broadcasts, end
+        assert len(body) == world * per_rank
+        for j in range(world):
+            mine = body[j * per_rank:(j + 1) * per_rank]
+            assert mine[0] == ("start",) and mine[-1] == ("end",)
+            for root, call in enumerate(mine[1:-1]):
+                ra, rb = shard_bounds(n, world, root)
+                send = (LOCAL + 0x100000 * j if root == j
+                        else ALL + 0x1000000 * j + 8 * ra)
+                assert call == ("bcast", send, ALL + 0x1000000 * j + 8 * ra,
+                                rb - ra, 8, root, 0x2000 + j, STREAM + j)
+    f.calls.clear()
+    for j in range(world):
+        assert lib.rr_comm_destroy(comms[j]) == 0
+    assert [c[1] for c in f.calls] == [0x2000 + j for j in range(world)]
+    # the same device twice, no devices, bad counts
+    twice = (_int * 2)(1, 1)
+    two = (_vp * 2)()
+    assert lib.rr_comm_init_all(two, 2, twice) == -4
+    assert b"twice" in lib.rr_last_error()
+    assert lib.rr_comm_init_all(two, 0, None) == -2
+    assert lib.rr_comm_init_all(None, 2, None) == -1

@@ -360,6 +360,53 @@ def test_monte_carlo_device_sampler_inside_a_two_rank_group(tmp_path):
         assert p.returncode == 0 and "rank %d ok" % r in o, o[-2000:]
 
 
+def test_monte_carlo_exchange_rccl_in_process(tmp_path):
+    """monte_carlo(sampler='device', exchange='rccl'): the per-set sums
+    all-gathered between the GPUs of the call through in-process RCCL
+    communicators (rr_comm_init_all, one thread, one group) before the host
+    gets them -- with the one GPU of this box: a clique of one.  The scores
+    are the host exchange's, 'sse_device' holds all sums on the GPU, and two
+    shards on one device are refused (one rank per GPU)."""
+    script = tmp_path / "mc_rccl.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from rrmpg_amd import models\n"
+        "from rrmpg_amd.tools import monte_carlo\n"
+        "from rrmpg_amd.utils import synthetic as syn\n"
+        "f = syn.make_forcing(900)\n"
+        "kw = dict(prec=f['prec'], etp=f['etp'], s_init=0.6, r_init=0.7)\n"
+        "m = models.GR4J()\n"
+        "qobs = f['prec'] * 0.3 + 0.1\n"
+        "call = dict(qobs=qobs, return_qsim=False, sampler='device', seed=5,\n"
+        "            score='nse')\n"
+        "ref = monte_carlo(m, 100_003, **call, **kw)\n"
+        "for g in (None, 1, 'all'):\n"
+        "    got = monte_carlo(m, 100_003, gpus=g, exchange='rccl', **call, **kw)\n"
+        "    assert np.array_equal(got['mse'], ref['mse']), g\n"
+        "    assert np.array_equal(got['nse'], ref['nse']), g\n"
+        "    dev = got['sse_device']\n"
+        "    assert len(dev) == 1 and dev[0].is_cuda\n"
+        "    assert np.array_equal(dev[0].cpu().numpy() / len(qobs), ref['mse'])\n"
+        "if torch.cuda.device_count() == 1:\n"
+        "    try:\n"
+        "        monte_carlo(m, 1000, gpus=2, exchange='rccl', **call, **kw)\n"
+        "        raise SystemExit('two ranks on one GPU were accepted')\n"
+        "    except ValueError as e:\n"
+        "        assert 'one GPU per shard' in str(e)\n"
+        "try:\n"
+        "    monte_carlo(m, 10, qobs=qobs, exchange='rccl', **kw)\n"
+        "    raise SystemExit('exchange without the device sampler')\n"
+        "except ValueError:\n"
+        "    pass\n"
+        "print('mc rccl ok')\n" % REPO)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True,
+                         text=True, timeout=300,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "mc rccl ok" in out.stdout, \
+        (out.stdout + out.stderr)[-2000:]
+
+
 def test_c_abi_allgather_over_rccl_on_one_rank(tmp_path):
     """The collective of the C-ABI itself (include/rrhip.h rr_comm_* /
     rr_allgather_metric: RCCL opened at first use, one group of broadcasts,
