@@ -225,9 +225,9 @@ struct SnowParLayout {
 // 152.9 -- these kernels wait for their chains, a third wave hides more of
 // them than the spills cost; the 3-slot tier at four waves 144.6 ms, the
 // 10-slot tier at three 412.8)
-#ifndef SNOW_TIER5_WAVES
+// (round 6, under the iterative-ilp scheduling of snownext_hyst.hip: held to
+// three waves 129.6 ms, not held 132.8)
 #define SNOW_TIER5_WAVES 3
-#endif
 template <int L, class UH, bool HYST>
 constexpr int snow_min_waves()
 {
