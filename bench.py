@@ -1087,7 +1087,9 @@ def extra_configs(args, device):
                                                r["qobs"]))}
             traffic, valu = traffic_record(a, r["n"], r["t"])
             rec["traffic_from"] = "profiles/traffic.json" if traffic else None
-            if args.live_counters == "all" and ident.startswith("cfg"):
+            if (args.live_counters == "all" and ident.startswith("cfg")
+                    and r["bytes_per_step"] * r["n"] * r["t"] * 1.1 + (4 << 30)
+                    < torch.cuda.mem_get_info(device)[0]):
                 # BASELINE configs[1]-[4]: this box's own counter passes
                 try:
                     live = live_counters(a, r["n"], r["t"])
@@ -1324,7 +1326,11 @@ def main():
         traffic, valu = traffic_record(args, n, t)
         committed = {"traffic": traffic, "valu_instr_per_unit": valu}
         live = None
-        if world == 1 and args.live_counters != "none":
+        # (the child allocates the sweep's outputs a second time beside ours)
+        out_bytes = r["bytes_per_step"] * n * t
+        free_b = torch.cuda.mem_get_info(device)[0]
+        if (world == 1 and args.live_counters != "none"
+                and out_bytes * 1.1 + (4 << 30) < free_b):
             # this box's own counter passes (the GPU is ours: nothing else of
             # this script runs meanwhile; the sweep's buffers stay allocated,
             # the child's fit beside them)
