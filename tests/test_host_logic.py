@@ -665,3 +665,21 @@ def test_bench_line_fits_the_drivers_tail():
         e["parity_spot"] = 2.123456789012345e-13
     assert len(json.dumps(bench.compact_line(worst),
                           separators=(",", ":"))) <= bench.LINE_LIMIT
+
+
+def test_monte_carlo_rejects_bad_exchange_before_touching_a_gpu():
+    """`exchange` (how the shards' scores of a sampler='device' sweep reach
+    the host) is validated with the other arguments, in front of any GPU
+    work."""
+    from rrmpg_amd.models import ABCModel
+    from rrmpg_amd.tools import monte_carlo
+    qobs = np.ones(10)
+    prec = np.ones(10)
+    with pytest.raises(ValueError, match="exchange"):
+        monte_carlo(ABCModel(), 5, qobs=qobs, return_qsim=False,
+                    sampler="device", exchange="mpi", prec=prec)
+    with pytest.raises(ValueError, match="sampler='device'"):
+        monte_carlo(ABCModel(), 5, qobs=qobs, exchange="rccl", prec=prec)
+    with pytest.raises(ValueError, match="qobs"):
+        monte_carlo(ABCModel(), 5, sampler="device", return_qsim=False,
+                    prec=prec)
