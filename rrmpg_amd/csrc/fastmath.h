@@ -1,33 +1,26 @@
 // fastmath.h -- the transcendental pieces of the ensemble kernels in fp64:
-//   fastpow_core      x**y, ~1 ulp, ~71 VALU instructions (OCML pow: ~224)
-//   fast_tanh         tanh, <= ~2.5 ulp, ~40 instructions (OCML tanh: ~165)
-//   inv_fourth_root   b**(-1/4), b >= 1, ~1.5 ulp, ~16 instructions
-// x**y first:
+//   fastpow_soil      (soil / FC)**Beta from the soil alone, table-driven in
+//                     plain double, 25 vector instructions (OCML pow: ~224)
+//   fast_tanh parts   tanh as a numerator / denominator pair: a [9/8] Pade
+//                     approximant inside |a| <= 1, expm1-based beyond
+//   inv_fourth_root   b**(-1/4), b >= 1, ~1.5 ulp, ~16 instructions; a
+//                     degree-7 polynomial for b - 1 <= 0.0416
 //
-// Why: after the scalar forcing loads and coalesced stores, the HBV-Edu step
-// is fp64-VALU-issue bound and (soil/FC)**Beta (reference:
-// rrmpg/models/hbvedu_model.py:99) was two thirds of its instructions
-// (profiles/README.md, r01a).  The reference evaluates that power with the
-// platform libm (numba -> llvm.pow.f64), which is itself only faithful to
-// <1 ulp, so any implementation of comparable accuracy is an equally valid
-// realisation of the same statement; parity is asserted at 1e-10 relative on
-// the discharge (observed ~1e-14).
-//
-// Method (x > 0 finite, the fast path):
-//   x = 2^k * m, m in [sqrt(1/2), sqrt(2));  s = (m-1)/(m+1) as a
-//   double-double (s_hi + s_lo; the division residual is taken with FMA);
-//   ln m = 2 atanh(s) = 2 s + 2 s^3 (1/3 + s^2/5 + ... + s^20/23): leading
-//   term in double-double, tail (<= 1 % of it) in double;  log2 x = k +
-//   ln m * log2(e) in double-double;  z = y * log2 x in double-double;
-//   2^z = 2^n * 2^r, n = rint(z), |r| <= 1/2, 2^r by its degree-13 Taylor
-//   polynomial (truncation 4e-18).
-// Everything else (x <= 0, inf, NaN, |z| >= 1000 i.e. over/underflow range,
-// non-finite y) is not handled here: fastpow_ok() is false and the caller
-// falls back to the general pow for the wave, so IEEE special cases stay
-// exactly those of pow().
+// Why: after the scalar forcing loads and coalesced stores, the kernels are
+// fp64-VALU-issue bound, and the reference's libm calls (numba ->
+// llvm.pow.f64 / tanh) were most of their instructions.  The platform libm is
+// itself only faithful to <1 ulp, so an implementation of comparable accuracy
+// is an equally valid realisation of the same statement; parity is asserted
+// at 1e-10 relative on the discharge (observed ~1e-14 ... 3e-13).  Arguments
+// outside a form's domain are voted out by its caller and take the general
+// libm function, so IEEE special cases stay exactly the reference's.
+// (Three earlier generations of the power -- double-double series, table-driven
+// double-double, table-driven plain double behind the quotient soil / FC: 71,
+// 50 and 34 instructions -- were removed in round 6 with their tables; their
+// error analyses and A/B numbers: profiles/README.md rounds 1-4.)
 //
 // The same source compiles for the host (tests/test_fastmath_cpu.py builds a
-// small harness with g++ and checks it against 80-bit powl): only the five
+// small harness with g++ and checks it against 80-bit powl): only the
 // primitives below differ.
 #pragma once
 
@@ -128,301 +121,6 @@ static inline double fp_from_hilo_(int hi, int lo) {
 #define FP_FROM_HILO(hi, lo) fp_from_hilo_((hi), (lo))
 #endif
 
-#include "pow_tables.h"
-#include "exp2_table.h"
-
-// Core: valid for finite x > 0.  Returns x**y if |y*log2 x| < 1000; *z_out
-// receives y*log2(x) (rounded) for the caller's range guard.
-FP_FN double fastpow_core(double x, double y, double *z_out)
-{
-    double m = FP_FREXP_MANT(x);               // [0.5, 1)
-    int e = FP_FREXP_EXP(x);
-    const bool low = m < 0.70710678118654757;
-    m = low ? m * 2.0 : m;                      // [sqrt(.5), sqrt(2))
-    e = low ? e - 1 : e;
-    const double k = (double)e;
-
-    // s = (m - 1) / (m + 1) as s_hi + s_lo
-    const double f = m - 1.0;                   // exact
-    const double g = m + 1.0;                   // may round ...
-    const double g_lo = m - (g - 1.0);          // ... by exactly this much
-    // 1/g to ~2^-50: hardware estimate (~2^-26) + one Newton step.  That is
-    // all the double-double quotient needs: the FMA residual below removes
-    // s_hi's error exactly and s_lo only has to be good to ~2^-50 itself.
-    double rg = FP_RCP(g);
-    rg = FP_FMA(FP_FMA(-g, rg, 1.0), rg, rg);
-    const double s_hi = f * rg;
-    double res = FP_FMA(-s_hi, g, f);           // f - s_hi*(g + g_lo)
-    res = FP_FMA(-s_hi, g_lo, res);
-    const double s_lo = res * rg;
-
-    // atanh(s) = s + s^3 (1/3 + s^2/5 + ... + s^18/21); s^2 <= 0.02944
-    const double s2 = s_hi * s_hi;
-    double p = 1.0 / 21.0;
-    p = FP_FMA_C(p, s2, 1.0 / 19.0);
-    p = FP_FMA_C(p, s2, 1.0 / 17.0);
-    p = FP_FMA_C(p, s2, 1.0 / 15.0);
-    p = FP_FMA_C(p, s2, 1.0 / 13.0);
-    p = FP_FMA_C(p, s2, 1.0 / 11.0);
-    p = FP_FMA_C(p, s2, 1.0 / 9.0);
-    p = FP_FMA_C(p, s2, 1.0 / 7.0);
-    p = FP_FMA_C(p, s2, 1.0 / 5.0);
-    p = FP_FMA_C(p, s2, 1.0 / 3.0);
-    // low part: s_lo * (1 + s^2) (first-order effect of s_lo) + tail
-    const double lo = FP_FMA(s_hi * s2, p, FP_FMA(s_lo, s2, s_lo));
-
-    // log2(m) = 2 (s_hi + lo) * log2(e), double-double
-    const double a_hi = 2.0 * s_hi, a_lo = 2.0 * lo;
-    const double L_hi = 1.4426950408889634, L_lo = 2.0355273740931033e-17;
-    const double p_hi = a_hi * L_hi;
-    const double p_lo =
-        FP_FMA(a_hi, L_hi, -p_hi) + FP_FMA(a_lo, L_hi, a_hi * L_lo);
-    // + k  (|k| >= 1 > |p_hi| or k == 0: fast two-sum is exact)
-    const double t_hi = k + p_hi;
-    const double t_lo = ((k - t_hi) + p_hi) + p_lo;
-    // * y
-    const double z_hi = y * t_hi;
-    const double z_lo = FP_FMA(y, t_hi, -z_hi) + y * t_lo;
-    *z_out = z_hi;
-
-    // 2^(z_hi + z_lo)
-    const double n = FP_RINT(z_hi);
-    const double r = (z_hi - n) + z_lo;         // |r| <= 0.5 (+ tiny)
-    double q = 1.3691488853904128e-12;          // ln2^13 / 13!
-    q = FP_FMA_C(q, r, 2.5678435993488206e-11);
-    q = FP_FMA_C(q, r, 4.4455382718708116e-10);
-    q = FP_FMA_C(q, r, 7.054911620801123e-09);
-    q = FP_FMA_C(q, r, 1.01780860092397e-07);
-    q = FP_FMA_C(q, r, 1.321548679014431e-06);
-    q = FP_FMA_C(q, r, 1.5252733804059841e-05);
-    q = FP_FMA_C(q, r, 0.0001540353039338161);
-    q = FP_FMA_C(q, r, 0.0013333558146428443);
-    q = FP_FMA_C(q, r, 0.009618129107628477);
-    q = FP_FMA_C(q, r, 0.05550410866482158);
-    q = FP_FMA_C(q, r, 0.24022650695910072);
-    q = FP_FMA_C(q, r, 0.6931471805599453);
-    q = FP_FMA_C(q, r, 1.0);
-    return FP_LDEXP(q, (int)n);
-}
-
-// True where fastpow_core's result may be used.
-FP_FN bool fastpow_ok(double x, double z)
-{
-    // x > 0 and finite (NaN fails both compares); |z| < 1000 keeps 2^z normal
-    // and rejects NaN / inf coming from a non-finite y
-    return (x > 0.0) && (x < __builtin_inf()) && (__builtin_fabs(z) < 1000.0);
-}
-
-// ---------------------------------------------------------------------------
-// Table-driven variant of fastpow_core: the same x**y for finite x > 0, with
-// the logarithm taken from a 128-entry table (pow_tables.h, generated by
-// tools/gen_pow_tables.py) instead of the division + degree-9 series above --
-// 11 instructions fewer, and slightly more accurate.  The scheme is the
-// classic one (Tang 1990; the form used by today's libms):
-//   bits(x) - bits(OFF), OFF = 0.6875, gives k and the subinterval i of
-//   z = x / 2^k in [OFF, 2 OFF);  with {invc, logc, logctail} = table[i],
-//   r = fma(z, invc, -1)  (|r| <= 2^-7, exact to one bit at 2^-62) and
-//   ln x = k ln2 + logc + logctail + r - r^2/2 + r^3 (1/3 - r/4 + ... - r^5/8),
-//   accumulated as hi + lo: k LN2HI + logc and the products feeding hi are
-//   exact by construction, the rest goes to lo (|lo| <~ 2^-14 |hi| ... ).
-// The exponent y is handed over already divided by ln 2, as a double-double
-// (y2hi + y2lo = y / ln 2, computed once per lane outside the time loop), so
-// z = y log2 x needs four FMAs and the exp2 stage of fastpow_core is reused.
-// `tab` points at FP_POWLOG_N entries of 4 doubles (LDS on the device).
-struct FpPowLogEntry { double invc, logc, logctail, lnc; };
-
-FP_FN void fastpow_tab_exponent(double y, double *y2hi, double *y2lo)
-{
-    const double h = y * FP_INVLN2HI;
-    *y2hi = h;
-    *y2lo = FP_FMA(y, FP_INVLN2HI, -h) + y * FP_INVLN2LO;
-}
-
-// VCONST: polynomial coefficients in VGPRs instead of SGPRs (see FP_FMA_CV)
-#define FP_FMA_K(a, b, c) \
-    (VCONST ? FP_FMA_CV((a), (b), (c)) : FP_FMA_C((a), (b), (c)))
-template <bool VCONST = false>
-FP_FN double fastpow_tab_core(double x, double y2hi, double y2lo,
-                              const FpPowLogEntry *tab, double *z_out)
-{
-    // k, i, z from the bit pattern (only the high word matters: OFF's low
-    // word is zero)
-    const int hi = FP_HI32(x);
-    const int tmp = hi - FP_POWLOG_OFF_HI;
-    const int i = (tmp >> 13) & (FP_POWLOG_N - 1);
-    const int k = tmp >> 20;                          // arithmetic shift
-    const double z = FP_FROM_HILO(hi - (tmp & (int)0xFFF00000), FP_LO32(x));
-    const double kd = (double)k;
-    const FpPowLogEntry e = tab[i];
-
-    const double r = FP_FMA(z, e.invc, -1.0);
-    // k ln2 + ln c + r, hi part exact up to the last addition
-    const double t1 = FP_FMA(kd, FP_LN2HI, e.logc);   // exact
-    const double t2 = t1 + r;
-    const double lo1 = FP_FMA(kd, FP_LN2LO, e.logctail);
-    const double lo2 = (t1 - t2) + r;
-    // - r^2/2 with its rounding error
-    const double ar = -0.5 * r;
-    const double ar2 = r * ar;
-    const double l_hi0 = t2 + ar2;
-    const double lo3 = FP_FMA(ar, r, -ar2);
-    const double lo4 = (t2 - l_hi0) + ar2;
-    // r^3 (1/3 - r/4 + r^2/5 - r^3/6 + r^4/7 - r^5/8) = (ar2 r) h(r),
-    // h = -2 (1/3 - r/4 + ...); truncation r^9/9 <= 2^-66
-    double h = 0.25;                                  // -2 * -1/8
-    h = FP_FMA_K(h, r, -2.0 / 7.0);
-    h = FP_FMA_K(h, r, 1.0 / 3.0);                    // -2 * -1/6
-    h = FP_FMA_K(h, r, -0.4);
-    h = FP_FMA(h, r, 0.5);                            // inline constant
-    h = FP_FMA_K(h, r, -2.0 / 3.0);
-    const double p = (ar2 * r) * h;
-    const double lo = (((lo1 + lo2) + lo3) + lo4) + p;
-    // ln x = l_hi0 + lo, |lo| < 2^-13 |l_hi0| (not renormalised: the product
-    // below only needs the pair's sum)
-
-    // z = (y2hi + y2lo) (l_hi0 + lo) = y log2 x
-    const double z_hi = y2hi * l_hi0;
-    double z_lo = FP_FMA(y2hi, l_hi0, -z_hi);
-    z_lo = FP_FMA(y2hi, lo, z_lo);
-    z_lo = FP_FMA(y2lo, l_hi0, z_lo);
-    *z_out = z_hi;
-
-    // 2^(z_hi + z_lo), as in fastpow_core
-    const double n = FP_RINT(z_hi);
-    const double q0 = (z_hi - n) + z_lo;              // |.| <= 0.5 (+ tiny)
-    // 2^q0 = 1 + q0 Q(q0), Q of degree 10 through the Chebyshev nodes of
-    // [-1/2, 1/2] (csrc/tools/gen_exp_poly.py; 0.18 x 2^-53, the same as the
-    // degree-12 Taylor polynomial this replaces: both are at the rounding of
-    // their coefficients)
-    double q = 4.4549605981865186e-10;
-    q = FP_FMA_K(q, q0, 7.072585949269223e-09);
-    q = FP_FMA_K(q, q0, 1.0178062445845774e-07);
-    q = FP_FMA_K(q, q0, 1.321544258792169e-06);
-    q = FP_FMA_K(q, q0, 1.525273382983612e-05);
-    q = FP_FMA_K(q, q0, 0.0001540353044173605);
-    q = FP_FMA_K(q, q0, 0.0013333558146416936);
-    q = FP_FMA_K(q, q0, 0.009618129107606888);
-    q = FP_FMA_K(q, q0, 0.0555041086648216);
-    q = FP_FMA_K(q, q0, 0.24022650695910097);
-    q = FP_FMA_K(q, q0, 0.6931471805599453);
-    q = FP_FMA(q, q0, 1.0);                           // inline constant
-    return FP_LDEXP(q, (int)n);
-}
-
-// The same power in PLAIN double arithmetic -- no double-double anywhere: ln x
-// = k ln2 + ln c + r - r^2/2 + ... + r^7/7 (truncation r^8/8 <= 2^-59), one
-// rounded product with y / ln 2, then the exp2 stage above.  16 instructions
-// fewer (34 instead of 50).  The price: the absolute error of ln x (a few
-// 2^-53 |ln x|) is multiplied by y, so the relative error of the result is
-// at most (4 + 3 |z| + |y| / 4) 2^-53 with z = y log2 x -- a few ulp for the
-// HBV-Edu box of a sane run (Beta 1..6, soil/FC 0.3..1), 70 ulp at its
-// corners, at most 2e-13 at the far corners of the guard box (|z| = 576) --
-// against the 1e-10 the discharge has to meet.  Measured: tests/native/fastmath_harness.cpp ("lite_*");
-// HBV-Edu's deviation from the reference semantics over 30 years: DESIGN.md section 4.
-// Same domain and guard as fastpow_tab_core (fastpow_tab_ok).
-#define FP_LN2 0x1.62e42fefa39efp-1
-// The evaluation in two halves, so that a caller can put work of its own
-// between the table read (an LDS access on the device) and the first use of
-// the entry: fastpow_tab_lookup splits x and fetches the subinterval's entry,
-// fastpow_tab_lite_finish does the arithmetic.
-struct FpPowLookup {
-    double z, kd, invc, lnc;
-};
-FP_FN FpPowLookup fastpow_tab_lookup(double x, const FpPowLogEntry *tab)
-{
-    const int hi = FP_HI32(x);
-    const int tmp = hi - FP_POWLOG_OFF_HI;
-    const int i = (tmp >> 13) & (FP_POWLOG_N - 1);
-    const int k = tmp >> 20;                          // arithmetic shift
-    FpPowLookup e;
-    e.z = FP_FROM_HILO(hi - (tmp & (int)0xFFF00000), FP_LO32(x));
-    e.kd = (double)k;
-    e.invc = tab[i].invc;
-    e.lnc = tab[i].lnc;
-    return e;
-}
-// EXPTAB (`exptab`: FP_EXP2_N doubles, exp2_table.h, LDS on the device): the
-// exponential 2^zz table-driven as well -- zz = k/64 + r, |r| <= 1/128,
-// 2^zz = 2^(k >> 6) * T[k & 63] * (1 + r q(r)) with q of degree 4 (0.02 ulp
-// of truncation): six arithmetic instructions where the polynomial on
-// |q0| <= 1/2 takes twelve, for one more table read and two integer
-// instructions.  The kernels of the large sweeps use it (energy per set-day is
-// their currency); a sweep of one or two waves per SIMD
-// would sit out the second table read's latency and keeps the polynomial.
-// About one ulp more than the polynomial form (the table entry's rounding and
-// the last multiply-add's): inside the stated bound, measured by
-// tests/native/fastmath_harness.cpp ("lite_tab_*").
-template <bool VCONST = false, bool EXPTAB = false>
-FP_FN double fastpow_tab_lite_finish(const FpPowLookup &e, double y2,
-                                     double *z_out,
-                                     const double *exptab = nullptr)
-{
-    const double r = FP_FMA(e.z, e.invc, -1.0);
-    const double t = FP_FMA(e.kd, FP_LN2, e.lnc);
-    // ln(1 + r) = r + r^2 (-1/2 + r/3 - r^2/4 + r^3/5 - r^4/6 + r^5/7)
-    double h = 1.0 / 7.0;
-    h = FP_FMA_K(h, r, -1.0 / 6.0);
-    h = FP_FMA_K(h, r, 0.2);
-    h = FP_FMA_K(h, r, -0.25);
-    h = FP_FMA_K(h, r, 1.0 / 3.0);
-    h = FP_FMA(h, r, -0.5);                           // inline constant
-    const double l = t + FP_FMA(r * r, h, r);
-    const double zz = y2 * l;
-    *z_out = zz;
-
-    if (EXPTAB) {
-        // The reduced argument is carried as d = N r = N zz - k (a plain
-        // difference of the two values the rounding needs anyway; exact) and
-        // the coefficients as c_j / N^(j+1): every Horner value is the one of
-        // the polynomial in r times a power of two, d q'(d) IS r q(r), the
-        // result has the same bits -- and the subtraction has no constant
-        // operand.  (As r = fma(k, -1/N, zz) hipcc spends a v_mov_b64 per
-        // evaluation to give the VOP2 v_fmac_f64, the only encoding that
-        // takes the literal, its accumulator.)
-        constexpr double I = 1.0 / FP_EXP2_N;            // a power of two
-        const double sN = zz * (double)FP_EXP2_N;
-        const double kd = FP_RINT(sN);
-        const double d = sN - kd;                        // exact
-        const int k = (int)kd;
-        const double tj = exptab[k & (FP_EXP2_N - 1)];
-        double q = FP_EXP2_C4 * (I * I * I * I * I);
-        q = FP_FMA_K(q, d, FP_EXP2_C3 * (I * I * I * I));
-        q = FP_FMA_K(q, d, FP_EXP2_C2 * (I * I * I));
-        q = FP_FMA_K(q, d, FP_EXP2_C1 * (I * I));
-        q = FP_FMA_K(q, d, FP_EXP2_C0 * I);
-        return FP_LDEXP(FP_FMA(tj, d * q, tj), k >> 6);      // arithmetic shift
-    }
-    const double n = FP_RINT(zz);
-    const double q0 = zz - n;                         // |.| <= 0.5
-    double q = 4.4549605981865186e-10;
-    q = FP_FMA_K(q, q0, 7.072585949269223e-09);
-    q = FP_FMA_K(q, q0, 1.0178062445845774e-07);
-    q = FP_FMA_K(q, q0, 1.321544258792169e-06);
-    q = FP_FMA_K(q, q0, 1.525273382983612e-05);
-    q = FP_FMA_K(q, q0, 0.0001540353044173605);
-    q = FP_FMA_K(q, q0, 0.0013333558146416936);
-    q = FP_FMA_K(q, q0, 0.009618129107606888);
-    q = FP_FMA_K(q, q0, 0.0555041086648216);
-    q = FP_FMA_K(q, q0, 0.24022650695910097);
-    q = FP_FMA_K(q, q0, 0.6931471805599453);
-    q = FP_FMA(q, q0, 1.0);                           // inline constant
-    return FP_LDEXP(q, (int)n);
-}
-template <bool VCONST = false, bool EXPTAB = false>
-FP_FN double fastpow_tab_lite_x(double x, double y2, const FpPowLogEntry *tab,
-                                const double *exptab, double *z_out)
-{
-    return fastpow_tab_lite_finish<VCONST, EXPTAB>(fastpow_tab_lookup(x, tab),
-                                                   y2, z_out, exptab);
-}
-template <bool VCONST = false>
-FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,
-                              double *z_out)
-{
-    return fastpow_tab_lite_finish<VCONST>(fastpow_tab_lookup(x, tab), y2,
-                                           z_out);
-}
-
 // ---------------------------------------------------------------------------
 // (soil / FC) ** Beta for HBV-Edu's effective precipitation
 // (hbvedu_model.py:99), round 5: the power of a QUOTIENT BY A LOOP INVARIANT,
@@ -433,7 +131,7 @@ FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,
 // -- so the quotient is never formed (one multiply and one link of the
 // dependent chain less), with both halves table-driven in plain double:
 //   * ln soil: soil = 2^e m, m in [1/2, 1) (v_frexp_exp / v_frexp_mant -- two
-//     instructions where the bit-pattern split of fastpow_tab_lookup takes
+//     instructions where the bit-pattern split of round 4's table lookup took
 //     five), the top 9 mantissa bits select {invc, lnc} (pow2_tables.h, 512
 //     entries of 16 bytes: one ds_read_b128), r = fma(m, invc, -1), |r| <=
 //     2^-10, ln(1 + r) = r + r^2 (A0 + A1 r + A2 r^2) (4.5e-17 absolute: two
@@ -443,7 +141,7 @@ FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,
 //     to nearest even of the hardware), kd = t - 1.5 2^52, d = sN - kd exact
 //     -- instead of v_ldexp + v_rndne + v_cvt; q of degree 3 on |d| / N <=
 //     1/512 (fit error 5e-18).
-// 28 vector instructions where fastpow_tab_lite_x behind the quotient took
+// 28 vector instructions where round 4's power behind the quotient took
 // 34.  What the subtraction ln soil - ln FC costs: the rounding of ln soil (a
 // few 2^-53 |ln soil|) is no longer relative to |ln(soil / FC)|, so the
 // relative error of the result is at most
@@ -455,6 +153,10 @@ FP_FN double fastpow_tab_lite(double x, double y2, const FpPowLogEntry *tab,
 // (fastpow_soil_ok); y2N and cF finite.
 #include "pow2_tables.h"
 struct FpSoilEntry { double invc, lnc; };
+#define FP_INVLN2HI 0x1.71547652b82fep+0          /* RN(1 / ln 2) */
+// VCONST: polynomial coefficients in VGPRs instead of SGPRs (see FP_FMA_CV)
+#define FP_FMA_K(a, b, c) \
+    (VCONST ? FP_FMA_CV((a), (b), (c)) : FP_FMA_C((a), (b), (c)))
 #define FP_SOIL_MAGIC 0x1.8p52
 static_assert(FP_SOIL_LOG_A0 == -0.5, "the inline constant below");
 #if !defined(__HIPCC__)
@@ -530,14 +232,6 @@ FP_FN bool fastpow_soil_ok(double x, double sN)
 {
     return (x >= 0x1p-1022) && (x < __builtin_inf()) &&
            (__builtin_fabs(sN) < 1000.0 * FP_SOIL_EXP_N);
-}
-
-// Where fastpow_tab_core's result may be used: x a positive NORMAL number
-// (the bit-pattern split does not handle subnormals), |z| < 1000.
-FP_FN bool fastpow_tab_ok(double x, double z)
-{
-    return (x >= 0x1p-1022) && (x < __builtin_inf()) &&
-           (__builtin_fabs(z) < 1000.0);
 }
 
 // ---------------------------------------------------------------------------

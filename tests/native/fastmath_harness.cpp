@@ -1,6 +1,6 @@
 // CPU accuracy harness for rrmpg_amd/csrc/fastmath.h (built and run by
-// tests/test_fastpow_cpu.py): compares fastpow_core with 80-bit powl on random
-// arguments and prints the worst error in ulp of the double result.
+// tests/test_fastmath_cpu.py): compares every fast form with 80-bit long-double
+// libm on random arguments and prints the worst errors.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -23,143 +23,6 @@ static double ulp_err(double got, long double want) {
 
 int main(int argc, char **argv) {
     long n = argc > 1 ? atol(argv[1]) : 2000000;
-    // set 1: the HBV-Edu box  x = soil/FC in (0.02, 2.5), y = Beta in (0.5, 8)
-    // set 2: wide             x = 2^U(-60,60), y = U(-12, 12)
-    // set 3: near 1           x = 1 + U(-1e-3,1e-3), y = U(-300, 300)
-    double worst[3] = {0, 0, 0};
-    double wx[3] = {0, 0, 0}, wy[3] = {0, 0, 0};
-    long bad_guard = 0;
-    for (int set = 0; set < 3; ++set)
-        for (long i = 0; i < n; ++i) {
-            double x, y;
-            if (set == 0) { x = 0.02 + 2.48 * u01(); y = 0.5 + 7.5 * u01(); }
-            else if (set == 1) { x = exp2(-60 + 120 * u01()); y = -12 + 24 * u01(); }
-            else { x = 1 + 2e-3 * (u01() - 0.5); y = -300 + 600 * u01(); }
-            double z;
-            double got = fastpow_core(x, y, &z);
-            if (!fastpow_ok(x, z)) { bad_guard++; continue; }
-            double err = ulp_err(got, powl((long double)x, (long double)y));
-            if (err > worst[set]) { worst[set] = err; wx[set] = x; wy[set] = y; }
-        }
-    // exact cases
-    double z;
-    int exact_ok = fastpow_core(1.0, 3.7, &z) == 1.0 &&
-                   fastpow_core(2.5, 0.0, &z) == 1.0 &&
-                   fastpow_core(2.0, 3.0, &z) == 8.0 &&
-                   fastpow_core(0.25, 0.5, &z) == 0.5 &&
-                   fastpow_core(4.0, -1.0, &z) == 0.25;
-    printf("worst_ulp_hbv %.4f at x=%.17g y=%.17g\n", worst[0], wx[0], wy[0]);
-    printf("worst_ulp_wide %.4f at x=%.17g y=%.17g\n", worst[1], wx[1], wy[1]);
-    printf("worst_ulp_near1 %.4f at x=%.17g y=%.17g\n", worst[2], wx[2], wy[2]);
-    printf("guard_rejected %ld\nexact_ok %d\n", bad_guard, exact_ok);
-    // libm's own pow for scale
-    double wl = 0; s = 88172645463325252ULL;
-    for (long i = 0; i < n; ++i) {
-        double x = 0.02 + 2.48 * u01(), y = 0.5 + 7.5 * u01();
-        double err = ulp_err(pow(x, y), powl((long double)x, (long double)y));
-        if (err > wl) wl = err;
-    }
-    printf("libm_pow_worst_ulp_hbv %.4f\n", wl);
-
-    // table-driven variant (fastpow_tab_core), same three argument sets
-    {
-        static const FpPowLogEntry tab[FP_POWLOG_N] = FP_POWLOG_TABLE_INIT;
-        double tw[3] = {0, 0, 0}, tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
-        long rej = 0;
-        s = 88172645463325252ULL;
-        for (int set = 0; set < 3; ++set)
-            for (long i = 0; i < n; ++i) {
-                double x, y;
-                if (set == 0) { x = 0.02 + 2.48 * u01(); y = 0.5 + 7.5 * u01(); }
-                else if (set == 1) { x = exp2(-60 + 120 * u01()); y = -12 + 24 * u01(); }
-                else { x = 1 + 2e-3 * (u01() - 0.5); y = -300 + 600 * u01(); }
-                double y2h, y2l, zz;
-                fastpow_tab_exponent(y, &y2h, &y2l);
-                double got = fastpow_tab_core(x, y2h, y2l, tab, &zz);
-                if (!fastpow_tab_ok(x, zz)) { rej++; continue; }
-                double err = ulp_err(got, powl((long double)x, (long double)y));
-                if (err > tw[set]) { tw[set] = err; tx[set] = x; ty[set] = y; }
-            }
-        double y2h, y2l, zz;
-        auto P = [&](double x, double y) {
-            fastpow_tab_exponent(y, &y2h, &y2l);
-            return fastpow_tab_core(x, y2h, y2l, tab, &zz);
-        };
-        int ex = P(1.0, 3.7) == 1.0 && P(2.5, 0.0) == 1.0 && P(2.0, 3.0) == 8.0 &&
-                 P(0.25, 0.5) == 0.5 && P(4.0, -1.0) == 0.25 &&
-                 !fastpow_tab_ok(4e-320, 0.0) && !fastpow_tab_ok(-1.0, 0.0) &&
-                 !fastpow_tab_ok(INFINITY, 0.0) && !fastpow_tab_ok(NAN, 0.0) &&
-                 !fastpow_tab_ok(0.0, 0.0) && fastpow_tab_ok(0x1p-1022, 3.0);
-        printf("tab_worst_ulp_hbv %.4f at x=%.17g y=%.17g\n", tw[0], tx[0], ty[0]);
-        printf("tab_worst_ulp_wide %.4f at x=%.17g y=%.17g\n", tw[1], tx[1], ty[1]);
-        printf("tab_worst_ulp_near1 %.4f at x=%.17g y=%.17g\n", tw[2], tx[2], ty[2]);
-        printf("tab_guard_rejected %ld\ntab_exact_ok %d\n", rej, ex);
-
-        // the plain-double variant (fastpow_tab_lite, HBV-Edu's default):
-        // relative error in units of 2^-53, (a) the box of a sane run,
-        // (b) the whole guard box x = 2^U(-9, 9), y = U(-64, 64), where the
-        // bound is (4 + 3 |z| + |y| / 4) 2^-53
-        double lw[2] = {0, 0}, lbound = 0;
-        s = 88172645463325252ULL;
-        for (int set = 0; set < 2; ++set)
-            for (long i = 0; i < n; ++i) {
-                double x, y;
-                if (set == 0) { x = 0.05 + 1.45 * u01(); y = 0.5 + 7.5 * u01(); }
-                else { x = exp2(-9 + 18 * u01()); y = -64 + 128 * u01(); }
-                double y2h, y2l, zl;
-                fastpow_tab_exponent(y, &y2h, &y2l);
-                const double got = fastpow_tab_lite(x, y2h, tab, &zl);
-                if (!fastpow_tab_ok(x, zl)) continue;
-                const long double want = powl((long double)x, (long double)y);
-                const double rel = (double)(fabsl((long double)got - want) /
-                                            want) * 0x1p53;
-                if (rel > lw[set]) lw[set] = rel;
-                const double over = rel / (4 + 3 * fabs(zl) + 0.25 * fabs(y));
-                if (over > lbound) lbound = over;
-            }
-        // ... and with the table-driven exp2 (fastpow_tab_lite_x<.., true>,
-        // the large sweeps' form): the same bound
-        static const double exptab[FP_EXP2_N] = FP_EXP2_TABLE_INIT;
-        double tw2[2] = {0, 0}, tbound = 0, tdiff = 0;
-        s = 88172645463325252ULL;
-        for (int set = 0; set < 2; ++set)
-            for (long i = 0; i < n; ++i) {
-                double x, y;
-                if (set == 0) { x = 0.05 + 1.45 * u01(); y = 0.5 + 7.5 * u01(); }
-                else { x = exp2(-9 + 18 * u01()); y = -64 + 128 * u01(); }
-                double y2h, y2l, zl2, zl3;
-                fastpow_tab_exponent(y, &y2h, &y2l);
-                const double got =
-                    fastpow_tab_lite_x<false, true>(x, y2h, tab, exptab, &zl2);
-                if (!fastpow_tab_ok(x, zl2)) continue;
-                const long double want = powl((long double)x, (long double)y);
-                const double rel = (double)(fabsl((long double)got - want) /
-                                            want) * 0x1p53;
-                if (rel > tw2[set]) tw2[set] = rel;
-                const double over = rel / (4 + 3 * fabs(zl2) + 0.25 * fabs(y));
-                if (over > tbound) tbound = over;
-                // against the polynomial form: the exponential's own share
-                const double poly = fastpow_tab_lite(x, y2h, tab, &zl3);
-                const double d = fabs(got - poly) / poly * 0x1p53;
-                if (d > tdiff) tdiff = d;
-            }
-        double zt;
-        int tex = fastpow_tab_lite_x<false, true>(1.0, 3.7 * FP_INVLN2HI, tab,
-                                                  exptab, &zt) == 1.0 &&
-                  fastpow_tab_lite_x<false, true>(2.5, 0.0, tab, exptab,
-                                                  &zt) == 1.0;
-        printf("lite_tab_worst_rel53_sane %.2f\nlite_tab_worst_rel53_box %.2f\n"
-               "lite_tab_worst_over_bound_x100 %.0f\nlite_tab_exact_ok %d\n"
-               "lite_tab_vs_poly_rel53 %.2f\n",
-               tw2[0], tw2[1], tbound * 100, tex, tdiff);
-        double zl;
-        int lex = fastpow_tab_lite(1.0, 3.7 * FP_INVLN2HI, tab, &zl) == 1.0 &&
-                  fastpow_tab_lite(2.5, 0.0, tab, &zl) == 1.0;
-        printf("lite_worst_rel53_sane %.2f\nlite_worst_rel53_box %.2f\n"
-               "lite_worst_over_bound_x100 %.0f\nlite_exact_ok %d\n",
-               lw[0], lw[1], lbound * 100, lex);
-    }
-
     // fastpow_soil (HBV-Edu's default since round 5): (soil / FC) ** Beta
     // from the soil alone, against powl of the EXACT quotient, relative
     // error in units of 2^-53 -- (a) a sane run's box: FC 50..1000 mm, soil

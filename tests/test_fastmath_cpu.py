@@ -3,7 +3,7 @@ uses instead of OCML's general pow / hipcc's division expansion.  Both headers
 are portable; small g++ harnesses (tests/native/) exercise the very source the
 kernels compile.
 
-  * fastmath.h : worst error vs 80-bit powl stays ~1 ulp (libm's pow: 0.5 ulp)
+  * fastmath.h : every fast form's worst error vs 80-bit libm inside its stated bound
   * invdiv.h  : bit-identical to `a / b` on 2e7 random + adversarial pairs
 """
 
@@ -27,30 +27,6 @@ def _build_and_run(src, tmp_path, *args):
 def test_fastpow_accuracy(tmp_path):
     out = _build_and_run("fastmath_harness.cpp", tmp_path, "400000")
     vals = dict(re.findall(r"^(\w+) ([0-9.]+)", out, flags=re.M))
-    assert float(vals["worst_ulp_hbv"]) < 1.25, out
-    assert float(vals["worst_ulp_wide"]) < 1.25, out
-    assert float(vals["worst_ulp_near1"]) < 1.25, out
-    assert int(vals["exact_ok"]) == 1, out
-    assert int(vals["guard_rejected"]) == 0, out
-    # table-driven variant used by the HBV-Edu kernel
-    assert float(vals["tab_worst_ulp_hbv"]) < 1.1, out
-    assert float(vals["tab_worst_ulp_wide"]) < 1.1, out
-    assert float(vals["tab_worst_ulp_near1"]) < 1.1, out
-    assert int(vals["tab_exact_ok"]) == 1, out
-    assert int(vals["tab_guard_rejected"]) == 0, out
-    # the plain-double variant HBV-Edu runs by default: relative error in
-    # units of 2^-53 -- a sane run's box, the whole guard box, and the
-    # stated bound (4 + 3 |y log2 x| + |y| / 4) 2^-53
-    assert float(vals["lite_worst_rel53_sane"]) < 100, out
-    assert float(vals["lite_worst_rel53_box"]) < 4 + 3 * 576, out
-    assert int(vals["lite_worst_over_bound_x100"]) <= 100, out
-    assert int(vals["lite_exact_ok"]) == 1, out
-    # the same power with the table-driven exp2 (the large sweeps' form)
-    assert float(vals["lite_tab_worst_rel53_sane"]) < 100, out
-    assert float(vals["lite_tab_worst_rel53_box"]) < 4 + 3 * 576, out
-    assert int(vals["lite_tab_worst_over_bound_x100"]) <= 100, out
-    assert int(vals["lite_tab_exact_ok"]) == 1, out
-    assert float(vals["lite_tab_vs_poly_rel53"]) < 4, out
     # HBV-Edu's default since round 5: the power from the soil alone
     # (fastpow_soil) against powl of the exact quotient -- a sane run's box,
     # the whole guard box (FC 1e-3..1e6, soil within 2^9 of it, |Beta| <= 64)
@@ -93,38 +69,6 @@ def test_invariant_division_is_bit_exact(tmp_path):
     assert int(vals["faithful_checked"]) > 9_000_000, out
     assert int(vals["faithful_worst_ulps_x100"]) <= 150, out
     assert int(vals["faithful_special_bad"]) == 0, out
-
-
-def test_pow_tables_header_matches_its_generator(tmp_path):
-    """rrmpg_amd/csrc/pow_tables.h is generated (mpmath, 60 digits) by
-    csrc/tools/gen_pow_tables.py; the committed header must be what the
-    generator writes, entry for entry."""
-    import importlib.util
-    import pytest
-    pytest.importorskip("mpmath")
-    gen = os.path.join(REPO, "rrmpg_amd", "csrc", "tools", "gen_pow_tables.py")
-    committed = os.path.join(REPO, "rrmpg_amd", "csrc", "pow_tables.h")
-    with open(committed) as fp:
-        want = fp.read()
-    spec = importlib.util.spec_from_file_location("gen_pow_tables", gen)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    fresh = str(tmp_path / "pow_tables.h")
-    mod.main(fresh)                      # (the committed file is not touched)
-    with open(fresh) as fp:
-        got = fp.read()
-    assert got == want
-    # shape of the table: 128 entries, the two around x = 1 are {1, 0, 0, 0}
-    rows = re.findall(r"\{(\S+), (\S+), (\S+), (\S+)\}, ", want)
-    assert len(rows) == 128
-    for i in (79, 80):
-        assert [float.fromhex(v) for v in rows[i]] == [1.0, 0.0, 0.0, 0.0]
-    for invc, logc, tail, lnc in rows:
-        invc, logc, tail, lnc = (float.fromhex(v)
-                                 for v in (invc, logc, tail, lnc))
-        assert (invc * 2 ** 9) % 1 == 0 or (invc * 2 ** 8) % 1 == 0
-        assert lnc == logc + tail          # the pair's sum, rounded once
-        assert (logc * 2 ** 43) % 1 == 0 and abs(tail) < 2 ** -43
 
 
 def test_pow2_tables_header_matches_its_generator(tmp_path):
