@@ -137,32 +137,13 @@ __device__ __forceinline__ lanemask_t lanes_finite(double a) {
     return lanes_of_class(a, 0x1f8);
 }
 
-// fp64 select on a lane mask: set lanes take `a`, the others `b`.  Written as
-// two v_cndmask_b32 in their 8-byte VOP3 encoding on purpose: the 4-byte VOP2
-// form hipcc prefers whenever the mask sits in VCC costs 17 cycles of SIMD
-// time per wave64 instruction on gfx950 unless VCC was written by the
-// instruction right before it, against 4.3 for the VOP3 form with the mask in
-// VCC or any SGPR pair (profiles/ubench/valu_cost.hip, rows sel_vop2_vcc /
-// sel_vop3_*).
-__device__ __forceinline__ double rr_select(lanemask_t m, double a, double b)
-{
-    int lo, hi;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3"
-        : "=v"(lo) : "v"(__double2loint(b)), "v"(__double2loint(a)), "s"(m));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3"
-        : "=v"(hi) : "v"(__double2hiint(b)), "v"(__double2hiint(a)), "s"(m));
-    return __hiloint2double(hi, lo);
-}
-// set lanes take +0.0, the others b
-__device__ __forceinline__ double rr_select_zero(lanemask_t m, double b)
-{
-    int lo, hi;
-    asm("v_cndmask_b32_e64 %0, %1, 0, %2"
-        : "=v"(lo) : "v"(__double2loint(b)), "s"(m));
-    asm("v_cndmask_b32_e64 %0, %1, 0, %2"
-        : "=v"(hi) : "v"(__double2hiint(b)), "s"(m));
-    return __hiloint2double(hi, lo);
-}
+// (A hardware finding the kernels are written around: a v_cndmask_b32 in its
+// 4-byte VOP2 encoding, which hipcc prefers whenever the mask sits in VCC,
+// costs 17 cycles of SIMD time per wave64 instruction on gfx950 unless VCC was
+// written by the instruction right before it, against 4.3 for the VOP3 form
+// with the mask in VCC or any SGPR pair -- profiles/ubench/valu_cost.hip, rows
+// sel_vop2_vcc / sel_vop3_*.  Hence selects next to their compares, FMA
+// factors and exec-masked moves instead of masks kept in VCC.)
 
 // lanes whose a suits inv_div_core as a numerator: |a| in [2^-900, 2^900], or
 // +0 (invdiv.h: inv_div_numerator_ok0).  A caller may tighten the upper
