@@ -254,6 +254,22 @@ UB_KERNEL_I(cmp_sel2_vcc,
     "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %0, %0, %8, vcc\nv_cndmask_b32_e32 %10, %10, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %1, %1, %8, vcc\nv_cndmask_b32_e32 %11, %11, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %2, %2, %8, vcc\nv_cndmask_b32_e32 %12, %12, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %3, %3, %8, vcc\nv_cndmask_b32_e32 %13, %13, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %4, %4, %8, vcc\nv_cndmask_b32_e32 %14, %14, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %5, %5, %8, vcc\nv_cndmask_b32_e32 %15, %15, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %6, %6, %8, vcc\nv_cndmask_b32_e32 %16, %16, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_cndmask_b32_e32 %7, %7, %8, vcc\nv_cndmask_b32_e32 %17, %17, %8, vcc\n", 3)
 UB_KERNEL_I(cmp_sel2_sgpr,
     "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %0, %0, %8, %9\nv_cndmask_b32_e64 %10, %10, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %1, %1, %8, %9\nv_cndmask_b32_e64 %11, %11, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %2, %2, %8, %9\nv_cndmask_b32_e64 %12, %12, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %3, %3, %8, %9\nv_cndmask_b32_e64 %13, %13, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %4, %4, %8, %9\nv_cndmask_b32_e64 %14, %14, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %5, %5, %8, %9\nv_cndmask_b32_e64 %15, %15, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %6, %6, %8, %9\nv_cndmask_b32_e64 %16, %16, %8, %9\n" "v_cmp_lt_f64 %9, %20, %18\nv_cndmask_b32_e64 %7, %7, %8, %9\nv_cndmask_b32_e64 %17, %17, %8, %9\n", 3)
+// a compare, 1 independent VOP3 instructions, then the VOP2 selects on VCC:
+// does the select's cost depend on how long ago VCC was written?
+UB_KERNEL_I(cmp_gap1_sel2_vcc,
+    "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %11, %11, 0, %8\nv_cndmask_b32_e32 %0, %0, %8, vcc\nv_cndmask_b32_e32 %10, %10, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %12, %12, 0, %8\nv_cndmask_b32_e32 %1, %1, %8, vcc\nv_cndmask_b32_e32 %11, %11, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %13, %13, 0, %8\nv_cndmask_b32_e32 %2, %2, %8, vcc\nv_cndmask_b32_e32 %12, %12, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %14, %14, 0, %8\nv_cndmask_b32_e32 %3, %3, %8, vcc\nv_cndmask_b32_e32 %13, %13, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %15, %15, 0, %8\nv_cndmask_b32_e32 %4, %4, %8, vcc\nv_cndmask_b32_e32 %14, %14, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %16, %16, 0, %8\nv_cndmask_b32_e32 %5, %5, %8, vcc\nv_cndmask_b32_e32 %15, %15, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %17, %17, 0, %8\nv_cndmask_b32_e32 %6, %6, %8, vcc\nv_cndmask_b32_e32 %16, %16, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %10, %10, 0, %8\nv_cndmask_b32_e32 %7, %7, %8, vcc\nv_cndmask_b32_e32 %17, %17, %8, vcc\n", 4)
+// a compare, 2 independent VOP3 instructions, then the VOP2 selects on VCC:
+// does the select's cost depend on how long ago VCC was written?
+UB_KERNEL_I(cmp_gap2_sel2_vcc,
+    "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_cndmask_b32_e32 %0, %0, %8, vcc\nv_cndmask_b32_e32 %10, %10, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_cndmask_b32_e32 %1, %1, %8, vcc\nv_cndmask_b32_e32 %11, %11, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_cndmask_b32_e32 %2, %2, %8, vcc\nv_cndmask_b32_e32 %12, %12, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_cndmask_b32_e32 %3, %3, %8, vcc\nv_cndmask_b32_e32 %13, %13, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_cndmask_b32_e32 %4, %4, %8, vcc\nv_cndmask_b32_e32 %14, %14, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_cndmask_b32_e32 %5, %5, %8, vcc\nv_cndmask_b32_e32 %15, %15, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_cndmask_b32_e32 %6, %6, %8, vcc\nv_cndmask_b32_e32 %16, %16, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_cndmask_b32_e32 %7, %7, %8, vcc\nv_cndmask_b32_e32 %17, %17, %8, vcc\n", 5)
+// a compare, 4 independent VOP3 instructions, then the VOP2 selects on VCC:
+// does the select's cost depend on how long ago VCC was written?
+UB_KERNEL_I(cmp_gap4_sel2_vcc,
+    "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_cndmask_b32_e32 %0, %0, %8, vcc\nv_cndmask_b32_e32 %10, %10, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_cndmask_b32_e32 %1, %1, %8, vcc\nv_cndmask_b32_e32 %11, %11, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_cndmask_b32_e32 %2, %2, %8, vcc\nv_cndmask_b32_e32 %12, %12, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_cndmask_b32_e32 %3, %3, %8, vcc\nv_cndmask_b32_e32 %13, %13, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_cndmask_b32_e32 %4, %4, %8, vcc\nv_cndmask_b32_e32 %14, %14, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_cndmask_b32_e32 %5, %5, %8, vcc\nv_cndmask_b32_e32 %15, %15, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_cndmask_b32_e32 %6, %6, %8, vcc\nv_cndmask_b32_e32 %16, %16, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_cndmask_b32_e32 %7, %7, %8, vcc\nv_cndmask_b32_e32 %17, %17, %8, vcc\n", 7)
+// a compare, 8 independent VOP3 instructions, then the VOP2 selects on VCC:
+// does the select's cost depend on how long ago VCC was written?
+UB_KERNEL_I(cmp_gap8_sel2_vcc,
+    "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_cndmask_b32_e32 %0, %0, %8, vcc\nv_cndmask_b32_e32 %10, %10, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_cndmask_b32_e32 %1, %1, %8, vcc\nv_cndmask_b32_e32 %11, %11, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_cndmask_b32_e32 %2, %2, %8, vcc\nv_cndmask_b32_e32 %12, %12, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_cndmask_b32_e32 %3, %3, %8, vcc\nv_cndmask_b32_e32 %13, %13, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_cndmask_b32_e32 %4, %4, %8, vcc\nv_cndmask_b32_e32 %14, %14, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_cndmask_b32_e32 %5, %5, %8, vcc\nv_cndmask_b32_e32 %15, %15, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %17, %17, 0, %8\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_cndmask_b32_e32 %6, %6, %8, vcc\nv_cndmask_b32_e32 %16, %16, %8, vcc\n" "v_cmp_lt_f64 vcc, %20, %18\nv_lshl_add_u32 %10, %10, 0, %8\nv_lshl_add_u32 %11, %11, 0, %8\nv_lshl_add_u32 %12, %12, 0, %8\nv_lshl_add_u32 %13, %13, 0, %8\nv_lshl_add_u32 %14, %14, 0, %8\nv_lshl_add_u32 %15, %15, 0, %8\nv_lshl_add_u32 %16, %16, 0, %8\nv_lshl_add_u32 %17, %17, 0, %8\nv_cndmask_b32_e32 %7, %7, %8, vcc\nv_cndmask_b32_e32 %17, %17, %8, vcc\n", 11)
 UB_KERNEL_I(addc_co_vcc,
     "v_addc_co_u32 %0, vcc, %0, %8, vcc\n" "v_addc_co_u32 %1, vcc, %1, %8, vcc\n" "v_addc_co_u32 %2, vcc, %2, %8, vcc\n" "v_addc_co_u32 %3, vcc, %3, %8, vcc\n" "v_addc_co_u32 %4, vcc, %4, %8, vcc\n" "v_addc_co_u32 %5, vcc, %5, %8, vcc\n" "v_addc_co_u32 %6, vcc, %6, %8, vcc\n" "v_addc_co_u32 %7, vcc, %7, %8, vcc\n", 1)
 UB_KERNEL_I(add_co_vcc,
@@ -288,7 +304,7 @@ static const Entry entries[] = {
     E(and_b32), E(lshl_add_u32), E(ashrrev_i32), E(lshl_add_u64),
     E(mad_u64_u32), E(fma_f32), E(cvt_f32_f64), E(cvt_f64_f32),
     E(readlane_b32), E(readfirstlane_b32), E(writelane_b32),
-    E(sel_vop2_vcc), E(sel_vop3_vcc), E(sel_vop3_sgpr), E(cmp_sel2_vcc), E(cmp_sel2_sgpr), E(addc_co_vcc), E(add_co_vcc), E(mov_b32_indep), E(fma_f32_indep), E(rsq_f32_indep), E(rcp_f32_indep), E(sqrt_f32_indep), E(lshl_add_u32_indep)};
+    E(sel_vop2_vcc), E(sel_vop3_vcc), E(sel_vop3_sgpr), E(cmp_sel2_vcc), E(cmp_sel2_sgpr), E(cmp_gap1_sel2_vcc), E(cmp_gap2_sel2_vcc), E(cmp_gap4_sel2_vcc), E(cmp_gap8_sel2_vcc), E(addc_co_vcc), E(add_co_vcc), E(mov_b32_indep), E(fma_f32_indep), E(rsq_f32_indep), E(rcp_f32_indep), E(sqrt_f32_indep), E(lshl_add_u32_indep)};
 
 static double run(kern_t k, int waves_per_simd, int iters,
                   unsigned long long *d_out, unsigned long long mask)
