@@ -25,6 +25,11 @@
 //   mode 7  two sets per lane: 64 FMAs + scalar mix + one 16-byte store per
 //           lane and trip (2,048 waves: the same sets as mode 2).
 //
+//   modes 10..15  mode 0 with another instruction in the FMA's place:
+//           v_add_f64, v_mul_f64, v_max_f64, v_cndmask_b32 (VOP3), v_add_u32,
+//           v_rcp_f64 (8 per trip instead of 32: quarter rate) -- what each
+//           kind costs at the socket.
+//
 //   hipcc --offload-arch=gfx950 -O2 -o energy energy.hip
 //   ./energy <mode> <seconds>     -> prints trips/s per wave and GB/s stored
 #include <hip/hip_runtime.h>
@@ -55,10 +60,11 @@ __global__ __launch_bounds__(64) void soak(double *out, const double *rec,
     typedef const double __attribute__((address_space(4))) *cp_t;
     cp_t rp = (cp_t)rec;
     unsigned sx = blockIdx.x;
-    constexpr bool STORES = MODE >= 2;
+    const unsigned long long sx64 = 0x5555555555555555ull ^ blockIdx.x;
+    constexpr bool STORES = MODE >= 2 && MODE < 10;
     constexpr bool SCALAR = MODE == 1 || MODE == 2 || MODE == 3 || MODE == 5 ||
                             MODE == 7;
-    constexpr int FMAS = (MODE == 4 || MODE == 6) ? 0
+    constexpr int FMAS = (MODE == 4 || MODE == 6 || MODE >= 10) ? 0
                          : (MODE == 5 ? 24 : (MODE == 7 ? 64 : 32));
     for (int t = 0; t < trips; ++t) {
         double r0 = 0, r1 = 0;
@@ -72,6 +78,28 @@ __global__ __launch_bounds__(64) void soak(double *out, const double *rec,
             for (int k = 0; k < 6; ++k) {
                 asm volatile("s_add_u32 %0, %0, 0x9e37\n\ts_xor_b32 %0, %0, 0x5bd1"
                              : "+s"(sx) : : "scc");
+            }
+        }
+        if constexpr (MODE >= 10) {
+            int *ai = reinterpret_cast<int *>(a);
+#pragma unroll
+            for (int r = 0; r < (MODE == 15 ? 1 : 4); ++r) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (MODE == 10)
+                        asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+                    else if (MODE == 11)
+                        asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+                    else if (MODE == 12)
+                        asm volatile("v_max_f64 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+                    else if (MODE == 13)
+                        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2"
+                                     : "+v"(ai[2 * k]) : "v"(ai[2 * k + 1]), "s"(sx64));
+                    else if (MODE == 14)
+                        asm volatile("v_add_u32 %0, %0, %1" : "+v"(ai[2 * k]) : "v"(ai[2 * k + 1]));
+                    else
+                        asm volatile("v_rcp_f64 %0, %0" : "+v"(a[k]));
+                }
             }
         }
 #pragma unroll
@@ -139,7 +167,13 @@ int main(int argc, char **argv)
         case 4: soak<4><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
         case 5: soak<5><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
         case 6: soak<6><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
-        default: soak<7><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        case 7: soak<7><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        case 10: soak<10><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        case 11: soak<11><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        case 12: soak<12><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        case 13: soak<13><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        case 14: soak<14><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
+        default: soak<15><<<waves, 64>>>(out, rec, ld, TRIPS, 0.999999, 1e-7); break;
         }
     };
     launch();
@@ -154,7 +188,7 @@ int main(int argc, char **argv)
         el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } while (el < seconds);
     const double trips_per_s = (double)launches * TRIPS / el;       // per wave
-    const bool stores = mode >= 2;
+    const bool stores = mode >= 2 && mode < 10;
     printf("mode %d waves %d seconds %.2f trips_per_wave_per_s %.4e "
            "stored_GBps %.1f wave_trips_per_s %.4e\n", mode, waves, el,
            trips_per_s, stores ? trips_per_s * waves * (wide ? 1024 : 512) / 1e9 : 0.0,

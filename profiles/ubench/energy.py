@@ -23,7 +23,11 @@ MODES = {0: "32 v_fma_f64 per trip",
          4: "the stores alone (no arithmetic)",
          5: "24 FMAs + scalar mix + stores",
          6: "stores alone, 16 B per lane (1 KiB per wave-row)",
-         7: "two sets per lane: 64 FMAs + scalar + 16-B store"}
+         7: "two sets per lane: 64 FMAs + scalar + 16-B store",
+         10: "32 v_add_f64 per trip", 11: "32 v_mul_f64 per trip",
+         12: "32 v_max_f64 per trip", 13: "32 v_cndmask_b32 (VOP3) per trip",
+         14: "32 v_add_u32 per trip", 15: "8 v_rcp_f64 per trip"}
+INSTR_PER_TRIP = {0: 32, 10: 32, 11: 32, 12: 32, 13: 32, 14: 32, 15: 8}
 
 
 def main():
@@ -39,7 +43,10 @@ def main():
                                    if isinstance(v, float)}))
     print("# mode | what | socket W | sclk MHz | wave-trips/s | stored GB/s |"
           " cycles per trip per SIMD")
+    only = [int(m) for m in sys.argv[2:]]
     for mode, what in MODES.items():
+        if only and mode not in only:
+            continue
         s = bench.SocketSampler(0)
         out = {}
 
@@ -60,9 +67,16 @@ def main():
         mhz = r.get("sclk_mhz") or float("nan")
         # 1024 SIMDs: cycles a SIMD spends per wave-trip
         cyc = mhz * 1e6 * 1024 / wt if wt else float("nan")
-        print("%d | %-44s | %7.1f | %7.1f | %.4e | %7.1f | %6.1f"
+        extra = ""
+        if mode in INSTR_PER_TRIP and rec and wt:
+            # dynamic power / lane-operations per second
+            pj = ((r.get("socket_w", 0) - rec["socket_w"])
+                  / (wt * INSTR_PER_TRIP[mode] * 64) * 1e12)
+            extra = " | %.1f pJ per lane-op, %.2f cycles per instr" % (
+                pj, cyc / INSTR_PER_TRIP[mode])
+        print("%d | %-44s | %7.1f | %7.1f | %.4e | %7.1f | %6.1f%s"
               % (mode, what, r.get("socket_w", float("nan")), mhz, wt,
-                 float(f.get("stored_GBps", "nan")), cyc), flush=True)
+                 float(f.get("stored_GBps", "nan")), cyc, extra), flush=True)
         time.sleep(1.0)
 
 
