@@ -107,39 +107,11 @@ def allgather_scores(local_scores, num_sets=None, group=None,
     by one).  Returns the concatenated [num_sets] tensor on every rank.
     Without an initialised process group (single process) it is the identity;
     so it is for a group of one rank unless always_collective is set (tests:
-    the RCCL call itself on a single-GPU box).
+    the RCCL call itself on a single-GPU box).  (allgather_scores_begin and
+    its finish() in one step.)
     """
-    if not (dist.is_available() and dist.is_initialized()):
-        return local_scores
-    world = dist.get_world_size(group)
-    if world == 1 and not always_collective:
-        return local_scores
-    rank = dist.get_rank(group)
-    if num_sets is None:
-        n = torch.tensor([local_scores.numel()], device=local_scores.device)
-        dist.all_reduce(n, group=group)
-        num_sets = int(n.item())
-    lens = [shard_bounds(num_sets, world, r) for r in range(world)]
-    lens = [b - a for a, b in lens]
-    if lens[rank] != local_scores.numel():
-        raise ValueError("rank %d holds %d scores, expected %d"
-                         % (rank, local_scores.numel(), lens[rank]))
-    longest = max(lens)
-    if min(lens) == longest:
-        out = torch.empty(num_sets, dtype=local_scores.dtype,
-                          device=local_scores.device)
-        dist.all_gather_into_tensor(out, local_scores.contiguous(),
-                                    group=group)
-        return out
-    # ragged: pad every block to the longest, gather, drop the padding
-    padded = torch.zeros(longest, dtype=local_scores.dtype,
-                         device=local_scores.device)
-    padded[:local_scores.numel()] = local_scores
-    out = torch.empty(world * longest, dtype=local_scores.dtype,
-                      device=local_scores.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
-    return torch.cat([out[r * longest:r * longest + lens[r]]
-                      for r in range(world)])
+    return allgather_scores_begin(local_scores, num_sets, group,
+                                  always_collective).finish()
 
 
 # ---------------------------------------------------------------------------
