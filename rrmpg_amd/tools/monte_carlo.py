@@ -181,6 +181,11 @@ def _monte_carlo_resident(model, num, qobs, score, seed, gpus, kwargs,
     world = (dist.get_world_size() if dist.is_available()
              and dist.is_initialized() else 1)
     if world > 1:
+        # ONE key for the job: rank 0's (a key drawn from every rank's own
+        # global generator would give every rank another population)
+        key = [seed]
+        dist.broadcast_object_list(key, src=0)
+        seed = int(key[0])
         first, stop = sharding.shard_bounds(num, world, dist.get_rank())
         params = rrdev.sample_params(model, stop - first, seed, n_total=num,
                                      first=first, device=ens.device)

@@ -347,6 +347,13 @@ def test_monte_carlo_device_sampler_inside_a_two_rank_group(tmp_path):
         "assert np.array_equal(got['nse'], ref['nse'])\n"
         "assert np.array_equal(np.asarray(got['params']),\n"
         "                      np.asarray(ref['params'])[a:b])\n"
+        "# no seed: the ranks' own generators differ, the job's key is rank 0's\n"
+        "np.random.seed(100 + rank)\n"
+        "del call['seed']\n"
+        "free = monte_carlo(m, 1001, **call, **kw)\n"
+        "both = [None, None]\n"
+        "dist.all_gather_object(both, free['mse'].tobytes())\n"
+        "assert both[0] == both[1]\n"
         "dist.barrier(); dist.destroy_process_group()\n"
         "print('rank', rank, 'ok')\n" % REPO)
     import socket
