@@ -64,7 +64,9 @@ struct __attribute__((aligned(8))) HbvDay {
 //          kernel's TAME loop copy;
 //   bit 1  a forcing value (temperature, precipitation, temp - T_m, PE_m)
 //          that is not finite or beyond HBV_CIVIL: every lane of the launch
-//          then takes the reference's own sequence (hbv_civil_lane).
+//          then takes the reference's own sequence (hbv_civil_lane);
+//   bit 2  an observation that is not finite (the run-away test of the
+//          reference instantiation then leaves the sums of squares aside).
 // dtemp_raw[c][t] = temp - T_m[month] as the reference forms it, for that
 // sequence (the day record carries the product with PE_m).
 __global__ void hbv_pack_forcing(const double *__restrict__ temp,
@@ -99,9 +101,14 @@ __global__ void hbv_pack_forcing(const double *__restrict__ temp,
                          !(fabs(d.dtemp) <= HBV_CIVIL);
     const int any_odd = __syncthreads_or(t < T && odd);
     const int any_uncivil = __syncthreads_or(t < T && uncivil);
+    // (bit 2: an observation that is not finite -- every sum of squares of
+    // the catchment then is not, whatever the set: hbvedu_kernel's run-away
+    // test cannot go by the sums)
+    const int any_gap = __syncthreads_or(t < T && !__builtin_isfinite(d.qobs));
     if (threadIdx.x == 0)
         flags[c * gridDim.x + blockIdx.x] = (any_odd ? 1 : 0) |
-                                            (any_uncivil ? 2 : 0);
+                                            (any_uncivil ? 2 : 0) |
+                                            (any_gap ? 4 : 0);
     if (t >= T) return;
     days[g] = d;
     dtemp_raw[g] = dtemp;
@@ -337,14 +344,51 @@ hbvedu_kernel(
     {
         const int nb = (int)((T + 255) / 256);
         const int *flags = day_flags + (int64_t)catchment * nb;
-        lanemask_t uncivil = 0;
-        for (int k = threadIdx.x; k - (int)threadIdx.x < nb; k += RR_BLOCK)
+        lanemask_t uncivil = 0, gaps = 0;
+        for (int k = threadIdx.x; k - (int)threadIdx.x < nb; k += RR_BLOCK) {
             uncivil |= RR_LANES(k < nb && (flags[k] & 2) != 0);
+            if (REFERENCE) gaps |= RR_LANES(k < nb && (flags[k] & 4) != 0);
+        }
         lane_civil = uncivil == 0 && fabs(snow_init) <= HBV_CIVIL &&
                      fabs(soil_init) <= HBV_CIVIL &&
                      fabs(s1_init) <= HBV_CIVIL &&
                      fabs(s2_init) <= HBV_CIVIL && hbv_civil_lane(p);
-        const bool wave_civil = (rr_exec() & ~RR_LANES(lane_civil)) == 0;
+        bool wave_civil = (rr_exec() & ~RR_LANES(lane_civil)) == 0;
+        if constexpr (REFERENCE) {
+            // ... and an all-civil wave in which a set RAN AWAY is this
+            // kernel's as well.  A civil set still can: FC = 1 mm under a
+            // soil of 100 mm makes (soil / FC)**Beta 1e4, the soil overshoots
+            // to -1e6, 1e14 ... and within weeks the stores are infinite --
+            // where the fast forms are no longer the reference's statements
+            // (inf * K_0 with K_0 = 0 is NaN in max(0, s1 - L) * K_0 and 0 in
+            // the folded form's hardware maximum; fuzz seed 684: NaN a day
+            // late).  Infinities and NaN stay in these recurrences (the
+            // reservoirs carry them into the discharge, the discharge into
+            // the sum of squares), so what the fast kernel -- which has just
+            // run this wave -- left in the LAST row of each output it wrote,
+            // and in the sums, tells; the fast kernel itself carries nothing
+            // for it (a flag store at the end of its sweep cost the
+            // multi-catchment kernels 12 VGPRs and their fourth wave per
+            // SIMD: 15.9 -> 18.7 ms for 125 catchments x 10k sets).  The wave
+            // then is computed again below, each lane with the reference's
+            // own day from the first day that starts with a store that is
+            // not finite (day_step) -- the rule a civil set gets among
+            // wave-mates that are not, so its bits do not depend on the
+            // company.
+            bool ran = false;
+            if (wave_civil && active) {
+                const int64_t last = (T - 1) * ld + i;
+                if (WRITE_Q) ran = ran || !__builtin_isfinite(qsim[last]);
+                if (WRITE_S)
+                    ran = ran || !__builtin_isfinite(snow_out[last]) ||
+                          !__builtin_isfinite(soil_out[last]) ||
+                          !__builtin_isfinite(s1_out[last]) ||
+                          !__builtin_isfinite(s2_out[last]);
+                if (WITH_SSE && gaps == 0)
+                    ran = ran || !__builtin_isfinite(sse[i]);
+            }
+            wave_civil = wave_civil && RR_LANES(ran) == 0;
+        }
         if (wave_civil == REFERENCE) {
             // not this kernel's wave.  (A piece of the time axis still tells
             // the next one, which is skipped just the same, not to wait.)
@@ -688,14 +732,21 @@ hbvedu_kernel(
         if constexpr (REFERENCE) {
             // each lane its own sequence: a civil lane the fast forms (the
             // bits it has in any other launch), every other lane the
-            // reference's own day, from the same start states
+            // reference's own day, from the same start states -- and a civil
+            // lane too from the day on which it starts with a store that is
+            // not finite (a set that ran away, see the wave's choice above:
+            // infinities and NaN stay, so does the choice)
             const HbvRefDay r = hbv_reference_day(
                 p, f.temp, f.prec, dtemp_raw[t], f.pe_m, snow, soil, s1, s2);
-            snow = lane_civil ? snow_n : r.snow;
-            soil = lane_civil ? soil_n : r.soil;
-            s1 = lane_civil ? s1_n : r.s1;
-            s2 = lane_civil ? s2_n : r.s2;
-            q_c = lane_civil ? q : r.q;
+            const bool fast_day =
+                lane_civil && __builtin_isfinite(snow) &&
+                __builtin_isfinite(soil) && __builtin_isfinite(s1) &&
+                __builtin_isfinite(s2);
+            snow = fast_day ? snow_n : r.snow;
+            soil = fast_day ? soil_n : r.soil;
+            s1 = fast_day ? s1_n : r.s1;
+            s2 = fast_day ? s2_n : r.s2;
+            q_c = fast_day ? q : r.q;
         } else {
             snow = snow_n; soil = soil_n; s1 = s1_n; s2 = s2_n;
         }

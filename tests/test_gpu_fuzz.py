@@ -267,6 +267,86 @@ def test_hbvedu_fuzz(models, oracle, hbv_variant):
     assert (amp.max(axis=0)[1::2] < 1e-9).mean() > 0.5   # most wild ones too
 
 
+def test_hbvedu_civil_set_that_runs_away(models, oracle, hbv_variant):
+    """Fuzz seed 684, set 443, kept as a case of its own: every parameter
+    inside the civil box, but FC = 1 mm under an initial soil of 100 mm makes
+    (soil / FC)**Beta 1e4 -- the soil overshoots, and within two months the
+    stores are infinite.  There the fast forms are no longer the reference's
+    statements (max(0, s1 - L) * K_0 with s1 = inf, K_0 = 0 is NaN; the
+    folded form's hardware maximum gives 0), and the near-surface store read
+    inf where the reference has NaN, a day late.  The reference kernel
+    behind the fast one now takes every all-civil wave whose last output row
+    (or sum of squares) is not finite and computes it again, each lane with
+    the reference's own day from the first day that starts with a store that
+    is not finite (csrc/hbvedu.hip): the NaN / inf pattern is the oracle's
+    day by day, the set's wave-mates keep their bits, and the set itself has
+    the same bits among civil wave-mates, among wild ones, and with the
+    discharge as the only output."""
+    g = golden("syn_hbvedu")
+    rng = np.random.default_rng(684)
+    lo = np.array([-1, 3, 100, 1, .01, 90, .05, .01, .01, .01, 2.])
+    hi = np.array([1, 7, 200, 7, .07, 180, .2, .1, .05, .05, 5.])
+    n, t = 200, 400
+    flat = lo + (hi - lo) * rng.random((n, 11))
+    wild = np.array([-0.6172643189812488, 1e-05, 1.0, 2.0,
+                     0.013688696087420371, 105.2038075127825, 0.0,
+                     0.07708904560274418, 0.036591165513947574,
+                     0.040856502449478624, 4.866631712418977])
+    where = [3, 64, 131, 199]
+    runaway = flat.copy()
+    runaway[where] = wild
+    runaway[131, 2] = 0.5           # (another run-away: FC = 0.5 mm)
+    args = (g["temp"][:t], g["prec"][:t], g["month"][:t], g["PE_m"],
+            g["T_m"], 0., 100., 3., 10.)
+    with np.errstate(all="ignore"):
+        ref = oracle.simulate_hbvedu(args[0], args[1], args[2] - 1, args[3],
+                                     args[4], (0., 100., 3., 10.), runaway,
+                                     return_storage=True, nthreads=8)
+    assert np.isnan(ref[0][:, where]).any() and np.isinf(ref[3][:, 3]).any()
+    out = models.HBVEdu().simulate(*args, return_storage=True,
+                                   params=_records(models.HBVEdu, runaway))
+    tame = models.HBVEdu().simulate(*args, return_storage=True,
+                                    params=_records(models.HBVEdu, flat))
+    others = np.setdiff1d(np.arange(n), where)
+    for a, b, c, name in zip(out, ref, tame,
+                             ["qsim", "snow", "soil", "s1", "s2"]):
+        for i in where:
+            x, r = a[:, i], b[:, i]
+            assert np.array_equal(np.isnan(x), np.isnan(r)), (name, i)
+            assert np.array_equal(np.isinf(x), np.isinf(r)), (name, i)
+            fin = np.isfinite(r)
+            assert np.allclose(x[fin], r[fin], rtol=1e-9, atol=0), (name, i)
+        # the wave-mates: the bits they have without the run-away sets
+        assert np.array_equal(a[:, others], c[:, others]), name
+    # ... in the company of wild sets (the reference kernel's waves from the
+    # start), and with qsim alone
+    company = runaway.copy()
+    company[[0, 70, 140, 198], 5] = np.nan
+    mixed = models.HBVEdu().simulate(*args, return_storage=True,
+                                     params=_records(models.HBVEdu, company))
+    for a, b, name in zip(out, mixed, ["qsim", "snow", "soil", "s1", "s2"]):
+        assert np.array_equal(a[:, where], b[:, where], equal_nan=True), name
+    q_only = models.HBVEdu().simulate(*args,
+                                      params=_records(models.HBVEdu, runaway))
+    assert np.array_equal(np.asarray(q_only), out[0], equal_nan=True)
+    # ... and the sums of squares, alone (the headline mode: nothing but the
+    # sums tells the reference kernel) and next to the discharge
+    from rrmpg_amd.models import hbvedu as hbv_mod
+    forcing = (args[0], args[1], (args[2] - 1).astype(np.int8), args[3],
+               args[4])
+    qobs = np.abs(np.asarray(tame[0][:, 7]))
+    recs = _records(models.HBVEdu, runaway)
+    _, sse_alone = hbv_mod._run(forcing, args[5:], recs, False, False, qobs)
+    (q_too, *_), sse_with = hbv_mod._run(forcing, args[5:], recs, True, False,
+                                         qobs)
+    assert np.array_equal(sse_alone, sse_with, equal_nan=True)
+    assert np.array_equal(q_too, out[0], equal_nan=True)
+    with np.errstate(all="ignore"):
+        want = ((ref[0] - qobs[:, None]) ** 2).sum(axis=0)
+    assert np.array_equal(np.isnan(sse_alone), np.isnan(want))
+    assert np.allclose(sse_alone[others], want[others], rtol=1e-9)
+
+
 def test_hbvedu_sets_do_not_feel_their_wave_mates(models, oracle):
     """Which sequence a set gets -- the fast forms or the reference's own
     (csrc/hbvedu.hip hbv_civil_lane) -- depends on ITS parameters only: a
