@@ -28,7 +28,10 @@
  *     (dense ld = N with N % 8 != 0) cost a million-set sweep up to 40 %
  *     (profiles/r04_row_pitch.txt).  Correctness does not depend on it;
  *   - any output pointer may be NULL = "do not materialise it"
- *     (return_storage=False in the reference);
+ *     (return_storage=False in the reference); storage outputs come WITH
+ *     the discharge, as return_storage=True returns them, or not at all
+ *     (storages without qsim: RR_E_NULL), and qsim may be NULL when only
+ *     the sums below are wanted;
  *   - qobs/sse: if both non-NULL the kernel also accumulates, in time order,
  *     sse[i] = sum_t (qobs[t] - qsim[t, i])^2  -- the numerator of
  *     calc_mse / calc_nse (reference: rrmpg/utils/metrics.py:131, :72) so a
@@ -54,7 +57,7 @@
  * NaN appear where and as the reference produces them, day by day.  The one
  * population that keeps the fast forms regardless is GR4J-family sets with
  * x4 > 20 days (the reference path holds 20-day unit hydrographs in
- * registers) and Cemaneige stacks of more than 8 layers.
+ * registers) and Cemaneige stacks of more than 5 layers.
  *
  * Two families:
  *   rr_<model>_simulate      host pointers; synchronous; the library moves
@@ -87,11 +90,12 @@ extern "C" {
 #define RR_E_NODEVICE -5  /* no usable gfx950 device                        */
 #define RR_E_WORKSPACE -6 /* workspace missing or too small                 */
 
-/* Cemaneige: up to this many elevation layers keep their snow states in
- * registers; more layers run through an HBM scratch (slower, same results). */
-#define RR_CEMANEIGE_MAX_LAYERS 8
-/* ... and the hysteresis / ice-melt couplings (next tier) up to this many */
-#define RR_SNOWNEXT_REG_LAYERS 5
+/* Cemaneige and its couplings: up to this many elevation layers -- the
+ * model's own five equal-area zones -- keep their snow states in registers;
+ * more layers run through an HBM scratch (slower, same results). */
+#define RR_CEMANEIGE_MAX_LAYERS 5
+/* (the hysteresis / ice-melt couplings' name for it) */
+#define RR_SNOWNEXT_REG_LAYERS RR_CEMANEIGE_MAX_LAYERS
 /* GR4J: largest x4 whose unit hydrographs (ceil(x4) ordinates for UH1,
  * ceil(2*x4+1) for UH2) live on chip -- registers up to 10, LDS up to this.
  * Longer ones run too, as in the reference, from a scratch in HBM behind the

@@ -157,6 +157,9 @@ extern "C" int rr_abc_simulate_dev(const double *prec, int64_t T,
         rr_set_error("rr_abc_simulate_dev: prec is NULL");
         return RR_E_NULL;
     }
+    if ((rc = rr_check_outputs("rr_abc_simulate_dev", qsim,
+                               storage != nullptr)) != RR_OK)
+        return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool q = qsim != nullptr, s = storage != nullptr, e = qobs && sse;
     const bool wide = (ld % 2 == 0) && (((uintptr_t)qsim) % 16 == 0) &&

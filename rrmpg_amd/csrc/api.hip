@@ -220,6 +220,16 @@ int rr_check_common(const char *who, int64_t T, int64_t N, int64_t ld,
     return RR_OK;
 }
 
+int rr_check_outputs(const char *who, const void *qsim, bool any_storage)
+{
+    if (any_storage && !qsim) {
+        rr_set_error("%s: storage outputs come with qsim (as the reference's "
+                     "return_storage returns them), not alone", who);
+        return RR_E_NULL;
+    }
+    return RR_OK;
+}
+
 // --------------------------------------------------------------------------
 // host-pointer family
 // --------------------------------------------------------------------------
@@ -862,6 +872,9 @@ extern "C" int rr_abc_simulate_opt(const double *prec, int64_t T,
 
     int rc = rr_check_common("rr_abc_simulate", T, N, N, params, qobs, sse);
     if (rc != RR_OK) return rc;
+    if ((rc = rr_check_outputs("rr_abc_simulate", qsim,
+                               storage != nullptr)) != RR_OK)
+        return rc;
     if (T == 0 || N == 0) return RR_OK;
     if (!prec) { rr_set_error("rr_abc_simulate: prec is NULL"); return RR_E_NULL; }
     return host_fan_out(N, [&](int64_t first, int64_t n) -> int {
@@ -911,6 +924,9 @@ extern "C" int rr_hbvedu_simulate_opt(
 
     int rc = rr_check_common("rr_hbvedu_simulate", T, N, N, params, qobs, sse);
     if (rc != RR_OK) return rc;
+    if ((rc = rr_check_outputs("rr_hbvedu_simulate", qsim,
+                               snow || soil || s1 || s2)) != RR_OK)
+        return rc;
     if (T == 0 || N == 0) return RR_OK;
     if (!temp || !prec || !month || !PE_m || !T_m) {
         rr_set_error("rr_hbvedu_simulate: NULL forcing pointer");
@@ -973,6 +989,9 @@ extern "C" int rr_gr4j_simulate_opt(const double *prec, const double *etp,
 
     int rc = rr_check_common("rr_gr4j_simulate", T, N, N, params, qobs, sse);
     if (rc != RR_OK) return rc;
+    if ((rc = rr_check_outputs("rr_gr4j_simulate", qsim,
+                               s_store || r_store)) != RR_OK)
+        return rc;
     if (T == 0 || N == 0) return RR_OK;
     if (!prec || !etp) {
         rr_set_error("rr_gr4j_simulate: NULL forcing pointer");
@@ -1033,6 +1052,9 @@ extern "C" int rr_cemaneige_simulate_opt(
     int rc = rr_check_common("rr_cemaneige_simulate", T, N, N, params, qobs,
                              sse);
     if (rc != RR_OK) return rc;
+    if ((rc = rr_check_outputs("rr_cemaneige_simulate", outflow,
+                               G || eTG)) != RR_OK)
+        return rc;
     if (T == 0 || N == 0) return RR_OK;
     if (L < 1) { rr_set_error("rr_cemaneige_simulate: L < 1"); return RR_E_PARAM; }
     if (!prec || !mean_temp || !frac_solid_prec) {
@@ -1096,6 +1118,9 @@ extern "C" int rr_cemaneigegr4j_simulate_opt(
     int rc = rr_check_common("rr_cemaneigegr4j_simulate", T, N, N, params,
                              qobs, sse);
     if (rc != RR_OK) return rc;
+    if ((rc = rr_check_outputs("rr_cemaneigegr4j_simulate", qsim,
+                               G || eTG || s_store || r_store)) != RR_OK)
+        return rc;
     if (T == 0 || N == 0) return RR_OK;
     if (L < 1) { rr_set_error("rr_cemaneigegr4j_simulate: L < 1"); return RR_E_PARAM; }
     if (!prec || !mean_temp || !etp || !frac_solid_prec) {
@@ -1250,6 +1275,10 @@ int snow_gr4j_host(const char *who, int variant, const double *prec,
     const int npar = 6 + (hyst ? 2 : 0) + (ice ? 1 : 0);
     int rc = rr_check_common(who, T, N, N, params, qobs, sse);
     if (rc != RR_OK) return rc;
+    if ((rc = rr_check_outputs(who, qsim,
+                               G || eTG || s_store || r_store || sca || icemelt ||
+                                   snowmelt)) != RR_OK)
+        return rc;
     if (T == 0 || N == 0) return RR_OK;
     if (L < 1) { rr_set_error("%s: L < 1", who); return RR_E_PARAM; }
     if (!prec || !mean_temp || !etp || !frac_solid_prec || (ice && !frac_ice)) {

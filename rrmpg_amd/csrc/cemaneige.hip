@@ -7,7 +7,7 @@
 // rrmpg/models/cemaneige.py:218-245, rrmpg/models/cemaneigegr4j.py:238-273).
 //
 // One lane per parameter set.  Per elevation layer the snow pack G and its
-// thermal state eTG live in registers (L <= 8 layers, kernels are
+// thermal state eTG live in registers (L <= 5 layers, kernels are
 // instantiated per L so the layer loop is fully unrolled).  Everything that
 // does not depend on the parameters is hoisted out of the N-fold sweep by two
 // small pre-pass kernels, with the very operations the reference performs
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(RR_BLOCK) void cemaneige_kernel(
 template <int L, class UH, bool SMALL = false>
 constexpr int coupled_min_waves()
 {
-    return (!SMALL && L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
-                                 uh_is_indexed<UH>))
+    return (!SMALL && (std::is_same<UH, UhRegs<3>>::value ||
+                       uh_is_indexed<UH>))
                ? (std::is_same<UH, UhRegs<3>>::value ? COUPLED_BIG_MINWAVES : 4)
                : 2;
 }
@@ -284,11 +284,13 @@ constexpr int coupled_min_waves()
 // population): occupancy is not a concern there and exposed latencies are,
 // so the polynomial constants and the melt thresholds sit in VGPRs and the
 // only scalar load left in the time loop is the prefetched day record.
-// Instantiated where the register file allows it.
+// Instantiated for the model's own five layers, where it was measured (fewer
+// layers run the many-waves form at any size), and where the register file
+// allows it.
 template <int L, class UH>
 constexpr bool coupled_has_small()
 {
-    return L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
+    return L == 5 && (std::is_same<UH, UhRegs<3>>::value ||
                       std::is_same<UH, UhRegs<5>>::value);
 }
 
@@ -439,8 +441,7 @@ struct Gr4jGen {
 template <int L, class UH>
 constexpr bool coupled_has_optimistic()
 {
-    return L <= 5 && (std::is_same<UH, UhRegs<3>>::value ||
-                      std::is_same<UH, UhRegs<5>>::value);
+    return coupled_has_small<L, UH>();
 }
 
 // The small-sweep form only (polynomial constants and melt thresholds in
@@ -866,6 +867,9 @@ extern "C" int rr_cemaneige_simulate_dev(
         rr_set_error("rr_cemaneige_simulate_dev: pass both G and eTG or none");
         return RR_E_NULL;
     }
+    if ((rc = rr_check_outputs("rr_cemaneige_simulate_dev", outflow,
+                               G != nullptr)) != RR_OK)
+        return rc;
     if (!workspace || workspace_bytes < cema_ws_bytes(T, L, false, N)) {
         rr_set_error("rr_cemaneige_simulate_dev: workspace too small");
         return RR_E_WORKSPACE;
@@ -1016,6 +1020,9 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
                      "outputs or none");
         return RR_E_NULL;
     }
+    if ((rc = rr_check_outputs("rr_cemaneigegr4j_simulate_dev", qsim,
+                               ns != 0)) != RR_OK)
+        return rc;
     if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true, N)) {
         rr_set_error("rr_cemaneigegr4j_simulate_dev: workspace too small");
         return RR_E_WORKSPACE;
@@ -1044,14 +1051,14 @@ extern "C" int rr_cemaneigegr4j_simulate_dev(
     // plan selects (gr4j_core.h)
     const size_t lds_bytes = GR4J_LDS_BYTES;
     if (L > RR_CEMANEIGE_MAX_LAYERS) {
-        gr4j_for_each_tier([&](auto uh) {
+        gr4j_for_each_indexed_tier([&](auto uh) {
             using UH = decltype(uh);
             cemaneige_dyn_kernel<UH>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
                    st>>>(days, gt, T, (int)L, cema_record_len((int)L, true),
                          snow_pack_init,
                          thermal_state_init, s_init, r_init, params, 6, N,
-                         d_plan, force_lds, state, qsim, G, eTG, s_store,
+                         d_plan, /*force_lds=*/1, state, qsim, G, eTG, s_store,
                          r_store, ld, qo, sse, uh_mem);
         });
         RR_HIP(hipGetLastError());

@@ -444,18 +444,25 @@ int rr_simd_count();
 int rr_check_common(const char *who, int64_t T, int64_t N, int64_t ld,
                     const void *params, const void *qobs, const void *sse);
 
-// Turns three runtime flags into compile-time template arguments:
-// f(std::bool_constant<a>, std::bool_constant<b>, std::bool_constant<c>).
+// Storage outputs are returned WITH the discharge, as the reference's
+// return_storage does (hbvedu.py:191 and its siblings), never alone: the
+// kernels are built for the five combinations of outputs that leaves.
+int rr_check_outputs(const char *who, const void *qsim, bool any_storage);
+
+// Turns the three output flags (discharge, storages, sums of squares) into
+// compile-time template arguments: f(std::bool_constant<q>, <s>, <e>) for
+// {q}, {q, s}, {q, e}, {q, s, e} and {e}.  Storages without the discharge are
+// refused before (rr_check_outputs); with nothing to write there is nothing
+// to launch.
 template <class F>
-static inline void rr_dispatch3(bool a, bool b, bool c, F &&f)
+static inline void rr_dispatch3(bool q, bool s, bool e, F &&f)
 {
     const std::true_type Y{};
     const std::false_type N{};
-    if (a) {
-        if (b) { if (c) f(Y, Y, Y); else f(Y, Y, N); }
-        else   { if (c) f(Y, N, Y); else f(Y, N, N); }
-    } else {
-        if (b) { if (c) f(N, Y, Y); else f(N, Y, N); }
-        else   { if (c) f(N, N, Y); else f(N, N, N); }
+    if (q) {
+        if (s) { if (e) f(Y, Y, Y); else f(Y, Y, N); }
+        else   { if (e) f(Y, N, Y); else f(Y, N, N); }
+    } else if (!s && e) {
+        f(N, N, Y);
     }
 }

@@ -640,6 +640,9 @@ extern "C" int rr_gr4j_simulate_dev(const double *prec, const double *etp,
         rr_set_error("rr_gr4j_simulate_dev: pass both storage outputs or none");
         return RR_E_NULL;
     }
+    if ((rc = rr_check_outputs("rr_gr4j_simulate_dev", qsim,
+                               s_store != nullptr)) != RR_OK)
+        return rc;
     if (!workspace || workspace_bytes < rr_gr4j_workspace_bytes(T, N)) {
         rr_set_error("rr_gr4j_simulate_dev: workspace too small");
         return RR_E_WORKSPACE;

@@ -517,6 +517,17 @@ static inline void gr4j_for_each_tier(F &&f)
     f(UhMem{});
 }
 
+// ... and for the indexed tiers only, which between them run any x4 (the
+// kernels for more than RR_CEMANEIGE_MAX_LAYERS layers, launched with
+// force_lds = 1: a rare path that is built for simplicity, not for the
+// register tiers' speed)
+template <class F>
+static inline void gr4j_for_each_indexed_tier(F &&f)
+{
+    f(UhLds{});
+    f(UhMem{});
+}
+
 // The transcendental calls of the daily step (reference: 1 tanh + 3 pow) are
 // evaluated with fastmath.h instead of OCML's general tanh / pow (165 / 224
 // VALU instructions each):

@@ -1044,8 +1044,8 @@ static int hbv_launch(const double *temp, const double *prec,
 
 static int hbv_check(const char *who, const void *temp, const void *prec,
                      const void *month, const void *PE_m, const void *T_m,
-                     const double *snow, const double *soil, const double *s1,
-                     const double *s2)
+                     const double *qsim, const double *snow,
+                     const double *soil, const double *s1, const double *s2)
 {
     if (!temp || !prec || !month || !PE_m || !T_m) {
         rr_set_error("%s: NULL forcing pointer", who);
@@ -1056,7 +1056,7 @@ static int hbv_check(const char *who, const void *temp, const void *prec,
         rr_set_error("%s: pass all four storage outputs or none", who);
         return RR_E_NULL;
     }
-    return RR_OK;
+    return rr_check_outputs(who, qsim, any_s);
 }
 
 extern "C" int rr_hbvedu_simulate_dev(
@@ -1071,7 +1071,8 @@ extern "C" int rr_hbvedu_simulate_dev(
     int rc = rr_check_common(who, T, N, ld, params, qobs, sse);
     if (rc != RR_OK) return rc;
     if (T == 0 || N == 0) return RR_OK;
-    rc = hbv_check(who, temp, prec, month, PE_m, T_m, snow, soil, s1, s2);
+    rc = hbv_check(who, temp, prec, month, PE_m, T_m, qsim, snow, soil, s1,
+                   s2);
     if (rc != RR_OK) return rc;
     if (!workspace || workspace_bytes < rr_hbvedu_workspace_bytes(T, N)) {
         rr_set_error("%s: workspace too small", who);
@@ -1108,7 +1109,8 @@ extern "C" int rr_hbvedu_simulate_catchments_dev(
         return RR_E_SIZE;
     }
     if (T == 0 || N == 0 || C == 0) return RR_OK;
-    rc = hbv_check(who, temp, prec, month, PE_m, T_m, snow, soil, s1, s2);
+    rc = hbv_check(who, temp, prec, month, PE_m, T_m, qsim, snow, soil, s1,
+                   s2);
     if (rc != RR_OK) return rc;
     if (!inits) {
         rr_set_error("%s: inits is NULL", who);

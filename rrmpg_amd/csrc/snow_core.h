@@ -441,29 +441,21 @@ __device__ __forceinline__ bool cema_wave_is_sane(const double *gtresh, int L,
            fabs(thermal_state_init) <= 1e300 && (rr_exec() & ~ctg_ok) == 0;
 }
 
-// calls f(std::integral_constant<int, L>) for the runtime L in 1..MAXL
-// (MAXL: RR_CEMANEIGE_MAX_LAYERS = 8, or RR_SNOWNEXT_REG_LAYERS = 5)
+// calls f(std::integral_constant<int, L>) for the runtime L in
+// 1..RR_CEMANEIGE_MAX_LAYERS (the callers send more layers to the kernels
+// that run from the HBM state scratch: per-layer kernels for L = 6..8 were
+// 72 of the library's kernels and 5 MB of its code for configurations nobody
+// has asked for; removed in round 6)
 template <int MAXL = RR_CEMANEIGE_MAX_LAYERS, class F>
 static inline void dispatch_layers(int L, F &&f)
 {
-    static_assert(MAXL == 5 || MAXL == 8, "dispatch_layers");
+    static_assert(MAXL == 5, "dispatch_layers");
     switch (L) {
     case 1: f(std::integral_constant<int, 1>{}); break;
     case 2: f(std::integral_constant<int, 2>{}); break;
     case 3: f(std::integral_constant<int, 3>{}); break;
     case 4: f(std::integral_constant<int, 4>{}); break;
-    default:
-        if constexpr (MAXL == 5) {
-            f(std::integral_constant<int, 5>{});
-        } else {
-            switch (L) {
-            case 5: f(std::integral_constant<int, 5>{}); break;
-            case 6: f(std::integral_constant<int, 6>{}); break;
-            case 7: f(std::integral_constant<int, 7>{}); break;
-            default: f(std::integral_constant<int, 8>{}); break;
-            }
-        }
-        break;
+    default: f(std::integral_constant<int, 5>{}); break;
     }
 }
 

@@ -687,6 +687,7 @@ static int snow_gr4j_dev(const char *who, const double *prec,
         rr_set_error("%s: pass all %d storage outputs or none", who, want);
         return RR_E_NULL;
     }
+    if ((rc = rr_check_outputs(who, qsim, got != 0)) != RR_OK) return rc;
     if (!workspace || workspace_bytes < cema_ws_bytes(T, L, true, N, 4, RR_SNOWNEXT_REG_LAYERS)) {
         rr_set_error("%s: workspace too small", who);
         return RR_E_WORKSPACE;
@@ -728,13 +729,13 @@ static int snow_gr4j_dev(const char *who, const double *prec,
     // of the library's 525 kernels and 3.5 MB of its code for configurations
     // nobody has asked for; removed in round 6)
     if (L > RR_SNOWNEXT_REG_LAYERS) {
-        gr4j_for_each_tier([&](auto uh) {
+        gr4j_for_each_indexed_tier([&](auto uh) {
             using UH = decltype(uh);
             snow_gr4j_dyn_kernel<UH, HYST, ICE>
                 <<<grid, block, std::is_same<UH, UhLds>::value ? lds_bytes : 0,
                    st>>>(out, days, gt, frac_ice, T, (int)L, snow_pack_init,
                          thermal_state_init, sca_init, s_init, r_init, params,
-                         lay, N, d_plan, force_lds, qsim != nullptr,
+                         lay, N, d_plan, /*force_lds=*/1, qsim != nullptr,
                          G != nullptr, state, qo, sse, uh_mem);
         });
         RR_HIP(hipGetLastError());

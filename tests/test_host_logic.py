@@ -66,6 +66,10 @@ def test_argument_errors_are_reported_without_gpu():
     # the kernels count days in 32 bits: more than 2e9 timesteps is a size error
     rc = lib.rr_abc_simulate(p, 2_000_000_001, 0.0, p, 1, p, None, None, None)
     assert rc == -2 and b"exceeds 2e9" in lib.rr_last_error()
+    # storages come with the discharge, as the reference's return_storage
+    # returns them (the kernels are built for those combinations only)
+    rc = lib.rr_abc_simulate(p, 4, 0.0, p, 1, None, p, None, None)
+    assert rc == -1 and b"come with qsim" in lib.rr_last_error()
     # empty problems succeed trivially
     assert lib.rr_abc_simulate(p, 0, 0.0, p, 1, p, None, None, None) == 0
 
