@@ -977,18 +977,22 @@ static int hbv_launch(const double *temp, const double *prec,
     // SIMD tiles lose -- nobody covers an item's own latencies: 125k sets 2.82
     // ms untiled, 3.31 with 11 pieces.)  RR_OPT_TIME_TILES: -1 by sweep size,
     // 0 never, k > 1 pieces.
+    // The plain loop exists in the persistent form only: where it is not
+    // tiled (a pinned variant 0 on a small sweep, RR_OPT_TIME_TILES = 0, a
+    // series of a few days) the same kernel runs with one piece -- the tests
+    // that pin variant 0 exercise the kernel the big sweeps run.
     int pieces = 0;
-    {
+    if (variant == 0) {
         const int64_t opt = rr_option(RR_OPT_TIME_TILES);
-        if (variant == 0 && T > 16 &&
-            waves * (opt > 1 ? opt : 64) < 0x7fffffff) {
+        pieces = 1;
+        if (T > 16 && waves * (opt > 1 ? opt : 64) < 0x7fffffff) {
             if (opt > 1) pieces = (int)opt;
             else if (opt < 0 && waves > many_waves) pieces = 4;
         }
     }
     int *queue = nullptr;
     double *tile_state = nullptr;
-    if (pieces > 1) {
+    if (pieces > 0) {
         queue = (int *)((char *)workspace + hbv_forcing_bytes(T, C));
         tile_state = (double *)((char *)queue + hbv_queue_bytes(N, C));
         RR_HIP(hipMemsetAsync(queue, 0, hbv_queue_bytes(N, C), st));
@@ -997,35 +1001,34 @@ static int hbv_launch(const double *temp, const double *prec,
                  [&](auto Q, auto S, auto E) {
         auto go = [&](auto V) {
             if constexpr (V.value == 0) {
-                if (pieces > 1) {
-                    auto kern = C == 1 ? hbvedu_kernel<Q.value, S.value,
-                                                       E.value, 0, true, 1>
-                                       : hbvedu_kernel<Q.value, S.value,
-                                                       E.value, 0, true, 2>;
-                    // as many waves as are resident at once, no more
-                    int per_cu = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                            &per_cu, kern, RR_BLOCK, 0) != hipSuccess ||
-                        per_cu < 1) {
-                        (void)hipGetLastError();
-                        per_cu = 16;
-                    }
-                    int64_t resident = (int64_t)per_cu * (simds / 4);
-                    const int64_t items = (int64_t)pieces * waves;
-                    if (resident > items) resident = items;
-                    kern<<<dim3((unsigned)resident), dim3(RR_BLOCK), 0, st>>>(
-                        days, T, snow_init, soil_init, s1_init, s2_init, inits,
-                        params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
-                        day_flags, dtemp_raw, queue, tile_state, pieces,
-                        (int)C, warm);
-                    return;
+                auto kern = C == 1 ? hbvedu_kernel<Q.value, S.value, E.value,
+                                                   0, true, 1>
+                                   : hbvedu_kernel<Q.value, S.value, E.value,
+                                                   0, true, 2>;
+                // as many waves as are resident at once, no more
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                        &per_cu, kern, RR_BLOCK, 0) != hipSuccess ||
+                    per_cu < 1) {
+                    (void)hipGetLastError();
+                    per_cu = 16;
                 }
-            }
-            hbvedu_kernel<Q.value, S.value, E.value, V.value, true>
-                <<<grid, dim3(RR_BLOCK), 0, st>>>(
+                int64_t resident = (int64_t)per_cu * (simds / 4);
+                const int64_t items = (int64_t)pieces * waves;
+                if (resident > items) resident = items;
+                kern<<<dim3((unsigned)resident), dim3(RR_BLOCK), 0, st>>>(
                     days, T, snow_init, soil_init, s1_init, s2_init, inits,
                     params, N, qsim, snow, soil, s1, s2, ld, qobs, sse,
-                    day_flags, dtemp_raw, nullptr, nullptr, 0, (int)C, warm);
+                    day_flags, dtemp_raw, queue, tile_state, pieces, (int)C,
+                    warm);
+            } else {
+                hbvedu_kernel<Q.value, S.value, E.value, V.value, true>
+                    <<<grid, dim3(RR_BLOCK), 0, st>>>(
+                        days, T, snow_init, soil_init, s1_init, s2_init,
+                        inits, params, N, qsim, snow, soil, s1, s2, ld, qobs,
+                        sse, day_flags, dtemp_raw, nullptr, nullptr, 0,
+                        (int)C, warm);
+            }
         };
         if (variant == 3) go(std::integral_constant<int, 3>{});
         else go(std::integral_constant<int, 0>{});
